@@ -1,0 +1,127 @@
+/*
+ * nr_hip.h -- C ABI of libnr_hip.so: the MI355X (gfx950) rasterizer hot path of neural_renderer.
+ *
+ * Drop-in boundary.  The reference launches its stages through
+ *     chainer.cuda.elementwise(in_params, out_params, body, name)(loop, *arrays)
+ * i.e. CuPy's ElementwiseKernel FFI: raw device arrays + constants pasted into the source, launched
+ * asynchronously on the current stream.  Each entry point below replaces one such launch site and is
+ * named after the reference method that owns it (reference = /root/reference/neural_renderer/rasterize.py):
+ *
+ *   nr_forward_face_index_map    <- Rasterize.forward_face_index_map_gpu   rasterize.py:94-359  (K1+K2)
+ *   nr_forward_texture_sampling  <- Rasterize.forward_texture_sampling      rasterize.py:361-438 (K4)
+ *                                   + forward_background_gpu / forward_alpha_map_gpu  :440-465   (K5)
+ *   nr_backward_pixel_map        <- Rasterize.backward_pixel_map_gpu        rasterize.py:517-748 (K6)
+ *   nr_backward_textures         <- Rasterize.backward_textures_gpu         rasterize.py:750-792 (K7)
+ *   nr_backward_depth_map        <- Rasterize.backward_depth_map_gpu        rasterize.py:794-847 (K8)
+ *
+ * Conventions
+ *   - plain device pointers (hipMalloc / torch caching allocator memory), C-contiguous, float32 / int32;
+ *     sizes are int32; near / far / eps are doubles because the reference pastes their Python repr into
+ *     the kernel source as double literals (rasterize.py:226-234, 428-433, 737-743).
+ *   - the library owns no memory and keeps no global mutable state: outputs, residuals and scratch
+ *     ("workspace", size from nr_*_workspace_bytes) all belong to the caller.
+ *   - every launch goes to `stream` (a hipStream_t passed as void*; NULL = the null stream), is
+ *     asynchronous, and never synchronises the device.  Functions are re-entrant and thread-safe.
+ *   - return value: 0 on success; < 0 argument error (NR_E_*); > 0 a hipError_t from the launch.
+ *     nr_error_string() renders either.
+ *   - layouts (B batch, F faces, S raster size, ts texture size):
+ *       faces [B,F,3,3] xyz per vertex: x,y in NDC (y up), z = positive camera depth
+ *       textures / grad_textures [B,F,ts,ts,ts,3]
+ *       face_index_map [B,S,S] int32 (-1 = no face), weight_map [B,S,S,3], depth_map [B,S,S],
+ *       face_inv_map [B,S,S,3,3], rgb_map / grad_rgb_map [B,S,S,3], alpha_map / grad_alpha_map [B,S,S],
+ *       sampling_index_map [B,S,S,8] int32, sampling_weight_map [B,S,S,8]; row 0 is the BOTTOM row
+ *       (the public Python API flips afterwards, rasterize.py:956-960).
+ */
+#ifndef NR_HIP_H
+#define NR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NR_VERSION 100 /* 0.1.0 */
+
+/* argument errors */
+#define NR_E_NULL (-1)      /* a required pointer is NULL */
+#define NR_E_SIZE (-2)      /* a size is out of range (B,F,S < 1, S > 16384, ts < 2, index overflow) */
+#define NR_E_WORKSPACE (-3) /* workspace missing or too small */
+#define NR_E_MODE (-4)      /* nothing to do / inconsistent optional arguments */
+
+/* flags for nr_forward_texture_sampling / nr_backward_textures */
+#define NR_FLAG_FIX_TEXTURE_BATCH_Z 1 /* read the face's z from the pixel's own batch element instead of
+                                         batch 0 (the reference reads batch 0: rasterize.py:389) */
+
+int nr_version(void);
+const char *nr_error_string(int code);
+
+/* Scratch needed by nr_forward_face_index_map: per-face inverse matrices (the reference's `faces_inv`,
+ * rasterize.py:240) plus per-face screen-space bounding boxes. */
+size_t nr_forward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_t image_size);
+
+/* Scratch needed by nr_backward_pixel_map (transposed copies of the maps for the vertical sweeps). */
+size_t nr_backward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_t image_size,
+                                   int32_t return_rgb, int32_t return_alpha);
+
+/*
+ * Visibility (K1+K2, rasterize.py:240-359; tie rule "min depth, then lowest face index").
+ * Writes EVERY element of face_index_map (-1 where empty), weight_map (0), depth_map (far) and, when
+ * non-NULL, face_inv_map (0) -- the caller need not pre-fill them (the reference does, :478-496).
+ * weight_map, depth_map and face_inv_map may each be NULL when the caller does not need them.
+ */
+int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map,
+                              float *face_inv_map, int32_t batch_size, int32_t num_faces, int32_t image_size,
+                              double near, double far, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Shading (K4 + K5, rasterize.py:361-465): trilinear sampling of the winning face's texture cube,
+ * background blending and alpha.  rgb_map (needs faces, textures, weight_map, depth_map, background)
+ * and alpha_map are each optional (NULL = not requested) but at least one must be given.
+ * background: 3 floats, or batch_size*3 floats when bg_per_batch != 0 (device memory).
+ * sampling_index_map / sampling_weight_map: optional residuals of the reference (:394-395); zero where empty.
+ */
+int nr_forward_texture_sampling(const float *faces, const float *textures, const int32_t *face_index_map,
+                                const float *weight_map, const float *depth_map, float *rgb_map,
+                                int32_t *sampling_index_map, float *sampling_weight_map, const float *background,
+                                int32_t bg_per_batch, float *alpha_map, int32_t batch_size, int32_t num_faces,
+                                int32_t image_size, int32_t texture_size, double eps, int32_t flags, void *stream);
+
+/*
+ * Approximate gradient of rgb / alpha w.r.t. vertex x, y (K6, rasterize.py:517-748).
+ * STORES every element of grad_faces [B,F,3,3] (z components and back faces = 0), like the reference
+ * (:736 after the zero fill of :851).  rgb_map must be the post-background map.
+ * return_rgb / return_alpha select the terms; the matching map and gradient pointers must be non-NULL.
+ */
+int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
+                          const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
+                          float *grad_faces, int32_t batch_size, int32_t num_faces, int32_t image_size, double eps,
+                          int32_t return_rgb, int32_t return_alpha, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
+/*
+ * Texture gradient (K7, rasterize.py:750-792): ACCUMULATES w * grad_rgb into the 8 sampled texels of
+ * grad_textures (caller zero-fills, :853).  If both sampling maps are given they are used as in the
+ * reference; if both are NULL the indices/weights are recomputed from faces, weight_map, depth_map, eps
+ * and flags with the forward's arithmetic (saves 64 B/pixel of residuals).
+ */
+int nr_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
+                         const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                         const float *depth_map, const float *grad_rgb_map, float *grad_textures,
+                         int32_t batch_size, int32_t num_faces, int32_t image_size, int32_t texture_size, double eps,
+                         int32_t flags, void *stream);
+
+/*
+ * Depth gradient (K8, rasterize.py:794-847): ACCUMULATES into grad_faces (run after nr_backward_pixel_map,
+ * :881-883).  face_inv_map may be NULL: the per-face inverse is then recomputed from faces with the
+ * forward's arithmetic (saves 36 B/pixel of residuals).
+ */
+int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
+                          const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
+                          float *grad_faces, int32_t batch_size, int32_t num_faces, int32_t image_size, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NR_HIP_H */

@@ -1,0 +1,48 @@
+"""Build libnr_hip.so (the C-ABI library of include/nr_hip.h) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container; the resulting .so is
+git-ignored but travels to the GPU box with the working tree.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = [os.path.join(HERE, 'csrc', 'nr_kernels.hip')]
+HEADERS = [os.path.join(os.path.dirname(HERE), 'include', 'nr_hip.h')]
+LIB_PATH = os.path.join(HERE, 'libnr_hip.so')
+
+# -ffp-contract=off + correctly rounded division: the parity contract (DESIGN.md "Numerics").
+# -munsafe-fp-atomics: hardware global_atomic_add_f32 instead of a CAS loop (torch memory is coarse-grained).
+HIPCC_FLAGS = [
+    '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
+    '-fhip-fp32-correctly-rounded-divide-sqrt', '-munsafe-fp-atomics', '-fno-fast-math',
+    '-fPIC', '-shared', '-fvisibility=hidden',
+]
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS + [os.path.abspath(__file__)])
+
+
+def build(force=False, verbose=False):
+    """Compile if the library is missing or older than its sources. Returns the library path."""
+    if force or needs_build():
+        cmd = [hipcc()] + HIPCC_FLAGS + SOURCES + ['-o', LIB_PATH]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

@@ -1,0 +1,62 @@
+"""ctypes binding of libnr_hip.so (include/nr_hip.h).  The product path has NO fallback: if the HIP
+library is missing or an entry point fails, this raises."""
+import ctypes
+import os
+
+from . import _build
+
+_c = ctypes
+_vp, _i32, _f64, _sz = _c.c_void_p, _c.c_int32, _c.c_double, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/nr_hip.h one to one
+SIGNATURES = {
+    'nr_version': (_c.c_int, []),
+    'nr_error_string': (_c.c_char_p, [_c.c_int]),
+    'nr_forward_workspace_bytes': (_sz, [_i32, _i32, _i32]),
+    'nr_backward_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    'nr_forward_face_index_map': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f64, _f64, _vp, _sz, _vp]),
+    'nr_forward_texture_sampling': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32,
+                                               _i32, _i32, _f64, _i32, _vp]),
+    'nr_backward_pixel_map': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f64, _i32, _i32, _vp,
+                                         _sz, _vp]),
+    'nr_backward_textures': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _i32,
+                                        _vp]),
+    'nr_backward_depth_map': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+}
+
+NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
+
+_lib = None
+
+
+class NRError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (never build implicitly at import on a GPU box: the .so ships in-tree; build() exists for that)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise NRError('%s not found: build it with `python -m neural_renderer_amd._build` '
+                      '(or __graft_entry__.build()); there is no CPU/eager fallback.' % path)
+    lib = _c.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().nr_error_string(code)
+        raise NRError('%s failed (%d): %s' % (what, code, msg.decode() if msg else '?'))
+
+
+def ptr(t):
+    """data_ptr of a tensor or None."""
+    return None if t is None else t.data_ptr()

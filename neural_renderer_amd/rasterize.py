@@ -1,0 +1,288 @@
+"""Rasterizer operator: the reference's `neural_renderer/rasterize.py` API on PyTorch-ROCm tensors,
+backed by the hand-written HIP kernels of libnr_hip.so (include/nr_hip.h) through ctypes.
+
+Mirrors (reference file:line):
+  Rasterize(image_size, near, far, eps, background_color, return_rgb, return_alpha, return_depth)
+      rasterize.py:19-64 (constructor), :467-513 (forward_gpu), :849-889 (backward_gpu)
+  rasterize_rgbad / rasterize / rasterize_silhouettes / rasterize_depth      rasterize.py:900-1060
+  use_unsafe_rasterizer                                                        rasterize.py:1063-1065
+  module defaults                                                              rasterize.py:7-16
+
+There is no CPU path (the reference has none either: rasterize.py:893-897) and no eager fallback.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F_
+
+from . import _lib
+
+DEFAULT_IMAGE_SIZE = 256
+DEFAULT_ANTI_ALIASING = True
+DEFAULT_NEAR = 0.1
+DEFAULT_FAR = 100
+DEFAULT_EPS = 1e-4
+DEFAULT_BACKGROUND_COLOR = (0, 0, 0)
+USE_UNSAFE_IMPLEMENTATION = False
+
+if 'NEURAL_RENDERER_UNSAFE' in os.environ and int(os.environ['NEURAL_RENDERER_UNSAFE']):
+    USE_UNSAFE_IMPLEMENTATION = True
+
+# the reference samples textures with the face depth of batch element 0
+# (rasterize.py:389).  Default = reference-literal; NR_FIX_TEXTURE_BATCH_Z=1 (or the `fix_batch_z`
+# attribute of a Rasterize instance) uses the pixel's own batch element.
+FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _RasterizeFunction(torch.autograd.Function):
+    """forward(ctx, faces, textures, cfg) -> (rgb_map [B,S,S,3] | None, alpha_map [B,S,S] | None,
+    depth_map [B,S,S] | None); backward(ctx, g_rgb, g_alpha, g_depth) -> (grad_faces, grad_textures, None)."""
+
+    @staticmethod
+    def forward(ctx, faces, textures, cfg):
+        lib = _lib.load()
+        if not faces.is_cuda:
+            raise NotImplementedError('neural_renderer_amd has no CPU rasterizer (neither has the reference: '
+                                      'rasterize.py:893-897)')
+        if faces.dtype != torch.float32 or faces.dim() != 4 or tuple(faces.shape[2:]) != (3, 3):
+            raise ValueError('faces must be float32 [batch size, num of faces, 3, 3], got %s %s'
+                             % (faces.dtype, tuple(faces.shape)))
+        return_rgb, return_alpha, return_depth = cfg['return_rgb'], cfg['return_alpha'], cfg['return_depth']
+        dev = faces.device
+        faces_c = faces.detach().contiguous()  # rasterize.py:470
+        B, F = faces_c.shape[:2]
+        S = int(cfg['image_size'])
+        ts = 0
+        textures_c = None
+        if return_rgb:
+            if textures is None:
+                raise ValueError('textures are required when return_rgb is set')
+            if (textures.dtype != torch.float32 or textures.dim() != 6 or textures.shape[0] != B or
+                    textures.shape[1] != F or textures.shape[2] < 2 or textures.shape[2] != textures.shape[3] or
+                    textures.shape[3] != textures.shape[4] or textures.shape[5] != 3):
+                raise ValueError('textures must be float32 [batch size, num of faces, ts, ts, ts, 3] with ts >= 2, '
+                                 'got %s %s' % (textures.dtype, tuple(textures.shape)))  # rasterize.py:78-90
+            textures_c = textures.detach().contiguous()  # :473
+            ts = int(textures_c.shape[2])
+
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            need_wd = return_rgb or return_depth
+            face_index_map = torch.empty((B, S, S), dtype=torch.int32, device=dev)
+            weight_map = torch.empty((B, S, S, 3), dtype=torch.float32, device=dev) if need_wd else None
+            depth_map = torch.empty((B, S, S), dtype=torch.float32, device=dev) if need_wd else None
+            ws_bytes = lib.nr_forward_workspace_bytes(B, F, S)
+            if ws_bytes == 0:
+                raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
+            workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _lib.check(lib.nr_forward_face_index_map(
+                faces_c.data_ptr(), face_index_map.data_ptr(), _lib.ptr(weight_map), _lib.ptr(depth_map), None,
+                B, F, S, float(cfg['near']), float(cfg['far']), workspace.data_ptr(), ws_bytes, stream),
+                'nr_forward_face_index_map')
+
+            rgb_map = alpha_map = background = None
+            bg_per_batch = 0
+            if return_rgb:
+                rgb_map = torch.empty((B, S, S, 3), dtype=torch.float32, device=dev)
+                bg = cfg['background_color']
+                if torch.is_tensor(bg):
+                    background = bg.detach().to(device=dev, dtype=torch.float32).contiguous()
+                else:
+                    background = torch.as_tensor(np.asarray(bg, dtype=np.float32), device=dev)
+                if tuple(background.shape) == (B, 3):
+                    bg_per_batch = 1  # rasterize.py:464-465
+                elif tuple(background.shape) != (3,):
+                    raise ValueError('background_color must have shape (3,) or (batch size, 3)')
+            if return_alpha:
+                alpha_map = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+            flags = _lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg['fix_batch_z'] else 0
+            if return_rgb or return_alpha:
+                _lib.check(lib.nr_forward_texture_sampling(
+                    faces_c.data_ptr(), _lib.ptr(textures_c), face_index_map.data_ptr(), _lib.ptr(weight_map),
+                    _lib.ptr(depth_map), _lib.ptr(rgb_map), None, None, _lib.ptr(background), bg_per_batch,
+                    _lib.ptr(alpha_map), B, F, S, ts, float(cfg['eps']), flags, stream),
+                    'nr_forward_texture_sampling')
+
+        ctx.cfg = dict(cfg, B=B, F=F, S=S, ts=ts, flags=flags)
+        # residuals (the reference keeps them on `self`, rasterize.py:39-58); outputs among them go through
+        # save_for_backward so that in-place edits by the caller are detected
+        ctx.save_for_backward(faces_c, face_index_map, weight_map, depth_map, rgb_map, alpha_map)
+        ctx.mark_non_differentiable(face_index_map)
+        outs = (rgb_map if return_rgb else None, alpha_map if return_alpha else None,
+                depth_map if return_depth else None, face_index_map)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth, _g_fi):
+        lib = _lib.load()
+        cfg = ctx.cfg
+        B, F, S, ts = cfg['B'], cfg['F'], cfg['S'], cfg['ts']
+        faces_c, face_index_map, weight_map, depth_map, rgb_map, alpha_map = ctx.saved_tensors
+        dev = faces_c.device
+        # None gradients are zeros (rasterize.py:858-878); a zero gradient adds exactly 0 to every
+        # `diff_grad`, so the corresponding term is skipped instead of being multiplied out.
+        use_rgb = cfg['return_rgb'] and g_rgb is not None
+        use_alpha = cfg['return_alpha'] and g_alpha is not None
+        use_depth = cfg['return_depth'] and g_depth is not None
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            if use_rgb:
+                g_rgb = g_rgb.contiguous()
+            if use_alpha:
+                g_alpha = g_alpha.contiguous()
+            if use_depth:
+                g_depth = g_depth.contiguous()
+            if use_rgb or use_alpha:
+                grad_faces = torch.empty_like(faces_c)  # K6 stores every element
+                ws_bytes = lib.nr_backward_workspace_bytes(B, F, S, int(use_rgb), int(use_alpha))
+                workspace = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+                _lib.check(lib.nr_backward_pixel_map(
+                    faces_c.data_ptr(), face_index_map.data_ptr(), _lib.ptr(rgb_map) if use_rgb else None,
+                    _lib.ptr(alpha_map) if use_alpha else None, _lib.ptr(g_rgb) if use_rgb else None,
+                    _lib.ptr(g_alpha) if use_alpha else None, grad_faces.data_ptr(), B, F, S, float(cfg['eps']),
+                    int(use_rgb), int(use_alpha), workspace.data_ptr(), ws_bytes, stream), 'nr_backward_pixel_map')
+            else:
+                grad_faces = torch.zeros_like(faces_c)  # rasterize.py:851
+            grad_textures = None
+            if use_rgb and ctx.needs_input_grad[1]:
+                grad_textures = torch.zeros((B, F, ts, ts, ts, 3), dtype=torch.float32, device=dev)  # :853
+                _lib.check(lib.nr_backward_textures(
+                    face_index_map.data_ptr(), None, None, faces_c.data_ptr(), weight_map.data_ptr(),
+                    depth_map.data_ptr(), g_rgb.data_ptr(), grad_textures.data_ptr(), B, F, S, ts,
+                    float(cfg['eps']), cfg['flags'], stream), 'nr_backward_textures')
+            if use_depth:
+                _lib.check(lib.nr_backward_depth_map(
+                    faces_c.data_ptr(), depth_map.data_ptr(), face_index_map.data_ptr(), None,
+                    weight_map.data_ptr(), g_depth.data_ptr(), grad_faces.data_ptr(), B, F, S, stream),
+                    'nr_backward_depth_map')
+        return grad_faces, grad_textures, None
+
+
+class Rasterize(object):
+    """Same constructor and call convention as the reference's `Rasterize` chainer.Function
+    (rasterize.py:19-64): `Rasterize(...)(faces[, textures]) -> (rgb, alpha, depth)` in the internal
+    layout (rgb [B,S,S,3], alpha/depth [B,S,S], row 0 = bottom), `None` for outputs not requested.
+    The intermediate maps of the last call stay on the instance like in the reference (:54-58)."""
+
+    def __init__(self, image_size, near, far, eps, background_color, return_rgb=False, return_alpha=False,
+                 return_depth=False):
+        if not any((return_rgb, return_alpha, return_depth)):
+            # nothing to draw (rasterize.py:25-27 raises a bare Exception)
+            raise Exception('nothing to draw: none of return_rgb / return_alpha / return_depth is set')
+        self.image_size = image_size
+        self.near = near
+        self.far = far
+        self.eps = eps
+        self.background_color = background_color
+        self.return_rgb = return_rgb
+        self.return_alpha = return_alpha
+        self.return_depth = return_depth
+        self.fix_batch_z = FIX_TEXTURE_BATCH_Z
+        self.face_index_map = None
+
+    def __call__(self, faces, textures=None):
+        cfg = dict(image_size=self.image_size, near=self.near, far=self.far, eps=self.eps,
+                   background_color=self.background_color if self.background_color is not None
+                   else DEFAULT_BACKGROUND_COLOR,
+                   return_rgb=bool(self.return_rgb), return_alpha=bool(self.return_alpha),
+                   return_depth=bool(self.return_depth), fix_batch_z=bool(self.fix_batch_z))
+        if not self.return_rgb:
+            textures = None
+        rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg)
+        self.face_index_map = fi
+        return rgb, alpha, depth
+
+
+def rasterize_rgbad(
+        faces,
+        textures=None,
+        image_size=DEFAULT_IMAGE_SIZE,
+        anti_aliasing=DEFAULT_ANTI_ALIASING,
+        near=DEFAULT_NEAR,
+        far=DEFAULT_FAR,
+        eps=DEFAULT_EPS,
+        background_color=DEFAULT_BACKGROUND_COLOR,
+        return_rgb=True,
+        return_alpha=True,
+        return_depth=True,
+):
+    """RGB, alpha and depth images from faces (and textures for RGB) -- reference rasterize.py:900-977.
+
+    Returns a dict with 'rgb' [B, 3, image_size, image_size], 'alpha' and 'depth' [B, image_size, image_size]
+    (None when not requested)."""
+    inputs = [faces] if textures is None else [faces, textures]
+    size = image_size * 2 if anti_aliasing else image_size  # 2x super-sampling, :945-951
+    rgb, alpha, depth = Rasterize(size, near, far, eps, background_color, return_rgb, return_alpha,
+                                  return_depth)(*inputs)
+    # transpose & vertical flip, :953-960
+    if return_rgb:
+        rgb = torch.flip(rgb.permute(0, 3, 1, 2), dims=[2])
+    if return_alpha:
+        alpha = torch.flip(alpha, dims=[1])
+    if return_depth:
+        depth = torch.flip(depth, dims=[1])
+    if anti_aliasing:  # 0.5x down-sampling, :962-969
+        if return_rgb:
+            rgb = F_.avg_pool2d(rgb, 2, 2)
+        if return_alpha:
+            alpha = F_.avg_pool2d(alpha[:, None, :, :], 2, 2)[:, 0]
+        if return_depth:
+            depth = F_.avg_pool2d(depth[:, None, :, :], 2, 2)[:, 0]
+    return {
+        'rgb': rgb if return_rgb else None,
+        'alpha': alpha if return_alpha else None,
+        'depth': depth if return_depth else None,
+    }
+
+
+def rasterize(
+        faces,
+        textures,
+        image_size=DEFAULT_IMAGE_SIZE,
+        anti_aliasing=DEFAULT_ANTI_ALIASING,
+        near=DEFAULT_NEAR,
+        far=DEFAULT_FAR,
+        eps=DEFAULT_EPS,
+        background_color=DEFAULT_BACKGROUND_COLOR,
+):
+    """RGB images [B, 3, image_size, image_size] -- reference rasterize.py:980-1008."""
+    return rasterize_rgbad(
+        faces, textures, image_size, anti_aliasing, near, far, eps, background_color, True, False, False)['rgb']
+
+
+def rasterize_silhouettes(
+        faces,
+        image_size=DEFAULT_IMAGE_SIZE,
+        anti_aliasing=DEFAULT_ANTI_ALIASING,
+        near=DEFAULT_NEAR,
+        far=DEFAULT_FAR,
+        eps=DEFAULT_EPS,
+):
+    """Alpha channels [B, image_size, image_size] -- reference rasterize.py:1011-1034."""
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, True, False)['alpha']
+
+
+def rasterize_depth(
+        faces,
+        image_size=DEFAULT_IMAGE_SIZE,
+        anti_aliasing=DEFAULT_ANTI_ALIASING,
+        near=DEFAULT_NEAR,
+        far=DEFAULT_FAR,
+        eps=DEFAULT_EPS,
+):
+    """Depth images [B, image_size, image_size] -- reference rasterize.py:1037-1060."""
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, False, True)['depth']
+
+
+def use_unsafe_rasterizer(flag):
+    """Kept for API compatibility (rasterize.py:1063-1065).  The reference's "unsafe" kernel is a
+    per-face scan conversion with a per-pixel spin lock and an order-dependent tie rule; this
+    implementation's only rasterizer already culls by screen-space boxes and is deterministic, so the
+    flag selects nothing."""
+    global USE_UNSAFE_IMPLEMENTATION
+    USE_UNSAFE_IMPLEMENTATION = flag

@@ -1,0 +1,101 @@
+"""Test-side driver of the C ABI (include/nr_hip.h): torch tensors in, numpy arrays out.  Used by the
+`-m gpu` parity tests so that they exercise exactly the entry points a reference-side binding would."""
+import numpy as np
+import torch
+
+from neural_renderer_amd import _lib
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def forward(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, background=(0, 0, 0), flags=0,
+            return_rgb=False, return_alpha=True, return_depth=False, want_face_inv=False, want_sampling=False):
+    """Runs nr_forward_face_index_map (+ nr_forward_texture_sampling). Returns dict of device tensors."""
+    lib = _lib.load()
+    f = dev(faces, torch.float32)
+    B, F = f.shape[:2]
+    out = {'faces': f}
+    out['face_index_map'] = torch.full((B, S, S), 12345, dtype=torch.int32, device='cuda')
+    out['weight_map'] = torch.full((B, S, S, 3), float('nan'), device='cuda')
+    out['depth_map'] = torch.full((B, S, S), float('nan'), device='cuda')
+    out['face_inv_map'] = torch.full((B, S, S, 3, 3), float('nan'), device='cuda') if want_face_inv else None
+    wsb = lib.nr_forward_workspace_bytes(B, F, S)
+    assert wsb > 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+    _lib.check(lib.nr_forward_face_index_map(
+        f.data_ptr(), out['face_index_map'].data_ptr(), out['weight_map'].data_ptr(), out['depth_map'].data_ptr(),
+        _lib.ptr(out['face_inv_map']), B, F, S, near, far, ws.data_ptr(), wsb, _stream()), 'fwd fi')
+    out['workspace'] = ws
+    ts = 0
+    if return_rgb or return_alpha:
+        t = bg = None
+        per_batch = 0
+        if return_rgb:
+            t = dev(textures, torch.float32)
+            ts = t.shape[2]
+            bg = dev(np.asarray(background, np.float32))
+            per_batch = int(bg.dim() == 2)
+            out['rgb_map'] = torch.full((B, S, S, 3), float('nan'), device='cuda')
+            if want_sampling:
+                out['sampling_index_map'] = torch.full((B, S, S, 8), -7, dtype=torch.int32, device='cuda')
+                out['sampling_weight_map'] = torch.full((B, S, S, 8), float('nan'), device='cuda')
+        if return_alpha:
+            out['alpha_map'] = torch.full((B, S, S), float('nan'), device='cuda')
+        out['textures'] = t
+        _lib.check(lib.nr_forward_texture_sampling(
+            f.data_ptr(), _lib.ptr(t), out['face_index_map'].data_ptr(), out['weight_map'].data_ptr(),
+            out['depth_map'].data_ptr(), _lib.ptr(out.get('rgb_map')), _lib.ptr(out.get('sampling_index_map')),
+            _lib.ptr(out.get('sampling_weight_map')), _lib.ptr(bg), per_batch, _lib.ptr(out.get('alpha_map')),
+            B, F, S, ts, eps, flags, _stream()), 'fwd shade')
+    out.update(B=B, F=F, S=S, ts=ts, eps=eps, flags=flags)
+    return out
+
+
+def backward(fw, g_rgb=None, g_alpha=None, g_depth=None, use_sampling_maps=False, use_face_inv_map=False):
+    """Runs K6 / K7 / K8 through the ABI on the residuals of `forward`. Returns (grad_faces, grad_textures)."""
+    lib = _lib.load()
+    B, F, S, ts = fw['B'], fw['F'], fw['S'], fw['ts']
+    grad_faces = torch.full((B, F, 3, 3), float('nan'), device='cuda')
+    grad_textures = None
+    gr = dev(g_rgb, torch.float32) if g_rgb is not None else None
+    ga = dev(g_alpha, torch.float32) if g_alpha is not None else None
+    gd = dev(g_depth, torch.float32) if g_depth is not None else None
+    if gr is not None or ga is not None:
+        wsb = lib.nr_backward_workspace_bytes(B, F, S, int(gr is not None), int(ga is not None))
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device='cuda')
+        _lib.check(lib.nr_backward_pixel_map(
+            fw['faces'].data_ptr(), fw['face_index_map'].data_ptr(),
+            _lib.ptr(fw.get('rgb_map')) if gr is not None else None,
+            _lib.ptr(fw.get('alpha_map')) if ga is not None else None, _lib.ptr(gr), _lib.ptr(ga),
+            grad_faces.data_ptr(), B, F, S, fw['eps'], int(gr is not None), int(ga is not None), ws.data_ptr(), wsb,
+            _stream()), 'bwd pixel_map')
+    else:
+        grad_faces.zero_()
+    if gr is not None:
+        grad_textures = torch.zeros((B, F, ts, ts, ts, 3), device='cuda')
+        sw = fw.get('sampling_weight_map') if use_sampling_maps else None
+        si = fw.get('sampling_index_map') if use_sampling_maps else None
+        _lib.check(lib.nr_backward_textures(
+            fw['face_index_map'].data_ptr(), _lib.ptr(sw), _lib.ptr(si), fw['faces'].data_ptr(),
+            fw['weight_map'].data_ptr(), fw['depth_map'].data_ptr(), gr.data_ptr(), grad_textures.data_ptr(),
+            B, F, S, ts, fw['eps'], fw['flags'], _stream()), 'bwd textures')
+    if gd is not None:
+        fim = fw.get('face_inv_map') if use_face_inv_map else None
+        _lib.check(lib.nr_backward_depth_map(
+            fw['faces'].data_ptr(), fw['depth_map'].data_ptr(), fw['face_index_map'].data_ptr(), _lib.ptr(fim),
+            fw['weight_map'].data_ptr(), gd.data_ptr(), grad_faces.data_ptr(), B, F, S, _stream()), 'bwd depth')
+    torch.cuda.synchronize()
+    return grad_faces, grad_textures
+
+
+def host(t):
+    return None if t is None else t.detach().cpu().numpy()
