@@ -93,7 +93,7 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
     am = torch.empty((B, S, S), device=dev)
     bg = torch.zeros(3, device=dev)
     gf = torch.empty_like(faces)
-    gt = torch.zeros_like(textures)
+    gt = torch.empty_like(textures)
     wsb = lib.nr_forward_workspace_bytes(B, F, S)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     bwsb = lib.nr_backward_workspace_bytes(B, F, S, 1, 1)

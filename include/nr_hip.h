@@ -101,10 +101,12 @@ int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, con
                           void *stream);
 
 /*
- * Texture gradient (K7, rasterize.py:750-792): ACCUMULATES w * grad_rgb into the 8 sampled texels of
- * grad_textures (caller zero-fills, :853).  If both sampling maps are given they are used as in the
- * reference; if both are NULL the indices/weights are recomputed from faces, weight_map, depth_map, eps
- * and flags with the forward's arithmetic (saves 64 B/pixel of residuals).
+ * Texture gradient (K7, rasterize.py:750-792): the sum of w * grad_rgb over the 8 taps of every pixel a
+ * face owns.  STORES every element of grad_textures [B,F,ts,ts,ts,3] (zeros for faces that own no pixel):
+ * the caller's zero fill (:853) is not needed.  faces is always required (screen boxes).  If both sampling
+ * maps are given they are used as in the reference; if both are NULL the indices/weights are recomputed
+ * from faces, weight_map, depth_map, eps and flags with the forward's arithmetic (saves 64 B/pixel of
+ * residuals).
  */
 int nr_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
                          const int32_t *sampling_index_map, const float *faces, const float *weight_map,

@@ -1,0 +1,293 @@
+// nr_backward_gather.hip -- K7 backward_textures (rasterize.py:750-792) and K8 backward_depth_map
+// (rasterize.py:794-847) + their C-ABI entry points.
+//
+// The reference scatters from pixels: 24 (K7) / 9 (K8) float atomicAdds per covered pixel, all pixels of a
+// face hitting the same few addresses.  On MI355X that formulation is bound by same-address atomic
+// serialisation in L2 (measured: 0.9 ms / 0.33 ms at the headline size, profiles/r01a).  Both gradients are
+// sums over "the pixels a face owns", so here they are GATHERED per face instead:
+//   * a group of lanes (16, 64 or 256 depending on the texture size) owns one face, walks the pixels of the
+//     face's screen box (the same box the forward used), keeps the pixels whose face_index equals the face,
+//     evaluates the reference's per-pixel terms and accumulates them privately;
+//   * K7: texture_size 2 (the Renderer default) has a static tap pattern -> 24 register accumulators per
+//     lane, group reduction, one 96-byte store per face; larger cubes accumulate in LDS (double);
+//     every element of grad_textures is STORED (zeros for faces that own nothing): no zero fill, no atomics;
+//   * K8: 9 register accumulators, group reduction, one read-modify-write of the face's 9 floats by a single
+//     lane (K6 stored them before, rasterize.py:881-883): no atomics.
+// Per-pixel terms use the reference's arithmetic; the order of the additions differs (as it does between
+// any two runs of the reference, whose atomics are unordered).
+#include "nr_device.h"
+
+using namespace nr;
+
+namespace {
+
+__device__ __forceinline__ float group_sum(float v, int width)
+{
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// --------------------------------------------------------------------------------------------------
+// B2: one face per group of L lanes (L = 16 | 64 | 256, a power of two; 256 / L faces per workgroup).
+// TS2 = true: texture_size == 2 and eps > 0, so every tap index is static: corner pn -> texel
+// (pn & 1) * 4 + ((pn >> 1) & 1) * 2 + ((pn >> 2) & 1)   (floor(tif) == 0 because tif <= 1 - eps, :402).
+template <bool TS2>
+__global__ __launch_bounds__(256) void k_backward_textures_face(
+    const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
+    const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
+    const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
+    float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z, int L)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
+
+    const int tid = threadIdx.x;
+    const int grp = tid / L, sub = tid - grp * L;
+    const int gi = blockIdx.x * (256 / L) + grp;  // global face index b * F + fn
+    const bool face_ok = gi < n_faces_total;
+    const int n_tex = ts * ts * ts * 3;
+    double *acc_l = s_acc + (size_t)grp * n_tex;
+
+    float acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0.0f;
+    if (!TS2) {
+        for (int k = sub; k < n_tex; k += L) acc_l[k] = 0.0;
+        __syncthreads();
+    }
+
+    if (face_ok) {
+        const int b = gi / F, fn = gi - b * F;
+        const float *f = faces + (size_t)gi * 9;
+        const BBox bb = face_bbox(f[0], f[1], f[3], f[4], f[6], f[7], S);
+        if (bb.x_lo <= bb.x_hi) {
+            // z of the three vertices as the forward sampled them: batch 0's geometry unless fixed (:389, Q1)
+            const float *fz = faces + ((size_t)(fix_batch_z ? b : 0) * F + fn) * 9;
+            const float face_z[9] = {0, 0, fz[2], 0, 0, fz[5], 0, 0, fz[8]};
+            const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
+            const int n_px = bw * bh;
+            const size_t img = (size_t)b * S * S;
+            for (int i = sub; i < n_px; i += L) {
+                const int yy = i / bw;
+                const size_t p = img + (size_t)(bb.y_lo + yy) * S + (bb.x_lo + (i - yy * bw));
+                if (face_index_map[p] != fn) continue;
+                Taps t;
+                if (sampling_weight_map) {
+#pragma unroll
+                    for (int pn = 0; pn < 8; pn++) {
+                        t.w[pn] = sampling_weight_map[8 * p + pn];
+                        t.isc[pn] = sampling_index_map[8 * p + pn];
+                    }
+                } else {
+                    const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                    compute_taps(face_z, w, depth_map[p], ts, eps, t);
+                }
+                const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
+#pragma unroll
+                for (int pn = 0; pn < 8; pn++) {
+                    if (TS2) {
+                        acc[3 * pn + 0] += t.w[pn] * g[0];  // :780
+                        acc[3 * pn + 1] += t.w[pn] * g[1];
+                        acc[3 * pn + 2] += t.w[pn] * g[2];
+                    } else {
+                        double *q = acc_l + t.isc[pn] * 3;
+                        atomicAdd(q + 0, (double)(t.w[pn] * g[0]));
+                        atomicAdd(q + 1, (double)(t.w[pn] * g[1]));
+                        atomicAdd(q + 2, (double)(t.w[pn] * g[2]));
+                    }
+                }
+            }
+        }
+    }
+
+    if (TS2) {
+        // L == 16 here: xor-reduce inside the 16-lane row, lane 0 stores the face's 24 floats (96 B)
+#pragma unroll
+        for (int k = 0; k < 24; k++) acc[k] = group_sum(acc[k], 16);
+        if (face_ok && sub == 0) {
+            float o[24];
+#pragma unroll
+            for (int pn = 0; pn < 8; pn++) {
+                const int isc = (pn & 1) * 4 + ((pn >> 1) & 1) * 2 + ((pn >> 2) & 1);
+                o[3 * isc + 0] = acc[3 * pn + 0];
+                o[3 * isc + 1] = acc[3 * pn + 1];
+                o[3 * isc + 2] = acc[3 * pn + 2];
+            }
+            float4 *dst = reinterpret_cast<float4 *>(grad_textures + (size_t)gi * 24);
+#pragma unroll
+            for (int k = 0; k < 6; k++) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        }
+    } else {
+        __syncthreads();
+        if (face_ok) {
+            float *dst = grad_textures + (size_t)gi * n_tex;
+            for (int k = sub; k < n_tex; k += L) dst[k] = (float)acc_l[k];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// B2 (fallback, texture_size > 13): per-pixel scatter with hardware f32 atomics (-munsafe-fp-atomics =>
+// global_atomic_add_f32), the reference's own formulation (rasterize.py:750-792).  The caller's
+// zero fill is replaced by a hipMemsetAsync in the entry point.
+__global__ __launch_bounds__(256) void k_backward_textures_atomic(
+    const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
+    const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
+    const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
+    float *__restrict__ grad_textures, int F, int S, int ts, double eps, int fix_batch_z, size_t n_pixels)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const int fi = face_index_map[i];
+    if (fi < 0) return;
+    const int b = (int)(i / ((size_t)S * S));
+    Taps t;
+    if (sampling_weight_map) {
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            t.w[pn] = sampling_weight_map[8 * i + pn];
+            t.isc[pn] = sampling_index_map[8 * i + pn];
+        }
+    } else {
+        const float *face = faces + ((size_t)(fix_batch_z ? b : 0) * F + fi) * 9;
+        const float w[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
+        compute_taps(face, w, depth_map[i], ts, eps, t);
+    }
+    const float g[3] = {g_rgb[3 * i], g_rgb[3 * i + 1], g_rgb[3 * i + 2]};
+    float *gt = grad_textures + ((size_t)b * F + fi) * ts * ts * ts * 3;
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        float *p = gt + t.isc[pn] * 3;
+        atomicAdd(p + 0, t.w[pn] * g[0]);  // :780
+        atomicAdd(p + 1, t.w[pn] * g[1]);
+        atomicAdd(p + 2, t.w[pn] * g[2]);
+    }
+}
+
+
+// --------------------------------------------------------------------------------------------------
+// B3: one face per group of 16 lanes; 9 register accumulators; a single lane adds the totals onto what K6
+// stored.  The per-face inverse matrix is recomputed from the vertices with the forward's arithmetic
+// (compute_face_inv) unless the caller supplies the reference's per-pixel face_inv_map residual.
+__global__ __launch_bounds__(256) void k_backward_depth_face(
+    const float *__restrict__ faces, const float *__restrict__ depth_map, const int32_t *__restrict__ face_index_map,
+    const float *__restrict__ face_inv_map, const float *__restrict__ weight_map, const float *__restrict__ g_depth,
+    float *__restrict__ grad_faces, int n_faces_total, int F, int S)
+{
+    constexpr int L = 16;
+    const int tid = threadIdx.x;
+    const int grp = tid / L, sub = tid - grp * L;
+    const int gi = blockIdx.x * (256 / L) + grp;
+    const bool face_ok = gi < n_faces_total;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] = 0.0f;
+    bool any_box = false;
+    if (face_ok) {
+        const int b = gi / F, fn = gi - b * F;
+        const float *fp = faces + (size_t)gi * 9;
+        float f[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = fp[k];
+        const BBox bb = face_bbox(f[0], f[1], f[3], f[4], f[6], f[7], S);
+        if (bb.x_lo <= bb.x_hi) {
+            any_box = true;
+            float inv[9];
+            const float fs = (float)S;
+            const float px[3] = {to_pixel(f[0], fs), to_pixel(f[3], fs), to_pixel(f[6], fs)};
+            const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
+            compute_face_inv(px, py, inv);
+            const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
+            const int n_px = bw * bh;
+            const size_t img = (size_t)b * S * S;
+            for (int i = sub; i < n_px; i += L) {
+                const int yy = i / bw;
+                const size_t p = img + (size_t)(bb.y_lo + yy) * S + (bb.x_lo + (i - yy * bw));
+                if (face_index_map[p] != fn) continue;
+                if (face_inv_map) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) inv[k] = face_inv_map[9 * p + k];
+                }
+                const float depth = depth_map[p];
+                const float depth2 = depth * depth;
+                const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                const float gd = g_depth[p];
+                // :824-827
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float z_k = f[3 * k + 2];
+                    acc[3 * k + 2] += gd * w[k] * depth2 / (z_k * z_k);
+                }
+                // :830-837
+                float tmp[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int l = 0; l < 3; l++) tmp[k] += -inv[3 * l + k] / f[3 * l + 2];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int l = 0; l < 2; l++) acc[3 * k + l] += -gd * tmp[l] * w[k] * depth2 * (float)S / 2.0f;
+            }
+        }
+    }
+    if (__ballot(any_box) == 0ull) return;  // whole wave has nothing to add
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] = group_sum(acc[k], L);
+    if (face_ok && any_box && sub == 0) {
+        float *gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) gf[k] += acc[k];
+    }
+}
+
+}  // namespace
+
+// ====================================================================================================
+NR_API int nr_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
+                                const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                                const float *depth_map, const float *grad_rgb_map, float *grad_textures, int32_t B,
+                                int32_t F, int32_t S, int32_t ts, double eps, int32_t flags, void *stream)
+{
+    if (!face_index_map || !grad_rgb_map || !grad_textures || !faces) return NR_E_NULL;
+    if ((sampling_index_map == nullptr) != (sampling_weight_map == nullptr)) return NR_E_MODE;
+    if (!sampling_weight_map && (!weight_map || !depth_map)) return NR_E_NULL;
+    if (int e = check_sizes(B, F, S)) return e;
+    if (ts < 2 || ts > 1024) return NR_E_SIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const int fix = (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0;
+    const int n = B * F;
+    const size_t n_tex = (size_t)ts * ts * ts * 3;
+    if (ts == 2 && eps > 0.0 && !sampling_weight_map) {
+        hipLaunchKernelGGL((k_backward_textures_face<true>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st,
+                           face_index_map, sampling_weight_map, sampling_index_map, faces, weight_map, depth_map,
+                           grad_rgb_map, grad_textures, n, F, S, ts, eps, fix, 16);
+    } else if (ts <= 13) {
+        const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
+        const size_t lds = (size_t)(256 / L) * n_tex * sizeof(double);
+        hipLaunchKernelGGL((k_backward_textures_face<false>), dim3((unsigned)((n + 256 / L - 1) / (256 / L))),
+                           dim3(256), lds, st, face_index_map, sampling_weight_map, sampling_index_map, faces,
+                           weight_map, depth_map, grad_rgb_map, grad_textures, n, F, S, ts, eps, fix, L);
+    } else {
+        // huge cubes: the reference's per-pixel scatter with hardware atomics
+        const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        const size_t np = (size_t)B * S * S;
+        hipLaunchKernelGGL(k_backward_textures_atomic, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st,
+                           face_index_map, sampling_weight_map, sampling_index_map, faces, weight_map, depth_map,
+                           grad_rgb_map, grad_textures, F, S, ts, eps, fix, np);
+    }
+    return launch_status();
+}
+
+NR_API int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
+                                 const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
+                                 float *grad_faces, int32_t B, int32_t F, int32_t S, void *stream)
+{
+    if (!faces || !depth_map || !face_index_map || !weight_map || !grad_depth_map || !grad_faces) return NR_E_NULL;
+    if (int e = check_sizes(B, F, S)) return e;
+    const int n = B * F;
+    hipLaunchKernelGGL(k_backward_depth_face, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, n, F,
+                       S);
+    return launch_status();
+}

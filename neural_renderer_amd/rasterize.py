@@ -150,7 +150,7 @@ class _RasterizeFunction(torch.autograd.Function):
                 grad_faces = torch.zeros_like(faces_c)  # rasterize.py:851
             grad_textures = None
             if use_rgb and ctx.needs_input_grad[1]:
-                grad_textures = torch.zeros((B, F, ts, ts, ts, 3), dtype=torch.float32, device=dev)  # :853
+                grad_textures = torch.empty((B, F, ts, ts, ts, 3), dtype=torch.float32, device=dev)  # K7 stores all
                 _lib.check(lib.nr_backward_textures(
                     face_index_map.data_ptr(), None, None, faces_c.data_ptr(), weight_map.data_ptr(),
                     depth_map.data_ptr(), g_rgb.data_ptr(), grad_textures.data_ptr(), B, F, S, ts,

@@ -248,12 +248,16 @@ API void oracle_forward_background_alpha(const int32_t *face_index_map, float *r
  * grad_faces [B*F*9] is STORED (every face written, zeros for back faces since the caller zero-fills
  * it first, :851, and back faces `return` before the store, :540).
  * Optional visit counter (may be NULL): number of pixel visits in the two sweeps (work statistic).
+ * accumulate_double != 0 is NOT the reference: every per-pixel term is still computed with the reference's
+ * float arithmetic, but the running sums are kept in double and rounded once at the end.  It isolates the
+ * per-term arithmetic (what a parallel implementation must reproduce) from the order-dependent float
+ * summation noise of the reference's serial loop; tests use both forms.
  */
 API void oracle_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                                    const float *alpha_map, const float *grad_rgb_map,
                                    const float *grad_alpha_map, float *grad_faces, int batch_size, int num_faces,
                                    int image_size, double eps, int return_rgb, int return_alpha,
-                                   long long *visit_counter)
+                                   long long *visit_counter, int accumulate_double)
 {
     const int is = image_size;
     const long n = (long)batch_size * num_faces;
@@ -264,6 +268,7 @@ API void oracle_backward_pixel_map(const float *faces, const int32_t *face_index
         const int fn = (int)(i % num_faces);
         const float *face = faces + i * 9;
         float grad_face[9] = {0};
+        double grad_face_d[9] = {0};
 
         if (is_backside(face)) continue; /* :540 */
 
@@ -347,13 +352,13 @@ API void oracle_backward_pixel_map(const float *faces, const int32_t *face_index
                                 float dist = (float)((double)((p[1][0] - p[0][0]) / (p[1][0] - (float)d0) *
                                                               ((float)d1 - d1_cross)) * 2. / is);
                                 dist = (0 < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
-                                grad_face[pi[0] * 3 + (1 - axis)] -= diff_grad / dist;
+                                { const float term = diff_grad / dist; grad_face[pi[0] * 3 + (1 - axis)] -= term; grad_face_d[pi[0] * 3 + (1 - axis)] -= (double)term; }
                             }
                             if (p[0][0] != (float)d0) { /* :653-657 */
                                 float dist = (float)((double)((p[1][0] - p[0][0]) / ((float)d0 - p[0][0]) *
                                                               ((float)d1 - d1_cross)) * 2. / is);
                                 dist = (0 < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
-                                grad_face[pi[1] * 3 + (1 - axis)] -= diff_grad / dist;
+                                { const float term = diff_grad / dist; grad_face[pi[1] * 3 + (1 - axis)] -= term; grad_face_d[pi[1] * 3 + (1 - axis)] -= (double)term; }
                             }
                         }
                     }
@@ -392,20 +397,20 @@ API void oracle_backward_pixel_map(const float *faces, const int32_t *face_index
                                 float dist = (float)((double)((p[1][0] - p[0][0]) / (p[1][0] - (float)d0) *
                                                               ((float)d1 - d1_cross)) * 2. / is);
                                 dist = (0 < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
-                                grad_face[pi[0] * 3 + (1 - axis)] -= diff_grad / dist;
+                                { const float term = diff_grad / dist; grad_face[pi[0] * 3 + (1 - axis)] -= term; grad_face_d[pi[0] * 3 + (1 - axis)] -= (double)term; }
                             }
                             if (p[0][0] != (float)d0) { /* :724-728 */
                                 float dist = (float)((double)((p[1][0] - p[0][0]) / ((float)d0 - p[0][0]) *
                                                               ((float)d1 - d1_cross)) * 2. / is);
                                 dist = (0 < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
-                                grad_face[pi[1] * 3 + (1 - axis)] -= diff_grad / dist;
+                                { const float term = diff_grad / dist; grad_face[pi[1] * 3 + (1 - axis)] -= term; grad_face_d[pi[1] * 3 + (1 - axis)] -= (double)term; }
                             }
                         }
                     }
                 }
             }
         }
-        for (int k = 0; k < 9; k++) grad_faces[i * 9 + k] = grad_face[k]; /* :736 */
+        for (int k = 0; k < 9; k++) grad_faces[i * 9 + k] = accumulate_double ? (float)grad_face_d[k] : grad_face[k]; /* :736 */
     }
     if (visit_counter) *visit_counter = visits;
 }
@@ -416,8 +421,10 @@ API void oracle_backward_pixel_map(const float *faces, const int32_t *face_index
 API void oracle_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
                                   const int32_t *sampling_index_map, const float *grad_rgb_map,
                                   float *grad_textures, int batch_size, int num_faces, int image_size,
-                                  int texture_size)
+                                  int texture_size, double *acc_d)
 {
+    /* acc_d != NULL (NOT the reference): accumulate into this double buffer [same shape as grad_textures]
+     * instead of grad_textures; see the note on accumulate_double at K6. */
     const int is = image_size;
     const int nf = num_faces;
     const int ts = texture_size;
@@ -426,11 +433,15 @@ API void oracle_backward_textures(const int32_t *face_index_map, const float *sa
         const int face_index = face_index_map[i];
         if (0 <= face_index) {
             const int bn = (int)(i / ((long)is * is));
-            float *grad_texture = grad_textures + ((long)bn * nf + face_index) * ts * ts * ts * 3;
+            const long toff = ((long)bn * nf + face_index) * ts * ts * ts * 3;
+            float *grad_texture = grad_textures + toff;
             for (int pn = 0; pn < 8; pn++) {
                 const float w = sampling_weight_map[i * 8 + pn];
                 const int isc = sampling_index_map[i * 8 + pn];
-                for (int k = 0; k < 3; k++) grad_texture[isc * 3 + k] += w * grad_rgb_map[i * 3 + k]; /* :780 */
+                for (int k = 0; k < 3; k++) {
+                    const float term = w * grad_rgb_map[i * 3 + k]; /* :780 */
+                    if (acc_d) acc_d[toff + isc * 3 + k] += (double)term; else grad_texture[isc * 3 + k] += term;
+                }
             }
         }
     }
@@ -443,8 +454,9 @@ API void oracle_backward_textures(const int32_t *face_index_map, const float *sa
 API void oracle_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                                    const float *face_inv_map, const float *weight_map,
                                    const float *grad_depth_map, float *grad_faces, int batch_size, int num_faces,
-                                   int image_size)
+                                   int image_size, double *acc_d)
 {
+    /* acc_d != NULL (NOT the reference): add the terms to this double buffer [B*F*9] instead of grad_faces. */
     const int is = image_size;
     const int nf = num_faces;
     const long n = (long)batch_size * is * is;
@@ -459,11 +471,13 @@ API void oracle_backward_depth_map(const float *faces, const float *depth_map, c
             const float *weight = weight_map + i * 3;
             const float grad_depth = grad_depth_map[i];
             float *grad_face = grad_faces + ((long)bn * nf + fn) * 9;
+            double *grad_face_d = acc_d ? acc_d + ((long)bn * nf + fn) * 9 : 0;
 
             /* :824-827 */
             for (int k = 0; k < 3; k++) {
                 const float z_k = face[3 * k + 2];
-                grad_face[3 * k + 2] += grad_depth * weight[k] * depth2 / (z_k * z_k);
+                const float term = grad_depth * weight[k] * depth2 / (z_k * z_k);
+                if (grad_face_d) grad_face_d[3 * k + 2] += (double)term; else grad_face[3 * k + 2] += term;
             }
 
             /* :830-837 */
@@ -472,7 +486,10 @@ API void oracle_backward_depth_map(const float *faces, const float *depth_map, c
                 for (int l = 0; l < 3; l++) tmp[k] += -face_inv[3 * l + k] / face[3 * l + 2];
             for (int k = 0; k < 3; k++)
                 for (int l = 0; l < 2; l++)
-                    grad_face[3 * k + l] += -grad_depth * tmp[l] * weight[k] * depth2 * (float)is / 2.0f;
+                {
+                    const float term = -grad_depth * tmp[l] * weight[k] * depth2 * (float)is / 2.0f;
+                    if (grad_face_d) grad_face_d[3 * k + l] += (double)term; else grad_face[3 * k + l] += term;
+                }
         }
     }
 }

@@ -141,7 +141,8 @@ class Rasterize(object):
         depth_r = self.depth_map.copy() if self.return_depth else None
         return rgb_r, alpha_r, depth_r
 
-    def backward(self, grad_rgb=None, grad_alpha=None, grad_depth=None):
+    def backward(self, grad_rgb=None, grad_alpha=None, grad_depth=None, accumulate_double=False):
+        """accumulate_double: keep K6's running sums in double (NOT the reference; see nr_oracle.c)."""
         L = lib()
         bs, nf, s = self.batch_size, self.num_faces, self.image_size
         # :851-855
@@ -165,20 +166,27 @@ class Rasterize(object):
             _p(self.faces, _f32p), _p(self.face_index_map, _i32p), _p(self.rgb_map, _f32p),
             _p(self.alpha_map, _f32p), _p(g_rgb, _f32p), _p(g_alpha, _f32p), _p(self.grad_faces, _f32p),
             bs, nf, s, ctypes.c_double(self.eps), int(self.return_rgb), int(self.return_alpha),
-            ctypes.byref(visits))
+            ctypes.byref(visits), int(accumulate_double))
         self.visits = visits.value
+        _f64p = ctypes.POINTER(ctypes.c_double)
         # :882 backward_textures_gpu
         if self.return_rgb:
+            acc = np.zeros(self.grad_textures.shape, np.float64) if accumulate_double else None
             L.oracle_backward_textures(
                 _p(self.face_index_map, _i32p), _p(self.sampling_weight_map, _f32p),
                 _p(self.sampling_index_map, _i32p), _p(g_rgb, _f32p), _p(self.grad_textures, _f32p),
-                bs, nf, s, self.texture_size)
+                bs, nf, s, self.texture_size, _p(acc, _f64p))
+            if acc is not None:
+                self.grad_textures = acc.astype(np.float32)
         # :883 backward_depth_map_gpu
         if self.return_depth:
+            acc = self.grad_faces.astype(np.float64) if accumulate_double else None
             L.oracle_backward_depth_map(
                 _p(self.faces, _f32p), _p(self.depth_map, _f32p), _p(self.face_index_map, _i32p),
                 _p(self.face_inv_map, _f32p), _p(self.weight_map, _f32p), _p(g_depth, _f32p),
-                _p(self.grad_faces, _f32p), bs, nf, s)
+                _p(self.grad_faces, _f32p), bs, nf, s, _p(acc, _f64p))
+            if acc is not None:
+                self.grad_faces = acc.astype(np.float32)
         if self.return_rgb:
             return self.grad_faces, self.grad_textures
         return self.grad_faces,

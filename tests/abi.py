@@ -81,7 +81,7 @@ def backward(fw, g_rgb=None, g_alpha=None, g_depth=None, use_sampling_maps=False
     else:
         grad_faces.zero_()
     if gr is not None:
-        grad_textures = torch.zeros((B, F, ts, ts, ts, 3), device='cuda')
+        grad_textures = torch.full((B, F, ts, ts, ts, 3), float('nan'), device='cuda')  # K7 stores every element
         sw = fw.get('sampling_weight_map') if use_sampling_maps else None
         si = fw.get('sampling_index_map') if use_sampling_maps else None
         _lib.check(lib.nr_backward_textures(

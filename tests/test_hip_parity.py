@@ -143,18 +143,31 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
     check_forward(fw, fn)
     g_rgb, g_alpha, g_depth = grads_for(fn, rng, rgb, alpha, depth)
     ref = fn.backward(g_rgb, g_alpha, g_depth)
+    ref_gf, ref_gt = ref[0].copy(), (ref[1].copy() if rgb else None)
+    # same per-pixel float terms, sums carried in double: isolates term arithmetic from summation order
+    ref_dd = fn.backward(g_rgb, g_alpha, g_depth, accumulate_double=True)
+    ref_d, ref_gt_d = ref_dd[0].copy(), (ref_dd[1].copy() if rgb else None)
     gf, gt = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                           use_face_inv_map=residual_maps)
     gf = abi.host(gf)
     assert not np.isnan(gf).any()
-    err_f = H.rel_err(gf, ref[0])
-    assert err_f <= RTOL, 'grad_faces rel err %g' % err_f
+    noise = H.rel_err(ref_gf, ref_d)       # the reference's own serial-float-sum rounding noise
+    err_d = H.rel_err(gf, ref_d)           # ours vs the exactly-summed terms
+    err_f = H.rel_err(gf, ref_gf)          # ours vs the literal reference order
+    # (with depth on, K8's per-lane float partial sums add a little order noise: looser bound)
+    assert err_d <= (1e-5 if depth else 2e-6), 'grad_faces vs double-summed oracle: %g' % err_d
+    assert err_f <= RTOL + 2 * noise, 'grad_faces rel err %g (reference summation noise %g)' % (err_f, noise)
     # back faces and z (when depth is off) are exactly zero, like the reference
     if not depth:
         assert np.all(gf[..., 2] == 0)
     if rgb:
-        err_t = H.rel_err(abi.host(gt), ref[1])
-        assert err_t <= RTOL, 'grad_textures rel err %g' % err_t
+        gt = abi.host(gt)
+        assert not np.isnan(gt).any(), 'grad_textures has unwritten elements'
+        noise_t = H.rel_err(ref_gt, ref_gt_d)
+        # K7 keeps per-lane float partial sums (like the reference's float atomics): float-sum noise applies
+        assert H.rel_err(gt, ref_gt_d) <= RTOL, 'grad_textures vs double-summed oracle'
+        err_t = H.rel_err(gt, ref_gt)
+        assert err_t <= RTOL + 2 * noise_t, 'grad_textures rel err %g (summation noise %g)' % (err_t, noise_t)
     return err_f
 
 
@@ -270,5 +283,5 @@ def test_headline_size_properties():
     np.testing.assert_allclose(gf2, 2 * gf1, rtol=1e-5, atol=1e-6)
     for i in (0, 37):
         fn = oracle_forward(faces[i:i + 1], None, S, 0.1, 100, 1e-4, None, False, True, False)
-        ref, = fn.backward(None, g[i:i + 1], None)
-        assert H.rel_err(gf1[i], ref[0]) <= RTOL
+        ref_d, = fn.backward(None, g[i:i + 1], None, accumulate_double=True)
+        assert H.rel_err(gf1[i], ref_d[0]) <= 2e-6
