@@ -39,7 +39,7 @@ struct __attribute__((aligned(16))) LineRec {
 };
 
 template <bool RGB, bool ALPHA>
-__global__ __launch_bounds__(WAVE) void k_backward_pixel_map(
+__global__ __launch_bounds__(WAVE) void k_bpm_global(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     float *__restrict__ grad_faces, int F, int S, double eps, int axis_mask)
@@ -216,14 +216,431 @@ __global__ __launch_bounds__(WAVE) void k_backward_pixel_map(
     }
 }
 
-}  // namespace
+
+// ==================================================================================================
+// Band pipeline (default path).  Measurements on the headline scene (profiles/r01b) showed the global-memory
+// kernel above to be bound by memory latency and, for the vertical sweeps (axis 0, stride S), by 3x
+// cache-line amplification.  The band pipeline makes every sweep an LDS access:
+//
+//   k_mark_visible / k_compact_visible   per image, the sorted list of faces that own at least one pixel.
+//          A face that owns no pixel contributes nothing to K6 (the out sweep needs face_index[in] == fn,
+//          :604, the in sweep only counts pixels owned by fn, :707), so ~2/3 of the front faces drop out.
+//   k_bpm_band   one workgroup per (image, axis, band of W consecutive lines d0).  It
+//          1. stages the band's W x S pixels of face_index / alpha / rgb / their gradients in LDS, laid out
+//             [line][d1] so that a sweep is a contiguous LDS run whatever the axis;
+//          2. scans the image's visible faces (one per thread): for each of the 3 edges the d0 range clipped
+//             to the band gives the face's lines; an exclusive scan assigns line slots;
+//          3. sets lines up one per thread (crossing point, in/out pixels, sweep ranges, the two distance
+//             coefficients, rasterize.py:573-579, :606-609, :665-672) into 32-byte LDS records;
+//          4. sweeps: the in / out sweeps of all lines are cut into segments of <= 16 pixels; segment ids are dense
+//             (exclusive scan of the per-line segment counts), one thread walks one segment (binary search
+//             id -> line), so the work is balanced whatever the mix of short in-sweeps and border-long
+//             out-sweeps; the two partial sums of a segment are kept in double and added to per-face LDS
+//             accumulators (ds_add_f64);
+//          5. adds the per-face sums to a double scratch array [B*F][3 vertices][x|y] (global_atomic_add_f64).
+//   k_bpm_finalize   rounds the scratch sums to float and STORES grad_faces (z = 0).
+// Every per-pixel term uses the reference's arithmetic; sums are carried in double, so the result is the
+// correctly rounded sum of the reference's terms up to double round-off (run-to-run differences of the
+// atomic order are ~1e-16 relative and do not survive the final rounding in practice).
+constexpr int BAND_THREADS = 512;
+constexpr int BAND_WIN = 256;    // line records per pass
+constexpr int SEG = 16;          // pixels of a sweep walked by one thread
+
+struct __attribute__((aligned(16))) BandLine {
+    int in_rng;   // from | to << 16 (from > to: empty)
+    int out_rng;  // from | to << 16
+    int geo;      // d1_in | ld << 16 | flags << 24   (flags: 1 has out, 2 has0, 4 has1, 8 direction > 0)
+    int tgt;      // slot | v0 << 16 | v1 << 18
+    float cross, c0, c1;
+    int fn;
+};
+
+__global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict__ fi_map,
+                                                      unsigned char *__restrict__ flags, int F, int SS, size_t P)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int fi = fi_map[i];
+    if (fi >= 0) flags[(i / SS) * F + fi] = 1;
+}
+
+__global__ __launch_bounds__(1024) void k_compact_visible(const unsigned char *__restrict__ flags,
+                                                          int *__restrict__ vis_list, int *__restrict__ vis_count,
+                                                          int F)
+{
+    __shared__ int s_wcnt[16];
+    __shared__ int s_base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int base = 0; base < F; base += 1024) {
+        const int fn = base + tid;
+        const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        if (v) vis_list[(size_t)b * F + off + __popcll(m & ((1ull << lane) - 1ull))] = fn;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += s_wcnt[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) vis_count[b] = s_base;
+}
+
+// exclusive scan of one int per thread over the workgroup; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int *total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < BAND_THREADS / 64; ++w) {
+        const int c = s_tmp[w];
+        if (w < wave) woff += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+template <bool RGB, bool ALPHA>
+__global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
+    const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
+    const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
+    const int *__restrict__ vis_list, const int *__restrict__ vis_count, double *__restrict__ scratch, int F, int S,
+    int W, int SP, double eps, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int band = blockIdx.x, axis = blockIdx.y, b = blockIdx.z;
+    const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
+    const int nld = band_hi - band_lo + 1;
+
+    // ---- LDS carve-out
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
+    int *s_fi = (int *)carve((size_t)W * SP * 4);
+    float *s_al = ALPHA ? (float *)carve((size_t)W * SP * 4) : nullptr;
+    float *s_ga = ALPHA ? (float *)carve((size_t)W * SP * 4) : nullptr;
+    float *s_rgb = RGB ? (float *)carve((size_t)W * SP * 12) : nullptr;
+    float *s_grgb = RGB ? (float *)carve((size_t)W * SP * 12) : nullptr;
+    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * BAND_WIN);
+    int *s_rec = (int *)carve(4 * BAND_WIN);
+    int *s_pref = (int *)carve(4 * BAND_WIN);
+    float *s_fp = (float *)carve(4 * 6 * BAND_THREADS);  // [slot][px0 px1 px2 py0 py1 py2]
+    int *s_ffn = (int *)carve(4 * BAND_THREADS);
+    double *s_acc = (double *)carve(8 * 3 * BAND_THREADS);
+    int *s_tmp = (int *)carve(4 * 16);
+
+    // ---- 1. stage the band: LDS[(ld, d1)] = map[b][d0 = band_lo + ld][d1] (axis 1) or map[b][d1][d0] (axis 0)
+    const size_t img = (size_t)b * S * S;
+    if (!(dbg & 2)) {
+        const int n = nld * S;
+        if (axis) {  // rows are contiguous in memory
+            for (int i = tid; i < n; i += BAND_THREADS) {
+                const int ld = i / S, d1 = i - ld * S;
+                const size_t g = img + (size_t)(band_lo + ld) * S + d1;
+                const int l = ld * SP + d1;
+                s_fi[l] = fi_map[g];
+                if (ALPHA) { s_al[l] = alpha_map[g]; s_ga[l] = g_alpha[g]; }
+            }
+            if (RGB)
+                for (int i = tid; i < 3 * n; i += BAND_THREADS) {
+                    const int ld = i / (3 * S), r = i - ld * 3 * S;
+                    const size_t g = (img + (size_t)(band_lo + ld) * S) * 3 + r;
+                    const int l = ld * SP * 3 + r;
+                    s_rgb[l] = rgb_map[g];
+                    s_grgb[l] = g_rgb[g];
+                }
+        } else {  // the band is nld adjacent columns: ld fastest so that a row's segment is read contiguously
+            for (int i = tid; i < n; i += BAND_THREADS) {
+                const int d1 = i / nld, ld = i - d1 * nld;
+                const size_t g = img + (size_t)d1 * S + band_lo + ld;
+                const int l = ld * SP + d1;
+                s_fi[l] = fi_map[g];
+                if (ALPHA) { s_al[l] = alpha_map[g]; s_ga[l] = g_alpha[g]; }
+            }
+            if (RGB)
+                for (int i = tid; i < 3 * n; i += BAND_THREADS) {
+                    const int d1 = i / (3 * nld), r = i - d1 * 3 * nld;  // r = ld * 3 + channel
+                    const int ld = r / 3, ch = r - ld * 3;
+                    const size_t g = (img + (size_t)d1 * S + band_lo) * 3 + r;
+                    const int l = (ld * SP + d1) * 3 + ch;
+                    s_rgb[l] = rgb_map[g];
+                    s_grgb[l] = g_rgb[g];
+                }
+        }
+    }
+    s_acc[3 * tid] = 0.0; s_acc[3 * tid + 1] = 0.0; s_acc[3 * tid + 2] = 0.0;
+    __syncthreads();
+
+    const float fs = (float)S;
+    const double s_d = (double)S, two_over_s = 2.0 / (double)S;
+    const bool s_pow2 = (S & (S - 1)) == 0;
+    const int n_vis = vis_count[b];
+
+    for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
+        // ---- 2. one visible face per thread: lines of its 3 edges inside the band
+        int fn = -1, nl = 0;
+        int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
+        if (chunk + tid < n_vis) {
+            fn = vis_list[(size_t)b * F + chunk + tid];
+            const float *f = faces + ((size_t)b * F + fn) * 9;
+            float px[3], py[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { px[k] = to_pixel(f[3 * k], fs); py[k] = to_pixel(f[3 * k + 1], fs); }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s_fp[6 * tid + k] = px[k]; s_fp[6 * tid + 3 + k] = py[k]; }
+            s_ffn[tid] = fn;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const int i0 = e, i1 = (e + 1) % 3;
+                const float p0x = axis ? py[i0] : px[i0], p1x = axis ? py[i1] : px[i1];
+                const int d0_from = (int)fmax((double)ceilf(fminf(p0x, p1x)), 0.0);   // :568
+                const int d0_to = (int)fmin((double)fmaxf(p0x, p1x), S - 1.0);        // :569
+                const int lo = max(d0_from, band_lo), hi = min(d0_to, band_hi);
+                // p0x == p1x: the only possible d0 equals both, so both contributions are skipped (:648, :653)
+                if (p0x != p1x && hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
+            }
+        }
+        int total_lines = 0;
+        const int line_off = block_excl_scan(nl, s_tmp, &total_lines);
+
+        for (int win = 0; win < ((dbg & 4) ? 0 : total_lines); win += BAND_WIN) {
+            // ---- compact records of the lines that fall into this window
+            if (nl > 0 && line_off < win + BAND_WIN && line_off + nl > win) {
+                int k = line_off;
+#pragma unroll
+                for (int e = 0; e < 3; e++)
+                    for (int j = 0; j < e_n[e]; j++, k++)
+                        if (k >= win && k < win + BAND_WIN) s_rec[k - win] = tid | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
+            }
+            __syncthreads();
+            const int n_win = min(total_lines - win, BAND_WIN);
+
+            // ---- 3. line setup, one line per thread: rasterize.py:543-579, :604-609, :665-672
+            if (tid < n_win) {
+                const int rec = s_rec[tid];
+                const int slot = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
+                const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+                const float *fp = s_fp + 6 * slot;
+                const int ox = axis ? 3 : 0, oy = axis ? 0 : 3;  // p[num][dim] = pp[num][(dim + axis) % 2] (:556)
+                const float p0x = fp[ox + i0], p0y = fp[oy + i0], p1x = fp[ox + i1], p1y = fp[oy + i1];
+                const float p2x = fp[ox + i2], p2y = fp[oy + i2];
+                int direction;
+                if (axis == 0) direction = (p0x < p1x) ? -1 : 1; else direction = (p0x < p1x) ? 1 : -1;  // :559-564
+                const int d0 = band_lo + ld;
+                const float d0f = (float)d0;
+                BandLine r;
+                r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = slot | (i0 << 16) | (i1 << 18);
+                r.cross = r.c0 = r.c1 = 0.0f;
+                r.fn = s_ffn[slot];
+                const float d1_cross = (p1y - p0y) / (p1x - p0x) * (d0f - p0x) + p0y;                  // :573
+                const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);     // :574
+                const int d1_out = d1_in + direction;                                                 // :575
+                if (!(d1_in < 0 || S <= d1_in) && !(d1_out < 0 || S <= d1_out)) {                     // :578-579
+                    int flags = (0 < direction) ? 8 : 0;
+                    if (p1x != d0f) flags |= 2;
+                    if (p0x != d0f) flags |= 4;
+                    r.c0 = (p1x - p0x) / (p1x - d0f);  // :649 leading factor, invariant along the sweep
+                    r.c1 = (p1x - p0x) / (d0f - p0x);  // :654
+                    if (s_fi[ld * SP + d1_in] == r.fn) {  // :604-609
+                        const int lim = (0 < direction) ? S - 1 : 0;
+                        const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
+                        r.out_rng = o_from | (o_to << 16);
+                        flags |= 1;
+                    }
+                    float d0_cross2;                      // :665-672
+                    if ((d0f - p0x) * (d0f - p2x) < 0)
+                        d0_cross2 = (p2y - p0y) / (p2x - p0x) * (d0f - p0x) + p0y;
+                    else
+                        d0_cross2 = (p1y - p2y) / (p1x - p2x) * (d0f - p2x) + p2y;
+                    const int lim2 = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
+                    const int i_from = max(min(d1_in, lim2), 0), i_to = min(max(d1_in, lim2), S - 1);
+                    r.in_rng = i_from | (i_to << 16);
+                    r.geo = d1_in | (ld << 16) | (flags << 24);
+                    r.cross = d1_cross;
+                }
+                s_line[tid] = r;
+            }
+            __syncthreads();
+
+            // ---- 4. sweeps, one SEGMENT (<= SEG pixels of one sweep) per thread.  Segment ids are dense:
+            //         line l owns ids [s_pref[l], s_pref[l + 1]): first its in-sweep pieces, then its out-sweep pieces.
+            int n_seg = 0;
+            if (tid < n_win) {
+                const BandLine &L = s_line[tid];
+                const int il = (L.in_rng >> 16) - (L.in_rng & 0xffff) + 1, ol = (L.out_rng >> 16) - (L.out_rng & 0xffff) + 1;
+                n_seg = (il > 0 ? (il + SEG - 1) / SEG : 0) + (ol > 0 ? (ol + SEG - 1) / SEG : 0);
+            }
+            int total_seg = 0;
+            const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
+            if (tid < n_win) s_pref[tid] = seg_off;
+            __syncthreads();
+            for (int sid = tid; sid < ((dbg & 1) ? 0 : total_seg); sid += BAND_THREADS) {
+                // last line l with s_pref[l] <= sid
+                int lo = 0, hi = n_win - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_pref[mid] <= sid) lo = mid; else hi = mid - 1;
+                }
+                const BandLine *L = &s_line[lo];
+                const int4 h = *reinterpret_cast<const int4 *>(L);
+                const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
+                int k = sid - s_pref[lo];
+                const int in_from = h.x & 0xffff, in_to = h.x >> 16;
+                const int n_in = in_to >= in_from ? (in_to - in_from + SEG) / SEG : 0;
+                const bool mode_in = k < n_in;
+                if (!mode_in) k -= n_in;
+                const int s_from = (mode_in ? in_from : (h.y & 0xffff)) + k * SEG;
+                const int s_to = min(s_from + SEG - 1, mode_in ? in_to : (h.y >> 16));
+                const int flags = (h.z >> 24) & 0xff;
+                const int ld = (h.z >> 16) & 0xff;
+                const int d1_in = h.z & 0xffff;
+                // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
+                const int lref = ld * SP + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
+                float ref_a = 0, ref_r = 0, ref_g = 0, ref_b = 0;
+                if (ALPHA) ref_a = s_al[lref];
+                if (RGB) { ref_r = s_rgb[3 * lref]; ref_g = s_rgb[3 * lref + 1]; ref_b = s_rgb[3 * lref + 2]; }
+                const float cross = c.x, c0 = c.y, c1 = c.z;
+                const int fnr = __float_as_int(c.w);
+                double a0 = 0.0, a1 = 0.0;
+                for (int d1 = s_from; d1 <= s_to; ++d1) {  // one pixel visit: :630-657 (out) / :697-728 (in)
+                    const int l = ld * SP + d1;
+                    if (mode_in && s_fi[l] != fnr) continue;  // :707
+                    float diff = 0.0f;
+                    if (ALPHA) diff += (s_al[l] - ref_a) * s_ga[l];
+                    if (RGB) {
+                        diff += (s_rgb[3 * l] - ref_r) * s_grgb[3 * l];
+                        diff += (s_rgb[3 * l + 1] - ref_g) * s_grgb[3 * l + 1];
+                        diff += (s_rgb[3 * l + 2] - ref_b) * s_grgb[3 * l + 2];
+                    }
+                    if (diff <= 0.0f) continue;  // :647 / :717
+                    const float t = (float)d1 - cross;
+                    if (flags & 2) {  // :648-652
+                        const float ct = c0 * t;
+                        float dist = (float)(s_pow2 ? (double)ct * two_over_s : (double)ct * 2.0 / s_d);
+                        dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
+                        a0 -= (double)(diff / dist);
+                    }
+                    if (flags & 4) {  // :653-657
+                        const float ct = c1 * t;
+                        float dist = (float)(s_pow2 ? (double)ct * two_over_s : (double)ct * 2.0 / s_d);
+                        dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
+                        a1 -= (double)(diff / dist);
+                    }
+                }
+                const int slot = h.w & 0xffff;
+                if (a0 != 0.0) atomicAdd(&s_acc[3 * slot + ((h.w >> 16) & 3)], a0);
+                if (a1 != 0.0) atomicAdd(&s_acc[3 * slot + ((h.w >> 18) & 3)], a1);
+            }
+            __syncthreads();
+        }
+
+        // ---- 5. per-face sums of this chunk -> global double scratch [face][vertex][x|y]
+        if (fn >= 0) {
+            double *dst = scratch + ((size_t)b * F + fn) * 6 + (1 - axis);
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                const double a = s_acc[3 * tid + v];
+                if (a != 0.0) atomicAdd(dst + 2 * v, a);
+                s_acc[3 * tid + v] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__ scratch, float *__restrict__ grad_faces,
+                                                      int n_faces_total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_faces_total) return;
+    const double *a = scratch + (size_t)i * 6;
+    float *o = grad_faces + (size_t)i * 9;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        o[3 * v + 0] = (float)a[2 * v + 0];
+        o[3 * v + 1] = (float)a[2 * v + 1];
+        o[3 * v + 2] = 0.0f;  // K6 never touches z
+    }
+}
 
 // ====================================================================================================
+
+struct BpmLayout {
+    size_t flags_off, scratch_off, count_off, list_off, total, zero_bytes;
+};
+
+BpmLayout bpm_layout(int B, int F)
+{
+    BpmLayout L;
+    const size_t n = (size_t)B * F;
+    L.flags_off = 0;
+    L.scratch_off = align_up(n, 256);                       // flags: n bytes
+    L.zero_bytes = L.scratch_off + n * 6 * sizeof(double);  // flags + scratch are zeroed by one memset
+    L.count_off = align_up(L.zero_bytes, 256);
+    L.list_off = L.count_off + align_up((size_t)B * sizeof(int), 256);
+    L.total = L.list_off + n * sizeof(int);
+    return L;
+}
+
+constexpr size_t BAND_FIXED_LDS = sizeof(BandLine) * BAND_WIN + 8 * BAND_WIN + 4 * 6 * BAND_THREADS + 4 * BAND_THREADS +
+                                  8 * 3 * BAND_THREADS + 64 + 8 * 16;
+
+// band width (lines per workgroup) for the given raster size and modes; 0 = does not fit (global fallback)
+int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes)
+{
+    const size_t per_px = 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0);
+    const char *env = getenv("NR_K6_LDS_KB");  // tuning knob: LDS budget per workgroup (default: two per CU)
+    const size_t budget = (env ? (size_t)atoi(env) : 80) * 1024;
+    const size_t SP = (size_t)S + 4;
+    for (int W = 16; W >= 1; W >>= 1) {
+        const size_t need = (size_t)W * SP * per_px + BAND_FIXED_LDS;
+        if (need <= budget || (W == 1 && need <= 160 * 1024)) {
+            *lds_bytes = need;
+            return W;
+        }
+    }
+    return 0;
+}
+
+template <bool RGB, bool ALPHA>
+int launch_band(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
+                const float *g_alpha, const int *vis_list, const int *vis_count, double *scratch, int B, int F, int S,
+                int W, size_t lds, double eps, hipStream_t st)
+{
+    auto kern = k_bpm_band<RGB, ALPHA>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid((unsigned)((S + W - 1) / W), 2, (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha, vis_list,
+                       vis_count, scratch, F, S, W, S + 4, eps, getenv("NR_K6_DEBUG") ? atoi(getenv("NR_K6_DEBUG")) : 0);
+    return 0;
+}
+
+}  // namespace
+
 NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32_t return_rgb, int32_t return_alpha)
 {
     (void)return_rgb; (void)return_alpha;
     if (check_sizes(B, F, S)) return 0;
-    return 0;  // the first-generation kernel sweeps the row-major maps directly
+    return bpm_layout(B, F).total;
 }
 
 NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
@@ -231,27 +648,61 @@ NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_m
                                  float *grad_faces, int32_t B, int32_t F, int32_t S, double eps, int32_t return_rgb,
                                  int32_t return_alpha, void *workspace, size_t workspace_bytes, void *stream)
 {
-    (void)workspace; (void)workspace_bytes;
     if (!faces || !face_index_map || !grad_faces) return NR_E_NULL;
     if (!return_rgb && !return_alpha) return NR_E_MODE;  // rasterize.py:523-524 returns early; callers skip the call
     if (return_rgb && (!rgb_map || !grad_rgb_map)) return NR_E_NULL;
     if (return_alpha && (!alpha_map || !grad_alpha_map)) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
-    if ((size_t)B * S * S > 0x7fffffffull / 3) return NR_E_SIZE;  // int32 pixel indexing inside the kernel
-    const int n = B * F;
-    const char *am = getenv("NR_K6_AXIS_MASK");  // experiment knob (default: both axes)
-    const int axis_mask = am ? atoi(am) : 3;
-    const dim3 grid((unsigned)n), block(WAVE);
+    if ((size_t)B * S * S > 0x7fffffffull / 3) return NR_E_SIZE;  // int32 pixel indexing inside the kernels
     hipStream_t st = (hipStream_t)stream;
-    if (return_rgb && return_alpha)
-        hipLaunchKernelGGL((k_backward_pixel_map<true, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                           alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
-    else if (return_rgb)
-        hipLaunchKernelGGL((k_backward_pixel_map<true, false>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                           alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+    const int n = B * F;
+    const bool rgb = return_rgb != 0, alpha = return_alpha != 0;
+
+    size_t lds = 0;
+    const int W = band_width(S, rgb, alpha, &lds);
+    const char *force = getenv("NR_K6_GLOBAL");  // experiment knob: force the global-memory kernel
+    {
+        if (W == 0 || (force && atoi(force))) {
+            const char *am = getenv("NR_K6_AXIS_MASK");
+            const int axis_mask = am ? atoi(am) : 3;
+            const dim3 grid((unsigned)n), block(WAVE);
+            if (rgb && alpha)
+                hipLaunchKernelGGL((k_bpm_global<true, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
+                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+            else if (rgb)
+                hipLaunchKernelGGL((k_bpm_global<true, false>), grid, block, 0, st, faces, face_index_map, rgb_map,
+                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+            else
+                hipLaunchKernelGGL((k_bpm_global<false, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
+                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+            return launch_status();
+        }
+    }
+
+    const BpmLayout L = bpm_layout(B, F);
+    if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
+    unsigned char *ws = (unsigned char *)workspace;
+    unsigned char *flags = ws + L.flags_off;
+    double *scratch = (double *)(ws + L.scratch_off);
+    int *vis_count = (int *)(ws + L.count_off);
+    int *vis_list = (int *)(ws + L.list_off);
+    hipError_t he = hipMemsetAsync(ws, 0, L.zero_bytes, st);
+    if (he != hipSuccess) return (int)he;
+    const size_t P = (size_t)B * S * S;
+    hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, face_index_map, flags, F,
+                       S * S, P);
+    hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)B), dim3(1024), 0, st, flags, vis_list, vis_count, F);
+    int rc;
+    if (rgb && alpha)
+        rc = launch_band<true, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list,
+                                     vis_count, scratch, B, F, S, W, lds, eps, st);
+    else if (rgb)
+        rc = launch_band<true, false>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,
+                                      vis_list, vis_count, scratch, B, F, S, W, lds, eps, st);
     else
-        hipLaunchKernelGGL((k_backward_pixel_map<false, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                           alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+        rc = launch_band<false, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,
+                                      vis_list, vis_count, scratch, B, F, S, W, lds, eps, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, grad_faces, n);
     return launch_status();
 }
-
