@@ -244,7 +244,8 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 // atomic order are ~1e-16 relative and do not survive the final rounding in practice).
 constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per pass
-constexpr int SEG = 16;          // pixels of a sweep walked by one thread
+constexpr int SEG = 15;          // pixels of a sweep walked by one thread (odd: consecutive segments of a
+                                 // sweep start 15 dwords apart, i.e. on different LDS banks)
 
 struct __attribute__((aligned(16))) BandLine {
     int in_rng;   // from | to << 16 (from > to: empty)
@@ -347,41 +348,80 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
 
     // ---- 1. stage the band: LDS[(ld, d1)] = map[b][d0 = band_lo + ld][d1] (axis 1) or map[b][d1][d0] (axis 0)
     const size_t img = (size_t)b * S * S;
-    if (!(dbg & 2)) {
-        const int n = nld * S;
-        if (axis) {  // rows are contiguous in memory
-            for (int i = tid; i < n; i += BAND_THREADS) {
-                const int ld = i / S, d1 = i - ld * S;
-                const size_t g = img + (size_t)(band_lo + ld) * S + d1;
-                const int l = ld * SP + d1;
-                s_fi[l] = fi_map[g];
-                if (ALPHA) { s_al[l] = alpha_map[g]; s_ga[l] = g_alpha[g]; }
-            }
-            if (RGB)
-                for (int i = tid; i < 3 * n; i += BAND_THREADS) {
-                    const int ld = i / (3 * S), r = i - ld * 3 * S;
-                    const size_t g = (img + (size_t)(band_lo + ld) * S) * 3 + r;
-                    const int l = ld * SP * 3 + r;
-                    s_rgb[l] = rgb_map[g];
-                    s_grgb[l] = g_rgb[g];
+    if (axis) {  // a band line is an image row: contiguous in memory
+        const bool vec = (S & 3) == 0;
+        for (int ld = 0; ld < nld; ++ld) {
+            const size_t g0 = img + (size_t)(band_lo + ld) * S;
+            const int l0 = ld * SP;
+            if (vec) {
+                for (int x = 4 * tid; x < S; x += 4 * BAND_THREADS) {
+                    *reinterpret_cast<int4 *>(s_fi + l0 + x) = *reinterpret_cast<const int4 *>(fi_map + g0 + x);
+                    if (ALPHA) {
+                        *reinterpret_cast<float4 *>(s_al + l0 + x) = *reinterpret_cast<const float4 *>(alpha_map + g0 + x);
+                        *reinterpret_cast<float4 *>(s_ga + l0 + x) = *reinterpret_cast<const float4 *>(g_alpha + g0 + x);
+                    }
                 }
-        } else {  // the band is nld adjacent columns: ld fastest so that a row's segment is read contiguously
-            for (int i = tid; i < n; i += BAND_THREADS) {
-                const int d1 = i / nld, ld = i - d1 * nld;
+                if (RGB)
+                    for (int x = 4 * tid; x < 3 * S; x += 4 * BAND_THREADS) {
+                        *reinterpret_cast<float4 *>(s_rgb + 3 * l0 + x) = *reinterpret_cast<const float4 *>(rgb_map + 3 * g0 + x);
+                        *reinterpret_cast<float4 *>(s_grgb + 3 * l0 + x) = *reinterpret_cast<const float4 *>(g_rgb + 3 * g0 + x);
+                    }
+            } else {
+                for (int x = tid; x < S; x += BAND_THREADS) {
+                    s_fi[l0 + x] = fi_map[g0 + x];
+                    if (ALPHA) { s_al[l0 + x] = alpha_map[g0 + x]; s_ga[l0 + x] = g_alpha[g0 + x]; }
+                }
+                if (RGB)
+                    for (int x = tid; x < 3 * S; x += BAND_THREADS) {
+                        s_rgb[3 * l0 + x] = rgb_map[3 * g0 + x];
+                        s_grgb[3 * l0 + x] = g_rgb[3 * g0 + x];
+                    }
+            }
+        }
+    } else {  // a band line is an image column: the band is nld adjacent columns, read row by row
+        if (nld == 4 && (S & 3) == 0) {  // one 16-byte load per (row, field), scattered to the 4 lines
+            for (int y = tid; y < S; y += BAND_THREADS) {
+                const size_t g = img + (size_t)y * S + band_lo;
+                const int4 vf = *reinterpret_cast<const int4 *>(fi_map + g);
+                s_fi[y] = vf.x; s_fi[SP + y] = vf.y; s_fi[2 * SP + y] = vf.z; s_fi[3 * SP + y] = vf.w;
+                if (ALPHA) {
+                    const float4 va = *reinterpret_cast<const float4 *>(alpha_map + g);
+                    const float4 vg = *reinterpret_cast<const float4 *>(g_alpha + g);
+                    s_al[y] = va.x; s_al[SP + y] = va.y; s_al[2 * SP + y] = va.z; s_al[3 * SP + y] = va.w;
+                    s_ga[y] = vg.x; s_ga[SP + y] = vg.y; s_ga[2 * SP + y] = vg.z; s_ga[3 * SP + y] = vg.w;
+                }
+                if (RGB) {
+                    const float4 *pr = reinterpret_cast<const float4 *>(rgb_map + 3 * g);
+                    const float4 *pg = reinterpret_cast<const float4 *>(g_rgb + 3 * g);
+                    const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], q0 = pg[0], q1 = pg[1], q2 = pg[2];
+                    const float rr[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                    const float qq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+                    for (int ld = 0; ld < 4; ++ld)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            s_rgb[(ld * SP + y) * 3 + ch] = rr[3 * ld + ch];
+                            s_grgb[(ld * SP + y) * 3 + ch] = qq[3 * ld + ch];
+                        }
+                }
+            }
+        } else {
+            // generic: thread -> (row d1, line ld) with ld fastest; advanced incrementally (no division in the loop)
+            const int step_d1 = BAND_THREADS / nld, step_ld = BAND_THREADS - step_d1 * nld;
+            int d1 = tid / nld, ld = tid - d1 * nld;
+            while (d1 < S) {
                 const size_t g = img + (size_t)d1 * S + band_lo + ld;
                 const int l = ld * SP + d1;
                 s_fi[l] = fi_map[g];
                 if (ALPHA) { s_al[l] = alpha_map[g]; s_ga[l] = g_alpha[g]; }
-            }
-            if (RGB)
-                for (int i = tid; i < 3 * n; i += BAND_THREADS) {
-                    const int d1 = i / (3 * nld), r = i - d1 * 3 * nld;  // r = ld * 3 + channel
-                    const int ld = r / 3, ch = r - ld * 3;
-                    const size_t g = (img + (size_t)d1 * S + band_lo) * 3 + r;
-                    const int l = (ld * SP + d1) * 3 + ch;
-                    s_rgb[l] = rgb_map[g];
-                    s_grgb[l] = g_rgb[g];
+                if (RGB) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) { s_rgb[3 * l + ch] = rgb_map[3 * g + ch]; s_grgb[3 * l + ch] = g_rgb[3 * g + ch]; }
                 }
+                d1 += step_d1;
+                ld += step_ld;
+                if (ld >= nld) { ld -= nld; ++d1; }
+            }
         }
     }
     s_acc[3 * tid] = 0.0; s_acc[3 * tid + 1] = 0.0; s_acc[3 * tid + 2] = 0.0;
@@ -518,27 +558,45 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
                 const float cross = c.x, c0 = c.y, c1 = c.z;
                 const int fnr = __float_as_int(c.w);
                 double a0 = 0.0, a1 = 0.0;
-                for (int d1 = s_from; d1 <= s_to; ++d1) {  // one pixel visit: :630-657 (out) / :697-728 (in)
+                const float two_over_s_f = (float)two_over_s;  // exact when S is a power of two
+                // pixel data of the NEXT visit is fetched before the current one is evaluated, so that the LDS
+                // latency hides behind the ~100 VALU instructions of a visit (occupancy here is only 2-4 waves/SIMD)
+                struct Px { int fi; float al, ga, r, g, b, gr, gg, gb; };
+                auto fetch = [&](int d1) {
+                    Px p;
                     const int l = ld * SP + d1;
-                    if (mode_in && s_fi[l] != fnr) continue;  // :707
-                    float diff = 0.0f;
-                    if (ALPHA) diff += (s_al[l] - ref_a) * s_ga[l];
+                    p.fi = s_fi[l];
+                    p.al = p.ga = p.r = p.g = p.b = p.gr = p.gg = p.gb = 0.0f;
+                    if (ALPHA) { p.al = s_al[l]; p.ga = s_ga[l]; }
                     if (RGB) {
-                        diff += (s_rgb[3 * l] - ref_r) * s_grgb[3 * l];
-                        diff += (s_rgb[3 * l + 1] - ref_g) * s_grgb[3 * l + 1];
-                        diff += (s_rgb[3 * l + 2] - ref_b) * s_grgb[3 * l + 2];
+                        p.r = s_rgb[3 * l]; p.g = s_rgb[3 * l + 1]; p.b = s_rgb[3 * l + 2];
+                        p.gr = s_grgb[3 * l]; p.gg = s_grgb[3 * l + 1]; p.gb = s_grgb[3 * l + 2];
+                    }
+                    return p;
+                };
+                Px nxt = fetch(s_from);
+                for (int d1 = s_from; d1 <= s_to; ++d1) {  // one pixel visit: :630-657 (out) / :697-728 (in)
+                    const Px p = nxt;
+                    if (d1 < s_to) nxt = fetch(d1 + 1);
+                    if (mode_in && p.fi != fnr) continue;  // :707
+                    float diff = 0.0f;
+                    if (ALPHA) diff += (p.al - ref_a) * p.ga;
+                    if (RGB) {
+                        diff += (p.r - ref_r) * p.gr;
+                        diff += (p.g - ref_g) * p.gg;
+                        diff += (p.b - ref_b) * p.gb;
                     }
                     if (diff <= 0.0f) continue;  // :647 / :717
                     const float t = (float)d1 - cross;
-                    if (flags & 2) {  // :648-652
+                    if (flags & 2) {  // :648-652 (x * 2. / S: an exact scaling when S is a power of two)
                         const float ct = c0 * t;
-                        float dist = (float)(s_pow2 ? (double)ct * two_over_s : (double)ct * 2.0 / s_d);
+                        float dist = s_pow2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
                         dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
                         a0 -= (double)(diff / dist);
                     }
                     if (flags & 4) {  // :653-657
                         const float ct = c1 * t;
-                        float dist = (float)(s_pow2 ? (double)ct * two_over_s : (double)ct * 2.0 / s_d);
+                        float dist = s_pow2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
                         dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
                         a1 -= (double)(diff / dist);
                     }

@@ -1,9 +1,9 @@
 // nr_forward.hip -- forward kernels of the gfx950 rasterizer + their C-ABI entry points.
 //
-//   k_face_setup    F1  per face: back-face cull, inverse barycentric matrix, screen bbox        (ref K1, :240-277)
-//   k_raster_tiles  F2  per 32x32 tile: bbox-scan of the image's faces, survivors' geometry staged in LDS,
-//                       then one pixel per lane (16x4 blocks per wave) resolves min-depth over the list
-//                                                                                               (ref K2, :279-359)
+//   k_face_raster   F1+F2  per face: back-face cull, inverse matrix, screen box (ref K1, :240-277) and
+//                          rasterization of the face's pixels into a packed 64-bit z-buffer (ref K2, :279-359)
+//   k_large_raster  F2'    faces with a large screen box, one workgroup per face
+//   k_resolve       F2''   per pixel: decode the winner, write face_index / weight / depth / face_inv maps
 //   k_shade         F3  per pixel: trilinear texture sampling + background + alpha        (ref K4+K5, :361-465)
 #include "nr_device.h"
 
@@ -12,73 +12,32 @@ using namespace nr;
 namespace {
 
 // --------------------------------------------------------------------------------------------------
-// F1: workspace = inv[B*F*9] floats (the reference's `faces_inv`, zeros for back faces), then bbox[B*F].
-__global__ __launch_bounds__(256) void k_face_setup(const float *__restrict__ faces, float *__restrict__ ws_inv,
-                                                    BBox *__restrict__ ws_bbox, int n_faces_total, int S)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_faces_total) return;
-    const float *f = faces + (size_t)i * 9;
-    const float x0 = f[0], y0 = f[1], x1 = f[3], y1 = f[4], x2 = f[6], y2 = f[7];
-    float inv[9];
-    if (is_backside(x0, y0, x1, y1, x2, y2)) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) inv[k] = 0.0f;  // rasterize.py:240 zeros_like + :253 continue
-    } else {
-        const float fs = (float)S;
-        const float px[3] = {to_pixel(x0, fs), to_pixel(x1, fs), to_pixel(x2, fs)};
-        const float py[3] = {to_pixel(y0, fs), to_pixel(y1, fs), to_pixel(y2, fs)};
-        compute_face_inv(px, py, inv);
-    }
-    float *o = ws_inv + (size_t)i * 9;
-#pragma unroll
-    for (int k = 0; k < 9; k++) o[k] = inv[k];
-    ws_bbox[i] = face_bbox(x0, y0, x1, y1, x2, y2, S);
-}
-
-// --------------------------------------------------------------------------------------------------
-// F2: tile rasterizer.  One workgroup (4 waves) per 32x32-pixel tile of one image.
-//   scan   every thread tests one face box per round against the tile (boxes of 4 rounds are fetched together
-//          so their memory latency overlaps); a hit is appended to an LDS list (wave-aggregated LDS atomic) and
-//          the hitting thread copies the face's 9 + 9 floats (vertices, inverse matrix) into the list entry;
-//   raster when the list is nearly full (or the faces are exhausted) the entries are rasterized two ways:
-//          SMALL faces (box-in-tile area <= SMALL_AREA pixels; the bulk of a fine mesh) are face-parallel: one
-//          lane per face walks the face's few pixels and publishes (depth bits << 32 | face index) with a
-//          64-bit LDS atomic min into the tile's z-buffer -- dense clusters of tiny faces (teapot knob: 185
-//          faces over one 16x4 block) cost passes of 64 faces instead of 185 serial wave-wide tests;
-//          LARGE faces are pixel-parallel: each wave walks its four 16x4 pixel blocks, 64 list entries per step
-//          (one box test per lane, __ballot), and for every surviving entry all 64 lanes read the entry from
-//          LDS (same address: broadcast) and test their own pixel, keeping the winner in registers;
-//   resolve at the end each pixel merges the register winner with the LDS z-buffer winner and re-evaluates the
-//          weights of an LDS winner (same function, same inputs -> same bits).
-// Both paths evaluate the reference's inside / barycentric / depth arithmetic through eval_pixel(); the
-// winner rule is "smaller zp, ties -> lower face index" (the reference scans faces in ascending order with
-// a strict `<`, rasterize.py:300,334), which the packed 64-bit min reproduces because near > 0 makes the
-// float bit pattern order-preserving.
-constexpr int TILE = 32;
-constexpr int BLK_W = 16, BLK_H = 4;
-constexpr int RASTER_THREADS = 256;
-constexpr int LIST_CAP = 384;       // entries; flushed when fewer than 256 slots remain
-constexpr int ENTRY_F = 20;         // floats per entry: 9 vertices + 9 inverse + 2 pad (80 B)
-constexpr int SMALL_AREA = 128;     // box-in-tile pixels up to which a face takes the face-parallel path
+// F2: face-parallel rasterizer with a packed 64-bit z-buffer.
+//
+// Measured history (profiles/r01a, r01b): a per-tile pixel-parallel kernel spent 0.8 ms on the headline scene
+// although the arithmetic is ~10 us worth of VALU work, because the teapot concentrates hundreds of tiny
+// faces in a few tiles (185 candidate faces over one 16x4 pixel block) and every candidate costs a
+// wave-wide test; a tile-local face-parallel variant still left 4/5 of the chip idle (only ~18 of 64
+// tiles per view contain geometry).  Faces, not pixels, are the balanced unit of work of a fine mesh:
+//   k_face_raster    one thread per face: back-face cull, inverse matrix, screen box (K1); small boxes
+//                    (<= SMALL_AREA pixels, i.e. practically every face of a mesh) are rasterized on the spot:
+//                    the thread walks the box, evaluates the reference's inside / barycentric / depth test
+//                    (K2 body) and publishes (depth bits << 32 | face index) with a 64-bit atomicMin on the
+//                    pixel's z-buffer word; faces with a large box are queued;
+//   k_large_raster   queued faces are rasterized by a whole workgroup each (threads stride over the box);
+//   k_resolve        one thread per pixel decodes the winner, re-evaluates its weights (same function, same
+//                    inputs -> same bits) and writes face_index / weight / depth / face_inv maps (every
+//                    element, init values where no face was found, rasterize.py:478-496).
+// The packed minimum reproduces the reference's winner rule "smaller zp, ties -> lower face index" (it
+// scans faces in ascending order with a strict `<`, rasterize.py:300,334): zp > near > 0, so the float bit
+// pattern is order-preserving as an unsigned integer.  The result does not depend on the order of the
+// atomics: face_index_map is bit-reproducible.
+constexpr int SMALL_AREA = 256;
 constexpr unsigned long long ZEMPTY = ~0ull;
 
 struct FaceGeo {
     float x0, y0, z0, x1, y1, z1, x2, y2, z2, i0, i1, i2, i3, i4, i5, i6, i7, i8;
 };
-
-__device__ __forceinline__ FaceGeo load_geo(const float *__restrict__ e)
-{
-    const float4 a = *reinterpret_cast<const float4 *>(e);       // x0 y0 z0 x1
-    const float4 b = *reinterpret_cast<const float4 *>(e + 4);   // y1 z1 x2 y2
-    const float4 c = *reinterpret_cast<const float4 *>(e + 8);   // z2 i0 i1 i2
-    const float4 d = *reinterpret_cast<const float4 *>(e + 12);  // i3 i4 i5 i6
-    const float2 g = *reinterpret_cast<const float2 *>(e + 16);  // i7 i8
-    FaceGeo q;
-    q.x0 = a.x; q.y0 = a.y; q.z0 = a.z; q.x1 = a.w; q.y1 = b.x; q.z1 = b.y; q.x2 = b.z; q.y2 = b.w; q.z2 = c.x;
-    q.i0 = c.y; q.i1 = c.z; q.i2 = c.w; q.i3 = d.x; q.i4 = d.y; q.i5 = d.z; q.i6 = d.w; q.i7 = g.x; q.i8 = g.y;
-    return q;
-}
 
 // One (face, pixel) evaluation of the reference's K2 body.  Returns false when the pixel is rejected.
 __device__ __forceinline__ bool eval_pixel(const FaceGeo &q, float xp, float yp, float xif, float yif, double near_d,
@@ -106,191 +65,121 @@ __device__ __forceinline__ bool eval_pixel(const FaceGeo &q, float xp, float yp,
     return true;
 }
 
-struct PixelState {
-    float z, w0, w1, w2;
-    int fn;
-};
+// pixel centre (2. * i + 1 - is) / is (rasterize.py:291-292, evaluated in double there).  Both operands are
+// integers below 2^24, exactly representable in float, and a correctly rounded float division of exact
+// operands equals the double division rounded to float (53 >= 2 * 24 + 2: the double rounding is innocuous).
+__device__ __forceinline__ float pixel_center_f(int i, int S) { return (float)(2 * i + 1 - S) / (float)S; }
 
-__global__ __launch_bounds__(RASTER_THREADS) void k_raster_tiles(
-    const float *__restrict__ faces, const float *__restrict__ ws_inv, const BBox *__restrict__ ws_bbox,
-    int32_t *__restrict__ face_index_map, float *__restrict__ weight_map, float *__restrict__ depth_map,
-    float *__restrict__ face_inv_map, int F, int S, int tiles_x, double near_d, double far_d)
+__device__ __forceinline__ void raster_pixel(const FaceGeo &g, unsigned fnu, int px, int py, int S, double near_d,
+                                             double far_d, unsigned long long *__restrict__ zrow)
 {
-    __shared__ __attribute__((aligned(16))) float s_geo[LIST_CAP * ENTRY_F];
-    __shared__ unsigned long long s_zbuf[TILE * TILE];
-    __shared__ int s_fn[LIST_CAP];
-    __shared__ BBox s_bb[LIST_CAP];
-    __shared__ float s_xp[TILE], s_yp[TILE];
-    __shared__ int s_cnt;
+    float zp, w0, w1, w2;
+    if (eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, near_d, far_d, zp, w0, w1, w2))
+        atomicMin(zrow + px, ((unsigned long long)__float_as_uint(zp) << 32) | fnu);
+}
 
-    const int b = blockIdx.y;
-    const int tile_x0 = (blockIdx.x % tiles_x) * TILE;
-    const int tile_y0 = (blockIdx.x / tiles_x) * TILE;
-    const int tile_x1 = min(tile_x0 + TILE, S) - 1, tile_y1 = min(tile_y0 + TILE, S) - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t face_base = (size_t)b * F;
+__global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces, float *__restrict__ ws_inv,
+                                                     unsigned long long *__restrict__ zbuf,
+                                                     int *__restrict__ large_list, int *__restrict__ n_large,
+                                                     int n_faces_total, int F, int S, double near_d, double far_d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_faces_total) return;
+    const float *f = faces + (size_t)i * 9;
+    FaceGeo g;
+    g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
+    const BBox bb = face_bbox(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
+    float inv[9];
+    if (is_backside(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2)) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) inv[k] = 0.0f;  // rasterize.py:240 zeros_like + :253 continue
+    } else {
+        const float fs = (float)S;
+        const float px[3] = {to_pixel(g.x0, fs), to_pixel(g.x1, fs), to_pixel(g.x2, fs)};
+        const float py[3] = {to_pixel(g.y0, fs), to_pixel(g.y1, fs), to_pixel(g.y2, fs)};
+        compute_face_inv(px, py, inv);
+    }
+    float *o = ws_inv + (size_t)i * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o[k] = inv[k];
+    if (bb.x_lo > bb.x_hi) return;
+    const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
+    if (bw * bh > SMALL_AREA) {
+        large_list[atomicAdd(n_large, 1)] = i;
+        return;
+    }
+    g.i0 = inv[0]; g.i1 = inv[1]; g.i2 = inv[2]; g.i3 = inv[3]; g.i4 = inv[4]; g.i5 = inv[5];
+    g.i6 = inv[6]; g.i7 = inv[7]; g.i8 = inv[8];
+    const int b = i / F;
+    const unsigned fnu = (unsigned)(i - b * F);
+    unsigned long long *zimg = zbuf + (size_t)b * S * S;
+    for (int py = bb.y_lo; py <= bb.y_hi; ++py)
+        for (int px = bb.x_lo; px <= bb.x_hi; ++px) raster_pixel(g, fnu, px, py, S, near_d, far_d, zimg + (size_t)py * S);
+}
 
-    // pixel centres of the tile's columns / rows (rasterize.py:291-292)
-    if (tid < TILE) s_xp[tid] = pixel_center(tile_x0 + tid, S);
-    else if (tid < 2 * TILE) s_yp[tid - TILE] = pixel_center(tile_y0 + tid - TILE, S);
-    for (int i = tid; i < TILE * TILE; i += RASTER_THREADS) s_zbuf[i] = ZEMPTY;
-    if (tid == 0) s_cnt = 0;
-
-    // this lane's pixels: block r of wave w sits at column block (r & 1), row block (2 * w + (r >> 1))
-    const int lx = lane & (BLK_W - 1), ly = lane >> 4;
-    const int lxa[2] = {lx, BLK_W + lx};
-    const int lya[2] = {(2 * wave) * BLK_H + ly, (2 * wave + 1) * BLK_H + ly};
-
-    const float far_f = (float)far_d;  // rasterize.py:296
-    PixelState st[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { st[r].z = far_f; st[r].fn = -1; st[r].w0 = st[r].w1 = st[r].w2 = 0.0f; }
-    __syncthreads();
-
-    constexpr int PF = 4;  // scan rounds whose boxes are fetched together
-    for (int base0 = 0; base0 < F; base0 += PF * RASTER_THREADS) {
-        BBox bbs[PF];
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int fn = base0 + u * RASTER_THREADS + tid;
-            bbs[u].x_lo = 1; bbs[u].x_hi = 0; bbs[u].y_lo = 1; bbs[u].y_hi = 0;
-            if (fn < F) bbs[u] = ws_bbox[face_base + fn];
-        }
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int base = base0 + u * RASTER_THREADS;
-            if (base >= F) break;  // uniform
-            // ---- scan: one box per thread
-            const int fn = base + tid;
-            const BBox bb = bbs[u];
-            const bool hit = (bb.x_lo <= bb.x_hi) && (bb.x_lo <= tile_x1) && (bb.x_hi >= tile_x0) &&
-                             (bb.y_lo <= tile_y1) && (bb.y_hi >= tile_y0);
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                int off = 0;
-                if (lane == 0) off = atomicAdd(&s_cnt, __popcll(m));
-                off = rfl(off);
-                if (hit) {
-                    const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-                    s_fn[pos] = fn;
-                    s_bb[pos] = bb;
-                    const float *f = faces + (face_base + fn) * 9;
-                    const float *iv = ws_inv + (face_base + fn) * 9;
-                    float *e = s_geo + pos * ENTRY_F;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) e[k] = f[k];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) e[9 + k] = iv[k];
-                }
-            }
-            __syncthreads();
-            const int n = s_cnt;
-            __syncthreads();  // everybody has read n before the next round's appends can move s_cnt
-            const bool last = base + RASTER_THREADS >= F;
-            if (n > LIST_CAP - RASTER_THREADS || (last && n > 0)) {
-                // ---- small faces: lane = face, LDS z-buffer
-                for (int j = tid; j < n; j += RASTER_THREADS) {
-                    const BBox q = s_bb[j];
-                    const int x_lo = max((int)q.x_lo, tile_x0), x_hi = min((int)q.x_hi, tile_x1);
-                    const int y_lo = max((int)q.y_lo, tile_y0), y_hi = min((int)q.y_hi, tile_y1);
-                    if ((x_hi - x_lo + 1) * (y_hi - y_lo + 1) > SMALL_AREA) continue;
-                    const FaceGeo g = load_geo(s_geo + j * ENTRY_F);
-                    const unsigned fnu = (unsigned)s_fn[j];
-                    for (int py = y_lo; py <= y_hi; py++) {
-                        const float yp = s_yp[py - tile_y0], yif = (float)py;
-                        for (int px = x_lo; px <= x_hi; px++) {
-                            float zp, w0, w1, w2;
-                            if (eval_pixel(g, s_xp[px - tile_x0], yp, (float)px, yif, near_d, far_d, zp, w0, w1, w2))
-                                atomicMin(&s_zbuf[(py - tile_y0) * TILE + (px - tile_x0)],
-                                          ((unsigned long long)__float_as_uint(zp) << 32) | fnu);
-                        }
-                    }
-                }
-                // ---- large faces: lane = pixel
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int cx = r & 1, cy = r >> 1;
-                    const int bx0 = tile_x0 + cx * BLK_W, by0 = tile_y0 + (2 * wave + cy) * BLK_H;
-                    const int bx1 = bx0 + BLK_W - 1, by1 = by0 + BLK_H - 1;
-                    const float xp = s_xp[lxa[cx]], yp = s_yp[lya[cy]];
-                    const float xif = (float)(tile_x0 + lxa[cx]), yif = (float)(tile_y0 + lya[cy]);
-                    for (int j0 = 0; j0 < n; j0 += WAVE) {
-                        const int j = j0 + lane;
-                        bool h2 = false;
-                        if (j < n) {
-                            const BBox q = s_bb[j];
-                            const int x_lo = max((int)q.x_lo, tile_x0), x_hi = min((int)q.x_hi, tile_x1);
-                            const int y_lo = max((int)q.y_lo, tile_y0), y_hi = min((int)q.y_hi, tile_y1);
-                            h2 = ((x_hi - x_lo + 1) * (y_hi - y_lo + 1) > SMALL_AREA) && (q.x_lo <= bx1) &&
-                                 (q.x_hi >= bx0) && (q.y_lo <= by1) && (q.y_hi >= by0);
-                        }
-                        unsigned long long mm = __ballot(h2);
-                        while (mm) {
-                            const int t = __builtin_ctzll(mm);
-                            mm &= mm - 1;
-                            const int idx = j0 + t;  // wave-uniform
-                            const FaceGeo g = load_geo(s_geo + idx * ENTRY_F);
-                            const int fn2 = s_fn[idx];
-                            float zp, w0, w1, w2;
-                            if (eval_pixel(g, xp, yp, xif, yif, near_d, far_d, zp, w0, w1, w2) &&
-                                (zp < st[r].z || (zp == st[r].z && fn2 < st[r].fn))) {  // :334 + explicit tie rule
-                                st[r].z = zp; st[r].fn = fn2; st[r].w0 = w0; st[r].w1 = w1; st[r].w2 = w2;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) s_cnt = 0;
-                __syncthreads();
-            }
+__global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces, const float *__restrict__ ws_inv,
+                                                      unsigned long long *__restrict__ zbuf,
+                                                      const int *__restrict__ large_list,
+                                                      const int *__restrict__ n_large, int F, int S, double near_d,
+                                                      double far_d)
+{
+    const int n = *n_large;
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const int i = large_list[j];
+        const float *f = faces + (size_t)i * 9;
+        const float *iv = ws_inv + (size_t)i * 9;
+        FaceGeo g;
+        g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
+        g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5]; g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
+        const BBox bb = face_bbox(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
+        const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
+        const int b = i / F;
+        const unsigned fnu = (unsigned)(i - b * F);
+        unsigned long long *zimg = zbuf + (size_t)b * S * S;
+        for (int k = threadIdx.x; k < bw * bh; k += blockDim.x) {
+            const int yy = k / bw, xx = k - yy * bw;
+            raster_pixel(g, fnu, bb.x_lo + xx, bb.y_lo + yy, S, near_d, far_d, zimg + (size_t)(bb.y_lo + yy) * S);
         }
     }
+}
 
-    // ---- resolve + epilogue: every pixel is written (init values where no face was found, :478-496)
+__global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces, const float *__restrict__ ws_inv,
+                                                 const unsigned long long *__restrict__ zbuf,
+                                                 int32_t *__restrict__ face_index_map, float *__restrict__ weight_map,
+                                                 float *__restrict__ depth_map, float *__restrict__ face_inv_map,
+                                                 int F, int S, double near_d, double far_d, size_t n_pixels)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const unsigned long long pk = zbuf[i];
+    int fn = -1;
+    float zp = (float)far_d, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;  // rasterize.py:296, :478-480
+    const float *iv = nullptr;
+    if (pk != ZEMPTY) {
+        fn = (int)(unsigned)(pk & 0xffffffffu);
+        const size_t SS = (size_t)S * S;
+        const int b = (int)(i / SS);
+        const int pn = (int)(i - (size_t)b * SS);
+        const int py = pn / S, px = pn - py * S;
+        const float *f = faces + ((size_t)b * F + fn) * 9;
+        iv = ws_inv + ((size_t)b * F + fn) * 9;
+        FaceGeo g;
+        g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
+        g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5]; g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
+        eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, near_d, far_d, zp, w0, w1, w2);
+    }
+    face_index_map[i] = fn;
+    if (depth_map) depth_map[i] = zp;
+    if (weight_map) {
+        float *w = weight_map + 3 * i;
+        w[0] = w0;
+        w[1] = w1;
+        w[2] = w2;
+    }
+    if (face_inv_map) {
+        float *o = face_inv_map + 9 * i;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int lxx = lxa[r & 1], lyy = lya[r >> 1];
-        const int px = tile_x0 + lxx, py = tile_y0 + lyy;
-        if (px < S && py < S) {
-            const unsigned long long pk = s_zbuf[lyy * TILE + lxx];
-            if (pk != ZEMPTY) {
-                const float zs = __uint_as_float((unsigned)(pk >> 32));
-                const int fs_ = (int)(unsigned)(pk & 0xffffffffu);
-                if (zs < st[r].z || (zs == st[r].z && fs_ < st[r].fn)) {
-                    // re-evaluate the winner to get its weights (same inputs, same function -> same bits)
-                    const float *f = faces + (face_base + fs_) * 9;
-                    const float *iv = ws_inv + (face_base + fs_) * 9;
-                    FaceGeo g;
-                    g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5];
-                    g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
-                    g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5];
-                    g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
-                    float zp, w0, w1, w2;
-                    eval_pixel(g, s_xp[lxx], s_yp[lyy], (float)px, (float)py, near_d, far_d, zp, w0, w1, w2);
-                    st[r].z = zp; st[r].fn = fs_; st[r].w0 = w0; st[r].w1 = w1; st[r].w2 = w2;
-                }
-            }
-            const size_t i = ((size_t)b * S + py) * S + px;
-            face_index_map[i] = st[r].fn;
-            if (depth_map) depth_map[i] = st[r].z;
-            if (weight_map) {
-                float *w = weight_map + 3 * i;
-                w[0] = st[r].w0;
-                w[1] = st[r].w1;
-                w[2] = st[r].w2;
-            }
-            if (face_inv_map) {
-                float *o = face_inv_map + 9 * i;
-                if (st[r].fn >= 0) {
-                    const float *iv = ws_inv + (face_base + st[r].fn) * 9;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) o[k] = iv[k];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) o[k] = 0.0f;
-                }
-            }
-        }
+        for (int k = 0; k < 9; k++) o[k] = (fn >= 0) ? iv[k] : 0.0f;
     }
 }
 
@@ -371,11 +260,27 @@ NR_API const char *nr_error_string(int code)
     }
 }
 
+namespace {
+struct FwdLayout {
+    size_t inv_off, zbuf_off, list_off, count_off, total;
+};
+FwdLayout fwd_layout(int B, int F, int S)
+{
+    FwdLayout L;
+    const size_t n = (size_t)B * F, P = (size_t)B * S * S;
+    L.inv_off = 0;
+    L.zbuf_off = align_up(n * 9 * sizeof(float), 256);
+    L.count_off = L.zbuf_off + P * sizeof(unsigned long long);  // the counter sits right behind the z-buffer
+    L.list_off = align_up(L.count_off + sizeof(int), 256);
+    L.total = L.list_off + n * sizeof(int);
+    return L;
+}
+}  // namespace
+
 NR_API size_t nr_forward_workspace_bytes(int32_t B, int32_t F, int32_t S)
 {
     if (check_sizes(B, F, S)) return 0;
-    const size_t n = (size_t)B * F;
-    return align_up(n * 9 * sizeof(float), 256) + align_up(n * sizeof(BBox), 256);
+    return fwd_layout(B, F, S).total;
 }
 
 NR_API int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map,
@@ -384,17 +289,27 @@ NR_API int nr_forward_face_index_map(const float *faces, int32_t *face_index_map
 {
     if (!faces || !face_index_map) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
-    if (!workspace || workspace_bytes < nr_forward_workspace_bytes(B, F, S)) return NR_E_WORKSPACE;
+    if (!(near > 0.0)) return NR_E_SIZE;  // the packed z-buffer needs positive depths (reference default 0.1)
+    const FwdLayout L = fwd_layout(B, F, S);
+    if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)B * F;
-    float *ws_inv = (float *)workspace;
-    BBox *ws_bbox = (BBox *)((char *)workspace + align_up(n * 9 * sizeof(float), 256));
+    const size_t n = (size_t)B * F, P = (size_t)B * S * S;
+    unsigned char *ws = (unsigned char *)workspace;
+    float *ws_inv = (float *)(ws + L.inv_off);
+    unsigned long long *zbuf = (unsigned long long *)(ws + L.zbuf_off);
+    int *n_large = (int *)(ws + L.count_off);
+    int *large_list = (int *)(ws + L.list_off);
 
-    hipLaunchKernelGGL(k_face_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, ws_inv, ws_bbox,
-                       (int)n, S);
-    const int tiles = (S + TILE - 1) / TILE;
-    hipLaunchKernelGGL(k_raster_tiles, dim3(tiles * tiles, B), dim3(RASTER_THREADS), 0, st, faces, ws_inv, ws_bbox,
-                       face_index_map, weight_map, depth_map, face_inv_map, F, S, tiles, near, far);
+    hipError_t he = hipMemsetAsync(zbuf, 0xff, P * sizeof(unsigned long long), st);  // ZEMPTY
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(n_large, 0, sizeof(int), st);
+    if (he != hipSuccess) return (int)he;
+    hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
+                       large_list, n_large, (int)n, F, S, near, far);
+    hipLaunchKernelGGL(k_large_raster, dim3(1024), dim3(256), 0, st, faces, ws_inv, zbuf, large_list, n_large, F, S,
+                       near, far);
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
+                       face_index_map, weight_map, depth_map, face_inv_map, F, S, near, far, P);
     return launch_status();
 }
 
