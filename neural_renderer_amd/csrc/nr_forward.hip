@@ -69,21 +69,33 @@ __device__ __forceinline__ bool eval_pixel(const FaceGeo &q, float xp, float yp,
 // integers below 2^24, exactly representable in float, and a correctly rounded float division of exact
 // operands equals the double division rounded to float (53 >= 2 * 24 + 2: the double rounding is innocuous).
 __device__ __forceinline__ float pixel_center_f(int i, int S) { return (float)(2 * i + 1 - S) / (float)S; }
+// same value with one multiply when S is a power of two (the quotient is then exactly representable)
+__device__ __forceinline__ float pixel_center_p(int i, int S, float inv_s, bool pow2)
+{
+    return pow2 ? (float)(2 * i + 1 - S) * inv_s : (float)(2 * i + 1 - S) / (float)S;
+}
 
-__device__ __forceinline__ void raster_pixel(const FaceGeo &g, unsigned fnu, int px, int py, int S, double near_d,
-                                             double far_d, unsigned long long *__restrict__ zrow)
+__device__ __forceinline__ void raster_pixel(const FaceGeo &g, unsigned fnu, int px, int py, float xp, float yp,
+                                             double near_d, double far_d, unsigned long long *__restrict__ zrow)
 {
     float zp, w0, w1, w2;
-    if (eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, near_d, far_d, zp, w0, w1, w2))
+    if (eval_pixel(g, xp, yp, (float)px, (float)py, near_d, far_d, zp, w0, w1, w2))
         atomicMin(zrow + px, ((unsigned long long)__float_as_uint(zp) << 32) | fnu);
 }
+
+// LPF lanes share one face (they split the rows of its box): 4x more waves than a thread-per-face launch,
+// each with 4x shorter serial loops.  The kernel is bound by the dependent-instruction latency of the IEEE
+// divisions in the K2 body (measured: 13 cycles per VALU instruction at 1.2 waves/SIMD), which more resident
+// waves hide.
+constexpr int LPF = 4;
 
 __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces, float *__restrict__ ws_inv,
                                                      unsigned long long *__restrict__ zbuf,
                                                      int *__restrict__ large_list, int *__restrict__ n_large,
                                                      int n_faces_total, int F, int S, double near_d, double far_d)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t / LPF, sub = t - i * LPF;
     if (i >= n_faces_total) return;
     const float *f = faces + (size_t)i * 9;
     FaceGeo g;
@@ -99,13 +111,15 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
         const float py[3] = {to_pixel(g.y0, fs), to_pixel(g.y1, fs), to_pixel(g.y2, fs)};
         compute_face_inv(px, py, inv);
     }
-    float *o = ws_inv + (size_t)i * 9;
+    if (sub == 0) {
+        float *o = ws_inv + (size_t)i * 9;
 #pragma unroll
-    for (int k = 0; k < 9; k++) o[k] = inv[k];
+        for (int k = 0; k < 9; k++) o[k] = inv[k];
+    }
     if (bb.x_lo > bb.x_hi) return;
     const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
     if (bw * bh > SMALL_AREA) {
-        large_list[atomicAdd(n_large, 1)] = i;
+        if (sub == 0) large_list[atomicAdd(n_large, 1)] = i;
         return;
     }
     g.i0 = inv[0]; g.i1 = inv[1]; g.i2 = inv[2]; g.i3 = inv[3]; g.i4 = inv[4]; g.i5 = inv[5];
@@ -113,8 +127,14 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     const int b = i / F;
     const unsigned fnu = (unsigned)(i - b * F);
     unsigned long long *zimg = zbuf + (size_t)b * S * S;
-    for (int py = bb.y_lo; py <= bb.y_hi; ++py)
-        for (int px = bb.x_lo; px <= bb.x_hi; ++px) raster_pixel(g, fnu, px, py, S, near_d, far_d, zimg + (size_t)py * S);
+    const bool pow2 = (S & (S - 1)) == 0;
+    const float inv_s = 1.0f / (float)S;
+    for (int py = bb.y_lo + sub; py <= bb.y_hi; py += LPF) {
+        const float yp = pixel_center_p(py, S, inv_s, pow2);
+        unsigned long long *zrow = zimg + (size_t)py * S;
+        for (int px = bb.x_lo; px <= bb.x_hi; ++px)
+            raster_pixel(g, fnu, px, py, pixel_center_p(px, S, inv_s, pow2), yp, near_d, far_d, zrow);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces, const float *__restrict__ ws_inv,
@@ -138,7 +158,8 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
         unsigned long long *zimg = zbuf + (size_t)b * S * S;
         for (int k = threadIdx.x; k < bw * bh; k += blockDim.x) {
             const int yy = k / bw, xx = k - yy * bw;
-            raster_pixel(g, fnu, bb.x_lo + xx, bb.y_lo + yy, S, near_d, far_d, zimg + (size_t)(bb.y_lo + yy) * S);
+            raster_pixel(g, fnu, bb.x_lo + xx, bb.y_lo + yy, pixel_center_f(bb.x_lo + xx, S), pixel_center_f(bb.y_lo + yy, S),
+                         near_d, far_d, zimg + (size_t)(bb.y_lo + yy) * S);
         }
     }
 }
@@ -304,7 +325,7 @@ NR_API int nr_forward_face_index_map(const float *faces, int32_t *face_index_map
     if (he != hipSuccess) return (int)he;
     he = hipMemsetAsync(n_large, 0, sizeof(int), st);
     if (he != hipSuccess) return (int)he;
-    hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
+    hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
                        large_list, n_large, (int)n, F, S, near, far);
     hipLaunchKernelGGL(k_large_raster, dim3(1024), dim3(256), 0, st, faces, ws_inv, zbuf, large_list, n_large, F, S,
                        near, far);
