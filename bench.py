@@ -173,13 +173,11 @@ def main():
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run' % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    from neural_renderer_amd import distributed as nrd
+    _, _, dev = nrd.init_from_env()  # one process per GPU; backend "nccl" = RCCL
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import neural_renderer_amd as nr
     B, S, ts, eps = args.batch, args.image_size, args.texture_size, 1e-3

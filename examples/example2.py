@@ -1,0 +1,84 @@
+"""
+Example 2. Optimizing vertices.
+(reference examples/example2.py re-hosted on PyTorch-ROCm: the Chainer Link becomes an nn.Module.)
+"""
+import argparse
+
+import numpy as np
+import torch
+import torch.nn as nn
+import tqdm
+
+import neural_renderer
+from example_io import make_gif, read_image
+
+
+class Model(nn.Module):
+    def __init__(self, filename_obj, filename_ref):
+        super(Model, self).__init__()
+        # load .obj
+        vertices, faces = neural_renderer.load_obj(filename_obj)
+        self.vertices = nn.Parameter(torch.from_numpy(vertices[None, :, :]))
+        self.register_buffer('faces', torch.from_numpy(faces[None, :, :]))
+
+        # create textures
+        texture_size = 2
+        self.register_buffer('textures', torch.ones((1, self.faces.shape[1], texture_size, texture_size, texture_size,
+                                                     3), dtype=torch.float32))
+
+        # load reference image
+        ref = read_image(filename_ref)
+        if ref.ndim == 3:
+            ref = ref.max(-1)
+        self.register_buffer('image_ref', torch.from_numpy((ref > 0.5).astype(np.float32)))
+
+        # setup renderer
+        self.renderer = neural_renderer.Renderer()
+
+    def forward(self):
+        self.renderer.eye = neural_renderer.get_points_from_angles(2.732, 0, 90)
+        image = self.renderer.render_silhouettes(self.vertices, self.faces)
+        loss = torch.sum(torch.square(image - self.image_ref[None, :, :]))
+        return loss
+
+
+def run():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-io', '--filename_obj', type=str, default='./examples/data/teapot.obj')
+    parser.add_argument('-ir', '--filename_ref', type=str, default='./examples/data/example2_ref.png')
+    parser.add_argument('-oo', '--filename_output_optimization', type=str,
+                        default='./examples/data/example2_optimization.gif')
+    parser.add_argument('-or', '--filename_output_result', type=str, default='./examples/data/example2_result.gif')
+    parser.add_argument('-g', '--gpu', type=int, default=0)
+    parser.add_argument('--steps', type=int, default=300)
+    args = parser.parse_args()
+    device = torch.device('cuda', args.gpu)
+
+    model = Model(args.filename_obj, args.filename_ref).to(device)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)  # chainer.optimizers.Adam() default alpha
+    frames = []
+    loop = tqdm.tqdm(range(args.steps))
+    for i in loop:
+        loop.set_description('Optimizing')
+        optimizer.zero_grad()
+        loss = model()
+        loss.backward()
+        optimizer.step()
+        with torch.no_grad():
+            images = model.renderer.render_silhouettes(model.vertices, model.faces)
+        frames.append(images.cpu().numpy()[0])
+    print('final loss %.3f' % float(loss))
+    make_gif(frames, args.filename_output_optimization)
+
+    # draw object
+    frames = []
+    for azimuth in tqdm.tqdm(range(0, 360, 4), desc='Drawing'):
+        model.renderer.eye = neural_renderer.get_points_from_angles(2.732, 0, azimuth)
+        with torch.no_grad():
+            images = model.renderer.render(model.vertices, model.faces, model.textures)
+        frames.append(images.cpu().numpy()[0].transpose((1, 2, 0)))
+    make_gif(frames, args.filename_output_result)
+
+
+if __name__ == '__main__':
+    run()

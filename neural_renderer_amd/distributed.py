@@ -1,0 +1,90 @@
+"""Multi-GPU support for the rasterizer: the batch-of-views dimension shards over the GPUs of a node.
+
+The reference has no multi-GPU path at all.  Every kernel of the hot path reads and writes
+only its own batch element (rasterize.py:287, 386-390, 533-536, 770-772, 814-821), so the forward and backward
+of a shard need NO communication: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI),
+each rendering views [start, stop) of the global batch.  Two optional collectives live outside the rasterizer:
+
+  all_gather_images   when the downstream loss needs the whole batch of rendered images (one all-gather of
+                      [B/R, C, H, W] per rank; 6.3 MB per rank for the headline RGB case);
+  all_reduce_shared_grads   when mesh parameters are shared by all views (reference mesh.py:29-34 broadcasts
+                      them), their gradients are summed over ranks -- a tiny [Nv,3] / [F,ts^3,3] all-reduce.
+
+Note on SURVEY quirk Q1: the reference samples textures with the face depth of *batch element 0*; under
+sharding that means "the first view of the local shard".  Use fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) when
+views differ in geometry and textures are non-uniform.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
+            int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from the torchrun environment. Returns (rank, world, device)."""
+    rank, world, local_rank = env_rank_world()
+    use_cuda = torch.cuda.is_available()
+    device = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        kwargs = {}
+        if use_cuda:
+            kwargs['device_id'] = device
+        dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), rank=rank, world_size=world, **kwargs)
+    return rank, world, device
+
+
+def shard_bounds(total, rank, world):
+    """Contiguous, balanced partition of `total` views: rank r owns [start, stop)."""
+    base, rem = divmod(int(total), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def shard(tensor, rank, world, dim=0):
+    start, stop = shard_bounds(tensor.shape[dim], rank, world)
+    return tensor.narrow(dim, start, stop - start)
+
+
+def all_gather_images(images, total=None):
+    """Gather per-rank image shards [b_r, ...] into the full batch [B, ...] on every rank (not differentiable
+    through the collective; use it on detached images or gather the per-view losses instead)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return images
+    world, rank = dist.get_world_size(), dist.get_rank()
+    images = images.contiguous()
+    if total is None:
+        n = torch.tensor([images.shape[0]], device=images.device, dtype=torch.int64)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+    else:
+        sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    if len(set(sizes)) == 1:
+        out = images.new_empty((sum(sizes),) + tuple(images.shape[1:]))
+        dist.all_gather_into_tensor(out, images)
+        return out
+    # uneven shards: pad to the largest, gather, trim
+    m = max(sizes)
+    padded = images.new_zeros((m,) + tuple(images.shape[1:]))
+    padded[:images.shape[0]] = images
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def all_reduce_shared_grads(parameters):
+    """Sum the gradients of parameters shared by all views (vertices / textures of one mesh) over the ranks."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for p in parameters:
+        if p.grad is not None:
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)

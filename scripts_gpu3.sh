@@ -1,2 +1,1 @@
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3
-TAG=now ITERS=10 python scripts/stage_times.py 2>&1 | tail -1
+timeout 900 python -m pytest tests -m gpu -q -k "examples" 2>&1 | tail -15
