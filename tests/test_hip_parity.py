@@ -3,6 +3,8 @@ same seeded inputs.  Bars (BASELINE.json north_star): face_index_map bit-exact; 
 within 1e-4 relative.  The forward float maps use the oracle's operation order and are expected to be
 bit-identical as well; the tests assert that and fall back to the stated tolerance only for the sums whose
 order legitimately differs (K6 tree reduction, K7/K8 atomics)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -154,8 +156,10 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
     noise = H.rel_err(ref_gf, ref_d)       # the reference's own serial-float-sum rounding noise
     err_d = H.rel_err(gf, ref_d)           # ours vs the exactly-summed terms
     err_f = H.rel_err(gf, ref_gf)          # ours vs the literal reference order
-    # (with depth on, K8's per-lane float partial sums add a little order noise: looser bound)
-    assert err_d <= (1e-5 if depth else 2e-6), 'grad_faces vs double-summed oracle: %g' % err_d
+    # default: every K6 term bit-identical to the reference's, sums in double (K8's float partials remain);
+    # NR_K6_FAST=1: hardware reciprocal + per-segment float sums (per-term deviation ~1e-7, amplified by cancellation)
+    bound = 5e-5 if os.environ.get('NR_K6_FAST') == '1' else (1e-5 if depth else 2e-6)
+    assert err_d <= bound, 'grad_faces vs double-summed oracle: %g' % err_d
     assert err_f <= RTOL + 2 * noise, 'grad_faces rel err %g (reference summation noise %g)' % (err_f, noise)
     # back faces and z (when depth is off) are exactly zero, like the reference
     if not depth:
@@ -285,3 +289,14 @@ def test_headline_size_properties():
         fn = oracle_forward(faces[i:i + 1], None, S, 0.1, 100, 1e-4, None, False, True, False)
         ref_d, = fn.backward(None, g[i:i + 1], None, accumulate_double=True)
         assert H.rel_err(gf1[i], ref_d[0]) <= 2e-6
+
+
+@pytest.mark.parametrize('modes', [(False, True, False), (True, True, False)], ids=['alpha', 'rgb+alpha'])
+def test_fast_k6_variant_within_tolerance(modes, monkeypatch):
+    """NR_K6_FAST=1 selects the reciprocal / float-partial-sum instantiation of K6 (-7 % time): still far inside the
+    1e-4 gradient tolerance."""
+    monkeypatch.setenv('NR_K6_FAST', '1')
+    faces, _ = H.teapot_views(2, 128)
+    rng = np.random.default_rng(21)
+    textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    check_backward(faces, textures, 128, 1e-3, modes, seed=22)
