@@ -300,3 +300,72 @@ def test_fast_k6_variant_within_tolerance(modes, monkeypatch):
     rng = np.random.default_rng(21)
     textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
     check_backward(faces, textures, 128, 1e-3, modes, seed=22)
+
+
+def test_global_memory_k6_fallback(monkeypatch):
+    """The band pipeline needs one band line of all maps in LDS; rasters too large for that use the
+    global-memory kernel (k_bpm_global).  NR_K6_GLOBAL=1 forces it so that it stays covered."""
+    monkeypatch.setenv('NR_K6_GLOBAL', '1')
+    faces, _ = H.teapot_views(2, 96)
+    rng = np.random.default_rng(23)
+    textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    check_backward(faces, textures, 96, 1e-3, (True, True, False), seed=24)
+
+
+def icosphere(level):
+    """Subdivided icosahedron (unit sphere): vertices [Nv,3], faces [Nf,3]."""
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, np.float32), np.array(f, np.int32)
+
+
+def project_mesh(v, f, eye, fill_back=True):
+    if fill_back:
+        f = np.concatenate((f, f[:, ::-1]), axis=0)
+    vv = O.perspective(O.look_at(v[None], eye), 30.)
+    return O.vertices_to_faces(vv, f[None])[0]
+
+
+def test_synthetic_shapenet_scale_meshes():
+    """BASELINE.json config 4 at test scale: distinct random meshes of ~5k faces (noisy icospheres, fill_back ->
+    10 240 faces), per-sample random rotation, texture_size 4 random textures, 128x128 RGB forward + backward."""
+    rng = np.random.default_rng(31)
+    v0, f0 = icosphere(4)  # 5120 faces
+    batch = []
+    for _ in range(3):
+        v = v0 * (0.55 + 0.12 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+        q = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+        batch.append(project_mesh((v @ q).astype(np.float32), f0, [0.3, 0.4, -2.6]))
+    faces = np.stack(batch)
+    textures = rng.uniform(0, 1, (3, faces.shape[1], 4, 4, 4, 3)).astype(np.float32)
+    check_backward(faces, textures, 128, 1e-3, (True, False, False), seed=32)
+
+
+def test_high_resolution_dense_mesh():
+    """BASELINE.json config 5 at test scale: one dense mesh (20 480 -> 40 960 faces with fill_back) whose faces
+    are mostly sub-pixel to a few pixels, texture_size 8, 192x192 (non power of two), all outputs."""
+    rng = np.random.default_rng(33)
+    v0, f0 = icosphere(5)
+    v = v0 * (0.6 + 0.05 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+    faces = project_mesh(v.astype(np.float32), f0, [0.0, 0.0, -2.4])[None]
+    textures = rng.uniform(0, 1, (1, faces.shape[1], 8, 8, 8, 3)).astype(np.float32)
+    check_backward(faces, textures, 192, 1e-3, (True, True, True), seed=34)
