@@ -13,6 +13,7 @@
  *   nr_backward_pixel_map        <- Rasterize.backward_pixel_map_gpu        rasterize.py:517-748 (K6)
  *   nr_backward_textures         <- Rasterize.backward_textures_gpu         rasterize.py:750-792 (K7)
  *   nr_backward_depth_map        <- Rasterize.backward_depth_map_gpu        rasterize.py:794-847 (K8)
+ *   nr_backward_rasterize        <- Rasterize.backward_gpu (K6 -> K7 -> K8 fused)  rasterize.py:849-889
  *
  * Conventions
  *   - plain device pointers (hipMalloc / torch caching allocator memory), C-contiguous, float32 / int32;
@@ -122,6 +123,22 @@ int nr_backward_textures(const int32_t *face_index_map, const float *sampling_we
 int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                           const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
                           float *grad_faces, int32_t batch_size, int32_t num_faces, int32_t image_size, void *stream);
+
+/*
+ * Fused backward = Rasterize.backward_gpu (rasterize.py:849-889): K6, then K7, then K8, identical results to the
+ * three stage calls above, sharing the per-image lists of visible faces that K6 builds (the gathers then
+ * visit only the faces that own a pixel).  A NULL gradient pointer means "that output has no gradient"
+ * (the reference substitutes zeros, :858-878): the corresponding terms are skipped.  STORES every element of
+ * grad_faces and, when grad_rgb_map and grad_textures are given, of grad_textures.  Needs weight_map / depth_map
+ * when grad_rgb_map or grad_depth_map is given, rgb_map / alpha_map for their gradients; workspace as for
+ * nr_backward_pixel_map.
+ */
+int nr_backward_rasterize(const float *faces, const int32_t *face_index_map, const float *weight_map,
+                          const float *depth_map, const float *rgb_map, const float *alpha_map,
+                          const float *grad_rgb_map, const float *grad_alpha_map, const float *grad_depth_map,
+                          float *grad_faces, float *grad_textures, int32_t batch_size, int32_t num_faces,
+                          int32_t image_size, int32_t texture_size, double eps, int32_t flags, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -36,14 +36,20 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
     const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
     const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
-    float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z, int L)
+    float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z, int L,
+    const int *__restrict__ vis_list, const int *__restrict__ vis_count)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
 
     const int tid = threadIdx.x;
     const int grp = tid / L, sub = tid - grp * L;
-    const int gi = blockIdx.x * (256 / L) + grp;  // global face index b * F + fn
-    const bool face_ok = gi < n_faces_total;
+    int gi = blockIdx.x * (256 / L) + grp;  // global face index b * F + fn
+    bool face_ok = gi < n_faces_total;
+    if (vis_list) {  // blockIdx.y = image, slot -> face through the image's visible list
+        const int slot = gi;
+        face_ok = slot < vis_count[blockIdx.y];
+        gi = face_ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + slot] : 0;
+    }
     const int n_tex = ts * ts * ts * 3;
     double *acc_l = s_acc + (size_t)grp * n_tex;
 
@@ -171,13 +177,19 @@ __global__ __launch_bounds__(256) void k_backward_textures_atomic(
 __global__ __launch_bounds__(256) void k_backward_depth_face(
     const float *__restrict__ faces, const float *__restrict__ depth_map, const int32_t *__restrict__ face_index_map,
     const float *__restrict__ face_inv_map, const float *__restrict__ weight_map, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces, int n_faces_total, int F, int S)
+    float *__restrict__ grad_faces, int n_faces_total, int F, int S, const int *__restrict__ vis_list,
+    const int *__restrict__ vis_count)
 {
     constexpr int L = 16;
     const int tid = threadIdx.x;
     const int grp = tid / L, sub = tid - grp * L;
-    const int gi = blockIdx.x * (256 / L) + grp;
-    const bool face_ok = gi < n_faces_total;
+    int gi = blockIdx.x * (256 / L) + grp;
+    bool face_ok = gi < n_faces_total;
+    if (vis_list) {
+        const int slot = gi;
+        face_ok = slot < vis_count[blockIdx.y];
+        gi = face_ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + slot] : 0;
+    }
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) acc[k] = 0.0f;
@@ -243,30 +255,39 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
 }  // namespace
 
 // ====================================================================================================
-NR_API int nr_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
-                                const int32_t *sampling_index_map, const float *faces, const float *weight_map,
-                                const float *depth_map, const float *grad_rgb_map, float *grad_textures, int32_t B,
-                                int32_t F, int32_t S, int32_t ts, double eps, int32_t flags, void *stream)
+int nr::run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
+                              const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                              const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F,
+                              int S, int ts, double eps, int flags, const int *vis_list, const int *vis_count,
+                              hipStream_t st)
 {
     if (!face_index_map || !grad_rgb_map || !grad_textures || !faces) return NR_E_NULL;
     if ((sampling_index_map == nullptr) != (sampling_weight_map == nullptr)) return NR_E_MODE;
     if (!sampling_weight_map && (!weight_map || !depth_map)) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
     if (ts < 2 || ts > 1024) return NR_E_SIZE;
-    hipStream_t st = (hipStream_t)stream;
     const int fix = (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0;
     const int n = B * F;
     const size_t n_tex = (size_t)ts * ts * ts * 3;
+    if (ts > 13) vis_list = nullptr;  // the atomic fallback walks pixels, not faces
+    if (vis_list) {
+        // only visible faces are visited: everything else is zero
+        const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (ts == 2 && eps > 0.0 && !sampling_weight_map) {
-        hipLaunchKernelGGL((k_backward_textures_face<true>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st,
-                           face_index_map, sampling_weight_map, sampling_index_map, faces, weight_map, depth_map,
-                           grad_rgb_map, grad_textures, n, F, S, ts, eps, fix, 16);
+        const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
+        hipLaunchKernelGGL((k_backward_textures_face<true>), grid, dim3(256), 0, st, face_index_map,
+                           sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                           grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count);
     } else if (ts <= 13) {
         const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
-        const size_t lds = (size_t)(256 / L) * n_tex * sizeof(double);
-        hipLaunchKernelGGL((k_backward_textures_face<false>), dim3((unsigned)((n + 256 / L - 1) / (256 / L))),
-                           dim3(256), lds, st, face_index_map, sampling_weight_map, sampling_index_map, faces,
-                           weight_map, depth_map, grad_rgb_map, grad_textures, n, F, S, ts, eps, fix, L);
+        const int per = 256 / L;
+        const size_t lds = (size_t)per * n_tex * sizeof(double);
+        const dim3 grid = vis_list ? dim3((unsigned)((F + per - 1) / per), (unsigned)B) : dim3((unsigned)((n + per - 1) / per));
+        hipLaunchKernelGGL((k_backward_textures_face<false>), grid, dim3(256), lds, st, face_index_map,
+                           sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                           grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count);
     } else {
         // huge cubes: the reference's per-pixel scatter with hardware atomics
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
@@ -279,15 +300,34 @@ NR_API int nr_backward_textures(const int32_t *face_index_map, const float *samp
     return launch_status();
 }
 
-NR_API int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
-                                 const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
-                                 float *grad_faces, int32_t B, int32_t F, int32_t S, void *stream)
+int nr::run_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
+                               const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
+                               float *grad_faces, int B, int F, int S, const int *vis_list, const int *vis_count,
+                               hipStream_t st)
 {
     if (!faces || !depth_map || !face_index_map || !weight_map || !grad_depth_map || !grad_faces) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
     const int n = B * F;
-    hipLaunchKernelGGL(k_backward_depth_face, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
-                       faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, n, F,
-                       S);
+    const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
+    hipLaunchKernelGGL(k_backward_depth_face, grid, dim3(256), 0, st, faces, depth_map, face_index_map, face_inv_map,
+                       weight_map, grad_depth_map, grad_faces, n, F, S, vis_list, vis_count);
     return launch_status();
+}
+
+NR_API int nr_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
+                                const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                                const float *depth_map, const float *grad_rgb_map, float *grad_textures, int32_t B,
+                                int32_t F, int32_t S, int32_t ts, double eps, int32_t flags, void *stream)
+{
+    return run_backward_textures(face_index_map, sampling_weight_map, sampling_index_map, faces, weight_map, depth_map,
+                                 grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, nullptr, nullptr,
+                                 (hipStream_t)stream);
+}
+
+NR_API int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
+                                 const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
+                                 float *grad_faces, int32_t B, int32_t F, int32_t S, void *stream)
+{
+    return run_backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map,
+                                  grad_faces, B, F, S, nullptr, nullptr, (hipStream_t)stream);
 }

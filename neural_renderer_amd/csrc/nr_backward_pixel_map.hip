@@ -717,18 +717,20 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
     return bpm_layout(B, F).total;
 }
 
-NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
-                                 const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
-                                 float *grad_faces, int32_t B, int32_t F, int32_t S, double eps, int32_t return_rgb,
-                                 int32_t return_alpha, void *workspace, size_t workspace_bytes, void *stream)
+int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
+                               const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
+                               float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
+                               void *workspace, size_t workspace_bytes, hipStream_t st, const int **vis_list_out,
+                               const int **vis_count_out)
 {
+    if (vis_list_out) *vis_list_out = nullptr;
+    if (vis_count_out) *vis_count_out = nullptr;
     if (!faces || !face_index_map || !grad_faces) return NR_E_NULL;
     if (!return_rgb && !return_alpha) return NR_E_MODE;  // rasterize.py:523-524 returns early; callers skip the call
     if (return_rgb && (!rgb_map || !grad_rgb_map)) return NR_E_NULL;
     if (return_alpha && (!alpha_map || !grad_alpha_map)) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
     if ((size_t)B * S * S > 0x7fffffffull / 3) return NR_E_SIZE;  // int32 pixel indexing inside the kernels
-    hipStream_t st = (hipStream_t)stream;
     const int n = B * F;
     const bool rgb = return_rgb != 0, alpha = return_alpha != 0;
 
@@ -760,6 +762,8 @@ NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_m
     double *scratch = (double *)(ws + L.scratch_off);
     int *vis_count = (int *)(ws + L.count_off);
     int *vis_list = (int *)(ws + L.list_off);
+    if (vis_list_out) *vis_list_out = vis_list;
+    if (vis_count_out) *vis_count_out = vis_count;
     hipError_t he = hipMemsetAsync(ws, 0, L.zero_bytes, st);
     if (he != hipSuccess) return (int)he;
     const size_t P = (size_t)B * S * S;
@@ -779,4 +783,51 @@ NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_m
     if (rc) return rc;
     hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, grad_faces, n);
     return launch_status();
+}
+
+NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
+                                 const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
+                                 float *grad_faces, int32_t B, int32_t F, int32_t S, double eps, int32_t return_rgb,
+                                 int32_t return_alpha, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return run_backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, B,
+                                  F, S, eps, return_rgb, return_alpha, workspace, workspace_bytes, (hipStream_t)stream,
+                                  nullptr, nullptr);
+}
+
+// Fused backward: K6, K7 and K8 of one Rasterize.backward_gpu call (rasterize.py:849-889) behind one entry point.
+// Same results as calling the three stage functions in the reference's order; the visible-face lists built for
+// K6 are reused by the K7 / K8 gathers, which then visit ~1/5 of the faces.
+NR_API int nr_backward_rasterize(const float *faces, const int32_t *face_index_map, const float *weight_map,
+                                 const float *depth_map, const float *rgb_map, const float *alpha_map,
+                                 const float *grad_rgb_map, const float *grad_alpha_map, const float *grad_depth_map,
+                                 float *grad_faces, float *grad_textures, int32_t B, int32_t F, int32_t S, int32_t ts,
+                                 double eps, int32_t flags, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!faces || !face_index_map || !grad_faces) return NR_E_NULL;
+    if (int e = check_sizes(B, F, S)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const bool use_rgb = grad_rgb_map != nullptr, use_alpha = grad_alpha_map != nullptr, use_depth = grad_depth_map != nullptr;
+    const int *vis_list = nullptr, *vis_count = nullptr;
+    if (use_rgb || use_alpha) {
+        if (int rc = run_backward_pixel_map(faces, face_index_map, use_rgb ? rgb_map : nullptr,
+                                            use_alpha ? alpha_map : nullptr, grad_rgb_map, grad_alpha_map, grad_faces,
+                                            B, F, S, eps, use_rgb, use_alpha, workspace, workspace_bytes, st, &vis_list,
+                                            &vis_count))
+            return rc;
+    } else {
+        const hipError_t e = hipMemsetAsync(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
+        if (e != hipSuccess) return (int)e;
+    }
+    if (use_rgb && grad_textures) {
+        if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, weight_map, depth_map, grad_rgb_map,
+                                           grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st))
+            return rc;
+    }
+    if (use_depth) {
+        if (int rc = run_backward_depth_map(faces, depth_map, face_index_map, nullptr, weight_map, grad_depth_map,
+                                            grad_faces, B, F, S, vis_list, vis_count, st))
+            return rc;
+    }
+    return 0;
 }

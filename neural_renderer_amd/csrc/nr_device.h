@@ -165,4 +165,23 @@ inline int launch_status()
     return e == hipSuccess ? 0 : (int)e;
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// stage runners shared between the per-stage ABI entry points and the fused nr_backward_rasterize.
+// vis_list / vis_count (optional): per-image sorted lists of the faces that own at least one pixel, as built
+// by the K6 band pipeline ([B][F] ints, [B] counts); when given, the gather kernels visit only those faces.
+int run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
+                           const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
+                           float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
+                           void *workspace, size_t workspace_bytes, hipStream_t st, const int **vis_list_out,
+                           const int **vis_count_out);
+int run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
+                          const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                          const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F, int S,
+                          int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st);
+int run_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
+                           const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
+                           float *grad_faces, int B, int F, int S, const int *vis_list, const int *vis_count,
+                           hipStream_t st);
+
 }  // namespace nr

@@ -137,29 +137,20 @@ class _RasterizeFunction(torch.autograd.Function):
                 g_alpha = g_alpha.contiguous()
             if use_depth:
                 g_depth = g_depth.contiguous()
-            if use_rgb or use_alpha:
-                grad_faces = torch.empty_like(faces_c)  # K6 stores every element
-                ws_bytes = lib.nr_backward_workspace_bytes(B, F, S, int(use_rgb), int(use_alpha))
-                workspace = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
-                _lib.check(lib.nr_backward_pixel_map(
-                    faces_c.data_ptr(), face_index_map.data_ptr(), _lib.ptr(rgb_map) if use_rgb else None,
-                    _lib.ptr(alpha_map) if use_alpha else None, _lib.ptr(g_rgb) if use_rgb else None,
-                    _lib.ptr(g_alpha) if use_alpha else None, grad_faces.data_ptr(), B, F, S, float(cfg['eps']),
-                    int(use_rgb), int(use_alpha), workspace.data_ptr(), ws_bytes, stream), 'nr_backward_pixel_map')
-            else:
-                grad_faces = torch.zeros_like(faces_c)  # rasterize.py:851
+            grad_faces = torch.empty_like(faces_c)  # stored by the library (zeros when neither rgb nor alpha)
             grad_textures = None
             if use_rgb and ctx.needs_input_grad[1]:
-                grad_textures = torch.empty((B, F, ts, ts, ts, 3), dtype=torch.float32, device=dev)  # K7 stores all
-                _lib.check(lib.nr_backward_textures(
-                    face_index_map.data_ptr(), None, None, faces_c.data_ptr(), weight_map.data_ptr(),
-                    depth_map.data_ptr(), g_rgb.data_ptr(), grad_textures.data_ptr(), B, F, S, ts,
-                    float(cfg['eps']), cfg['flags'], stream), 'nr_backward_textures')
-            if use_depth:
-                _lib.check(lib.nr_backward_depth_map(
-                    faces_c.data_ptr(), depth_map.data_ptr(), face_index_map.data_ptr(), None,
-                    weight_map.data_ptr(), g_depth.data_ptr(), grad_faces.data_ptr(), B, F, S, stream),
-                    'nr_backward_depth_map')
+                grad_textures = torch.empty((B, F, ts, ts, ts, 3), dtype=torch.float32, device=dev)
+            ws_bytes = lib.nr_backward_workspace_bytes(B, F, S, int(use_rgb), int(use_alpha))
+            workspace = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+            # K6 -> K7 -> K8 (rasterize.py:881-883) behind one call
+            _lib.check(lib.nr_backward_rasterize(
+                faces_c.data_ptr(), face_index_map.data_ptr(), _lib.ptr(weight_map), _lib.ptr(depth_map),
+                _lib.ptr(rgb_map) if use_rgb else None, _lib.ptr(alpha_map) if use_alpha else None,
+                _lib.ptr(g_rgb) if use_rgb else None, _lib.ptr(g_alpha) if use_alpha else None,
+                _lib.ptr(g_depth) if use_depth else None, grad_faces.data_ptr(), _lib.ptr(grad_textures),
+                B, F, S, ts, float(cfg['eps']), cfg['flags'], workspace.data_ptr(), ws_bytes, stream),
+                'nr_backward_rasterize')
         return grad_faces, grad_textures, None
 
 

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Timings of the BASELINE.json configurations other than the headline one (and of the headline scene per mode),
+through the product's Rasterize operator.  One JSON line per row; run on the GPU box:
+    python scripts/bench_configs.py > gpurun_out/configs.jsonl
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import bench  # noqa: E402
+import neural_renderer_amd as nr  # noqa: E402
+
+dev = torch.device('cuda', 0)
+
+
+def timeit(fn, iters=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def run(name, faces, textures, S, modes, eps, iters=10):
+    rgb, alpha, depth = modes
+    faces = faces.clone().requires_grad_(True)
+    if textures is not None:
+        textures = textures.clone().requires_grad_(rgb)
+    B, F = faces.shape[:2]
+    gen = torch.Generator(device='cpu').manual_seed(7)
+    with torch.no_grad():
+        outs = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), rgb, alpha, depth)(faces, textures if rgb else None)
+        grads = [None if o is None else (2 * (o / (100.0 if k == 2 else 1.0) - torch.rand(o.shape, generator=gen).to(dev))
+                                         / (100.0 if k == 2 else 1.0)).contiguous() for k, o in enumerate(outs)]
+        cov = float((nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), False, True, False)(faces)[1]).mean())
+
+    def step():
+        faces.grad = None
+        if textures is not None:
+            textures.grad = None
+        o = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), rgb, alpha, depth)(faces, textures if rgb else None)
+        torch.autograd.backward([x for x in o if x is not None], [g for g in grads if g is not None])
+
+    def fwd():
+        with torch.no_grad():
+            nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), rgb, alpha, depth)(faces, textures if rgb else None)
+
+    ms = timeit(step, iters)
+    ms_f = timeit(fwd, iters)
+    print(json.dumps({'config': name, 'B': B, 'F': F, 'S': S, 'ts': 0 if textures is None else textures.shape[2],
+                      'modes': ''.join(c for c, m in zip('rad', modes) if m), 'coverage': round(cov, 4),
+                      'ms_fwd_bwd': round(ms, 4), 'ms_fwd': round(ms_f, 4),
+                      'mpixel_s': round(B * S * S / ms / 1e3, 1)}), flush=True)
+
+
+def main():
+    # headline scene, per mode, AA off (S 256) and AA on (S 512)
+    for S in (256, 512):
+        faces, textures = bench.build_scene(dev, 64, 0, 64, S, 2)
+        for name, modes, eps in (('H silhouette', (False, True, False), 1e-4), ('H rgb', (True, False, False), 1e-3),
+                                 ('H depth', (False, False, True), 1e-4), ('H rgb+alpha+depth', (True, True, True), 1e-3)):
+            run('%s S%d' % (name, S), faces, textures, S, modes, eps)
+    # config 2: 16 azimuth views, RGB + depth + silhouette
+    faces, textures = bench.build_scene(dev, 16, 0, 16, 256, 2)
+    run('C2 teapot 16 views', faces, textures, 256, (True, True, True), 1e-3)
+    # config 4 (per-GPU share): 64 distinct ~5k-face meshes (10 240 with fill_back), ts 4 random textures, 256x256 RGB
+    from test_hip_parity import icosphere, project_mesh
+    rng = np.random.default_rng(1234)
+    v0, f0 = icosphere(4)
+    batch = []
+    for _ in range(64):
+        v = v0 * (0.55 + 0.12 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+        q = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+        batch.append(project_mesh((v @ q).astype(np.float32), f0, [0.3, 0.4, -2.6]))
+    faces = torch.from_numpy(np.stack(batch)).to(dev)
+    textures = torch.rand((64, faces.shape[1], 4, 4, 4, 3), device=dev)
+    run('C4 64 random meshes x 10240 faces ts4', faces, textures, 256, (True, False, False), 1e-3)
+    del faces, textures
+    # config 5: one 327 680-face icosphere (655 360 with fill_back), 1024x1024, ts 8
+    v0, f0 = icosphere(7)
+    v = v0 * (0.6 + 0.02 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+    faces = torch.from_numpy(project_mesh(v.astype(np.float32), f0, [0.0, 0.0, -2.4])[None]).to(dev)
+    textures = torch.rand((1, faces.shape[1], 8, 8, 8, 3), device=dev)
+    run('C5 655k-face mesh 1024x1024 ts8', faces, textures, 1024, (True, True, True), 1e-3, iters=5)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests -m gpu -q -k "fallback or shapenet or high_res" 2>&1 | tail -12
+timeout 900 python scripts/bench_configs.py 2>&1 | tail -14 | tee gpurun_out/configs.jsonl

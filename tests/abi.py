@@ -99,3 +99,23 @@ def backward(fw, g_rgb=None, g_alpha=None, g_depth=None, use_sampling_maps=False
 
 def host(t):
     return None if t is None else t.detach().cpu().numpy()
+
+
+def backward_fused(fw, g_rgb=None, g_alpha=None, g_depth=None):
+    """nr_backward_rasterize (K6 -> K7 -> K8 behind one call) on the residuals of `forward`."""
+    lib = _lib.load()
+    B, F, S, ts = fw['B'], fw['F'], fw['S'], fw['ts']
+    gr = dev(g_rgb, torch.float32) if g_rgb is not None else None
+    ga = dev(g_alpha, torch.float32) if g_alpha is not None else None
+    gd = dev(g_depth, torch.float32) if g_depth is not None else None
+    grad_faces = torch.full((B, F, 3, 3), float('nan'), device='cuda')
+    grad_textures = torch.full((B, F, ts, ts, ts, 3), float('nan'), device='cuda') if gr is not None else None
+    wsb = lib.nr_backward_workspace_bytes(B, F, S, int(gr is not None), int(ga is not None))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device='cuda')
+    _lib.check(lib.nr_backward_rasterize(
+        fw['faces'].data_ptr(), fw['face_index_map'].data_ptr(), _lib.ptr(fw.get('weight_map')),
+        _lib.ptr(fw.get('depth_map')), _lib.ptr(fw.get('rgb_map')), _lib.ptr(fw.get('alpha_map')), _lib.ptr(gr),
+        _lib.ptr(ga), _lib.ptr(gd), grad_faces.data_ptr(), _lib.ptr(grad_textures), B, F, S, ts, fw['eps'],
+        fw['flags'], ws.data_ptr(), wsb, _stream()), 'bwd fused')
+    torch.cuda.synchronize()
+    return grad_faces, grad_textures

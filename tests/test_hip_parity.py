@@ -369,3 +369,22 @@ def test_high_resolution_dense_mesh():
     faces = project_mesh(v.astype(np.float32), f0, [0.0, 0.0, -2.4])[None]
     textures = rng.uniform(0, 1, (1, faces.shape[1], 8, 8, 8, 3)).astype(np.float32)
     check_backward(faces, textures, 192, 1e-3, (True, True, True), seed=34)
+
+
+@pytest.mark.parametrize('modes', [(True, True, True), (False, True, False), (False, False, True), (True, False, False)],
+                         ids=['all', 'alpha', 'depth', 'rgb'])
+def test_fused_backward_equals_stage_calls(modes):
+    """nr_backward_rasterize == nr_backward_pixel_map + nr_backward_textures + nr_backward_depth_map, bit for bit."""
+    rgb, alpha, depth = modes
+    faces, _ = H.teapot_views(3, 96)
+    rng = np.random.default_rng(41)
+    textures = rng.uniform(0, 1, (3, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    fw = abi.forward(faces, textures, 96, 0.1, 100.0, 1e-3, (0.1, 0.2, 0.3), 0, rgb, alpha, depth)
+    g_rgb = rng.normal(size=(3, 96, 96, 3)).astype(np.float32) if rgb else None
+    g_alpha = rng.normal(size=(3, 96, 96)).astype(np.float32) if alpha else None
+    g_depth = rng.normal(size=(3, 96, 96)).astype(np.float32) if depth else None
+    gf_a, gt_a = abi.backward(fw, g_rgb, g_alpha, g_depth)
+    gf_b, gt_b = abi.backward_fused(fw, g_rgb, g_alpha, g_depth)
+    np.testing.assert_array_equal(abi.host(gf_a), abi.host(gf_b))
+    if rgb:
+        np.testing.assert_array_equal(abi.host(gt_a), abi.host(gt_b))
