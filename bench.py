@@ -116,6 +116,14 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
             faces.data_ptr(), dm.data_ptr(), fi.data_ptr(), None, wm.data_ptr(), g_depth.data_ptr(), gf.data_ptr(),
             B, F, S, st),
     }
+    # the two fused entry points the autograd operator actually calls
+    calls['fused_forward_rasterize'] = lambda: lib.nr_forward_rasterize(
+        faces.data_ptr(), textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(),
+        am.data_ptr(), bg.data_ptr(), 0, B, F, S, ts, 0.1, 100.0, eps, 0, ws.data_ptr(), wsb, st)
+    calls['fused_backward_rasterize'] = lambda: lib.nr_backward_rasterize(
+        faces.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(), am.data_ptr(), g_rgb.data_ptr(),
+        g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(), gt.data_ptr(), B, F, S, ts, eps, 0, bws.data_ptr(), bwsb,
+        st)
     out = {}
     for name, call in calls.items():
         for _ in range(2):
@@ -255,7 +263,7 @@ def main():
             'backward_textures': ab['backward_textures'],
             'backward_depth_map': ab['backward_depth_map'],
         }
-        dominant = max(stages, key=stages.get)
+        dominant = max(stage_bytes, key=lambda k: stages[k])
         achieved = stage_bytes[dominant] / (stages[dominant] * 1e-6) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')

@@ -13,6 +13,7 @@
  *   nr_backward_pixel_map        <- Rasterize.backward_pixel_map_gpu        rasterize.py:517-748 (K6)
  *   nr_backward_textures         <- Rasterize.backward_textures_gpu         rasterize.py:750-792 (K7)
  *   nr_backward_depth_map        <- Rasterize.backward_depth_map_gpu        rasterize.py:794-847 (K8)
+ *   nr_forward_rasterize         <- Rasterize.forward_gpu  (K1+K2 -> K4+K5 fused) rasterize.py:467-513
  *   nr_backward_rasterize        <- Rasterize.backward_gpu (K6 -> K7 -> K8 fused)  rasterize.py:849-889
  *
  * Conventions
@@ -123,6 +124,17 @@ int nr_backward_textures(const int32_t *face_index_map, const float *sampling_we
 int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                           const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
                           float *grad_faces, int32_t batch_size, int32_t num_faces, int32_t image_size, void *stream);
+
+/*
+ * Fused forward = Rasterize.forward_gpu (rasterize.py:467-513): nr_forward_face_index_map followed by
+ * nr_forward_texture_sampling, identical results, one resolve pass (the winner is shaded while still in
+ * registers).  rgb_map / alpha_map / weight_map / depth_map are each optional (NULL = not requested).
+ */
+int nr_forward_rasterize(const float *faces, const float *textures, int32_t *face_index_map, float *weight_map,
+                         float *depth_map, float *rgb_map, float *alpha_map, const float *background,
+                         int32_t bg_per_batch, int32_t batch_size, int32_t num_faces, int32_t image_size,
+                         int32_t texture_size, double near, double far, double eps, int32_t flags, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /*
  * Fused backward = Rasterize.backward_gpu (rasterize.py:849-889): K6, then K7, then K8, identical results to the

@@ -164,62 +164,16 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces, const float *__restrict__ ws_inv,
-                                                 const unsigned long long *__restrict__ zbuf,
-                                                 int32_t *__restrict__ face_index_map, float *__restrict__ weight_map,
-                                                 float *__restrict__ depth_map, float *__restrict__ face_inv_map,
-                                                 int F, int S, double near_d, double far_d, size_t n_pixels)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
-    const unsigned long long pk = zbuf[i];
-    int fn = -1;
-    float zp = (float)far_d, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;  // rasterize.py:296, :478-480
-    const float *iv = nullptr;
-    if (pk != ZEMPTY) {
-        fn = (int)(unsigned)(pk & 0xffffffffu);
-        const size_t SS = (size_t)S * S;
-        const int b = (int)(i / SS);
-        const int pn = (int)(i - (size_t)b * SS);
-        const int py = pn / S, px = pn - py * S;
-        const float *f = faces + ((size_t)b * F + fn) * 9;
-        iv = ws_inv + ((size_t)b * F + fn) * 9;
-        FaceGeo g;
-        g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
-        g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5]; g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
-        eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, near_d, far_d, zp, w0, w1, w2);
-    }
-    face_index_map[i] = fn;
-    if (depth_map) depth_map[i] = zp;
-    if (weight_map) {
-        float *w = weight_map + 3 * i;
-        w[0] = w0;
-        w[1] = w1;
-        w[2] = w2;
-    }
-    if (face_inv_map) {
-        float *o = face_inv_map + 9 * i;
-#pragma unroll
-        for (int k = 0; k < 9; k++) o[k] = (fn >= 0) ? iv[k] : 0.0f;
-    }
-}
-
 // --------------------------------------------------------------------------------------------------
 // F3: shading, one pixel per thread (linear pixel index: fully coalesced map traffic).
-__global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, const float *__restrict__ textures,
-                                               const int32_t *__restrict__ face_index_map,
-                                               const float *__restrict__ weight_map,
-                                               const float *__restrict__ depth_map, float *__restrict__ rgb_map,
-                                               int32_t *__restrict__ sampling_index_map,
-                                               float *__restrict__ sampling_weight_map,
-                                               const float *__restrict__ background, int bg_per_batch,
-                                               float *__restrict__ alpha_map, int F, int S, int ts, double eps,
-                                               int fix_batch_z, size_t n_pixels)
+// Shading of one pixel (K4 + K5, rasterize.py:361-465): shared by k_shade and the fused k_resolve.
+__device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, float w1, float w2, float depth,
+                                            const float *__restrict__ faces, const float *__restrict__ textures,
+                                            float *__restrict__ rgb_map, int32_t *__restrict__ sampling_index_map,
+                                            float *__restrict__ sampling_weight_map,
+                                            const float *__restrict__ background, int bg_per_batch,
+                                            float *__restrict__ alpha_map, int F, int ts, double eps, int fix_batch_z)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
-    const int fi = face_index_map[i];
-    const int b = (int)(i / ((size_t)S * S));
     if (alpha_map) alpha_map[i] = (fi >= 0) ? 1.0f : 0.0f;  // :449
     if (!rgb_map) return;
     float rgb[3];
@@ -227,8 +181,8 @@ __global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, 
     if (fi >= 0) {
         const float *face = faces + ((size_t)(fix_batch_z ? b : 0) * F + fi) * 9;  // :389 (Q1)
         const float *texture = textures + ((size_t)b * F + fi) * ts * ts * ts * 3;   // :390
-        const float w[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
-        compute_taps(face, w, depth_map[i], ts, eps, t);
+        const float w[3] = {w0, w1, w2};
+        compute_taps(face, w, depth, ts, eps, t);
         rgb[0] = rgb[1] = rgb[2] = 0.0f;
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {
@@ -262,6 +216,75 @@ __global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, 
         p[0] = make_float4(t.w[0], t.w[1], t.w[2], t.w[3]);
         p[1] = make_float4(t.w[4], t.w[5], t.w[6], t.w[7]);
     }
+}
+
+__global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, const float *__restrict__ textures,
+                                               const int32_t *__restrict__ face_index_map,
+                                               const float *__restrict__ weight_map,
+                                               const float *__restrict__ depth_map, float *__restrict__ rgb_map,
+                                               int32_t *__restrict__ sampling_index_map,
+                                               float *__restrict__ sampling_weight_map,
+                                               const float *__restrict__ background, int bg_per_batch,
+                                               float *__restrict__ alpha_map, int F, int S, int ts, double eps,
+                                               int fix_batch_z, size_t n_pixels)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const int fi = face_index_map[i];
+    const int b = (int)(i / ((size_t)S * S));
+    float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, depth = 0.0f;
+    if (rgb_map && fi >= 0) { w0 = weight_map[3 * i]; w1 = weight_map[3 * i + 1]; w2 = weight_map[3 * i + 2]; depth = depth_map[i]; }
+    shade_pixel(i, b, fi, w0, w1, w2, depth, faces, textures, rgb_map, sampling_index_map, sampling_weight_map, background,
+                bg_per_batch, alpha_map, F, ts, eps, fix_batch_z);
+}
+
+__global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces, const float *__restrict__ ws_inv,
+                                                 const unsigned long long *__restrict__ zbuf,
+                                                 int32_t *__restrict__ face_index_map, float *__restrict__ weight_map,
+                                                 float *__restrict__ depth_map, float *__restrict__ face_inv_map,
+                                                 int F, int S, double near_d, double far_d, size_t n_pixels,
+                                                 // fused shading (all NULL / 0 when not requested)
+                                                 const float *__restrict__ textures, float *__restrict__ rgb_map,
+                                                 const float *__restrict__ background, int bg_per_batch,
+                                                 float *__restrict__ alpha_map, int ts, double eps, int fix_batch_z)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const unsigned long long pk = zbuf[i];
+    int fn = -1;
+    float zp = (float)far_d, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;  // rasterize.py:296, :478-480
+    const float *iv = nullptr;
+    int b = 0;
+    if (rgb_map || alpha_map) b = (int)(i / ((size_t)S * S));
+    if (pk != ZEMPTY) {
+        fn = (int)(unsigned)(pk & 0xffffffffu);
+        const size_t SS = (size_t)S * S;
+        b = (int)(i / SS);
+        const int pn = (int)(i - (size_t)b * SS);
+        const int py = pn / S, px = pn - py * S;
+        const float *f = faces + ((size_t)b * F + fn) * 9;
+        iv = ws_inv + ((size_t)b * F + fn) * 9;
+        FaceGeo g;
+        g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
+        g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5]; g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
+        eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, near_d, far_d, zp, w0, w1, w2);
+    }
+    face_index_map[i] = fn;
+    if (depth_map) depth_map[i] = zp;
+    if (weight_map) {
+        float *w = weight_map + 3 * i;
+        w[0] = w0;
+        w[1] = w1;
+        w[2] = w2;
+    }
+    if (face_inv_map) {
+        float *o = face_inv_map + 9 * i;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = (fn >= 0) ? iv[k] : 0.0f;
+    }
+    if (rgb_map || alpha_map)
+        shade_pixel(i, b, fn, w0, w1, w2, zp, faces, textures, rgb_map, nullptr, nullptr, background, bg_per_batch, alpha_map,
+                    F, ts, eps, fix_batch_z);
 }
 
 }  // namespace
@@ -304,16 +327,17 @@ NR_API size_t nr_forward_workspace_bytes(int32_t B, int32_t F, int32_t S)
     return fwd_layout(B, F, S).total;
 }
 
-NR_API int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map,
-                                     float *face_inv_map, int32_t B, int32_t F, int32_t S, double near, double far,
-                                     void *workspace, size_t workspace_bytes, void *stream)
+namespace {
+int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map, float *face_inv_map,
+                int B, int F, int S, double near, double far, void *workspace, size_t workspace_bytes, hipStream_t st,
+                const float *textures, float *rgb_map, const float *background, int bg_per_batch, float *alpha_map,
+                int ts, double eps, int fix_batch_z)
 {
     if (!faces || !face_index_map) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
     if (!(near > 0.0)) return NR_E_SIZE;  // the packed z-buffer needs positive depths (reference default 0.1)
     const FwdLayout L = fwd_layout(B, F, S);
     if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)B * F, P = (size_t)B * S * S;
     unsigned char *ws = (unsigned char *)workspace;
     float *ws_inv = (float *)(ws + L.inv_off);
@@ -321,17 +345,45 @@ NR_API int nr_forward_face_index_map(const float *faces, int32_t *face_index_map
     int *n_large = (int *)(ws + L.count_off);
     int *large_list = (int *)(ws + L.list_off);
 
-    hipError_t he = hipMemsetAsync(zbuf, 0xff, P * sizeof(unsigned long long), st);  // ZEMPTY
+    // ZEMPTY words and, right behind them, the large-face counter (0xffffffff + 1 == 0 would also do, but keep it plain)
+    hipError_t he = hipMemsetAsync(zbuf, 0xff, P * sizeof(unsigned long long), st);
     if (he != hipSuccess) return (int)he;
     he = hipMemsetAsync(n_large, 0, sizeof(int), st);
     if (he != hipSuccess) return (int)he;
     hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
                        large_list, n_large, (int)n, F, S, near, far);
-    hipLaunchKernelGGL(k_large_raster, dim3(1024), dim3(256), 0, st, faces, ws_inv, zbuf, large_list, n_large, F, S,
+    hipLaunchKernelGGL(k_large_raster, dim3(256), dim3(256), 0, st, faces, ws_inv, zbuf, large_list, n_large, F, S,
                        near, far);
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
-                       face_index_map, weight_map, depth_map, face_inv_map, F, S, near, far, P);
+                       face_index_map, weight_map, depth_map, face_inv_map, F, S, near, far, P, textures, rgb_map,
+                       background, bg_per_batch, alpha_map, ts, eps, fix_batch_z);
     return launch_status();
+}
+}  // namespace
+
+NR_API int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map,
+                                     float *face_inv_map, int32_t B, int32_t F, int32_t S, double near, double far,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    return run_forward(faces, face_index_map, weight_map, depth_map, face_inv_map, B, F, S, near, far, workspace,
+                       workspace_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, 0, nullptr, 0, 0.0, 0);
+}
+
+// Fused forward = Rasterize.forward_gpu (rasterize.py:467-513): visibility, texture sampling, background and alpha
+// behind one entry point; the shading runs inside the resolve pass, on the winner still in registers.
+NR_API int nr_forward_rasterize(const float *faces, const float *textures, int32_t *face_index_map, float *weight_map,
+                                float *depth_map, float *rgb_map, float *alpha_map, const float *background,
+                                int32_t bg_per_batch, int32_t B, int32_t F, int32_t S, int32_t ts, double near,
+                                double far, double eps, int32_t flags, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    if (rgb_map) {
+        if (!textures || !background) return NR_E_NULL;
+        if (ts < 2 || ts > 1024) return NR_E_SIZE;
+    }
+    return run_forward(faces, face_index_map, weight_map, depth_map, nullptr, B, F, S, near, far, workspace,
+                       workspace_bytes, (hipStream_t)stream, textures, rgb_map, background, bg_per_batch, alpha_map, ts,
+                       eps, (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0);
 }
 
 NR_API int nr_forward_texture_sampling(const float *faces, const float *textures, const int32_t *face_index_map,

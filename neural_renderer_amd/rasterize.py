@@ -39,6 +39,21 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_BG_CACHE = {}
+
+
+def _background_tensor(bg, device):
+    """Device copy of a host background colour, cached (a pageable H2D copy per call would serialise the stream)."""
+    arr = np.asarray(bg, dtype=np.float32)
+    key = (str(device), arr.shape, arr.tobytes())
+    t = _BG_CACHE.get(key)
+    if t is None:
+        if len(_BG_CACHE) > 64:
+            _BG_CACHE.clear()
+        t = _BG_CACHE[key] = torch.as_tensor(arr, device=device)
+    return t
+
+
 class _RasterizeFunction(torch.autograd.Function):
     """forward(ctx, faces, textures, cfg) -> (rgb_map [B,S,S,3] | None, alpha_map [B,S,S] | None,
     depth_map [B,S,S] | None); backward(ctx, g_rgb, g_alpha, g_depth) -> (grad_faces, grad_textures, None)."""
@@ -80,11 +95,6 @@ class _RasterizeFunction(torch.autograd.Function):
             if ws_bytes == 0:
                 raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
             workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-            _lib.check(lib.nr_forward_face_index_map(
-                faces_c.data_ptr(), face_index_map.data_ptr(), _lib.ptr(weight_map), _lib.ptr(depth_map), None,
-                B, F, S, float(cfg['near']), float(cfg['far']), workspace.data_ptr(), ws_bytes, stream),
-                'nr_forward_face_index_map')
-
             rgb_map = alpha_map = background = None
             bg_per_batch = 0
             if return_rgb:
@@ -93,7 +103,7 @@ class _RasterizeFunction(torch.autograd.Function):
                 if torch.is_tensor(bg):
                     background = bg.detach().to(device=dev, dtype=torch.float32).contiguous()
                 else:
-                    background = torch.as_tensor(np.asarray(bg, dtype=np.float32), device=dev)
+                    background = _background_tensor(bg, dev)
                 if tuple(background.shape) == (B, 3):
                     bg_per_batch = 1  # rasterize.py:464-465
                 elif tuple(background.shape) != (3,):
@@ -101,12 +111,12 @@ class _RasterizeFunction(torch.autograd.Function):
             if return_alpha:
                 alpha_map = torch.empty((B, S, S), dtype=torch.float32, device=dev)
             flags = _lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg['fix_batch_z'] else 0
-            if return_rgb or return_alpha:
-                _lib.check(lib.nr_forward_texture_sampling(
-                    faces_c.data_ptr(), _lib.ptr(textures_c), face_index_map.data_ptr(), _lib.ptr(weight_map),
-                    _lib.ptr(depth_map), _lib.ptr(rgb_map), None, None, _lib.ptr(background), bg_per_batch,
-                    _lib.ptr(alpha_map), B, F, S, ts, float(cfg['eps']), flags, stream),
-                    'nr_forward_texture_sampling')
+            # visibility + shading behind one call (rasterize.py:499-502)
+            _lib.check(lib.nr_forward_rasterize(
+                faces_c.data_ptr(), _lib.ptr(textures_c), face_index_map.data_ptr(), _lib.ptr(weight_map),
+                _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(alpha_map), _lib.ptr(background), bg_per_batch,
+                B, F, S, ts, float(cfg['near']), float(cfg['far']), float(cfg['eps']), flags, workspace.data_ptr(),
+                ws_bytes, stream), 'nr_forward_rasterize')
 
         ctx.cfg = dict(cfg, B=B, F=F, S=S, ts=ts, flags=flags)
         # residuals (the reference keeps them on `self`, rasterize.py:39-58); outputs among them go through

@@ -119,3 +119,33 @@ def backward_fused(fw, g_rgb=None, g_alpha=None, g_depth=None):
         fw['flags'], ws.data_ptr(), wsb, _stream()), 'bwd fused')
     torch.cuda.synchronize()
     return grad_faces, grad_textures
+
+
+def forward_fused(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, background=(0, 0, 0), flags=0,
+                  return_rgb=False, return_alpha=True, return_depth=False):
+    """nr_forward_rasterize (visibility + shading behind one call)."""
+    lib = _lib.load()
+    f = dev(faces, torch.float32)
+    B, F = f.shape[:2]
+    out = {'faces': f, 'face_index_map': torch.full((B, S, S), 12345, dtype=torch.int32, device='cuda'),
+           'weight_map': torch.full((B, S, S, 3), float('nan'), device='cuda'),
+           'depth_map': torch.full((B, S, S), float('nan'), device='cuda')}
+    t = bg = None
+    ts, per_batch = 0, 0
+    if return_rgb:
+        t = dev(textures, torch.float32)
+        ts = t.shape[2]
+        bg = dev(np.asarray(background, np.float32))
+        per_batch = int(bg.dim() == 2)
+        out['rgb_map'] = torch.full((B, S, S, 3), float('nan'), device='cuda')
+    if return_alpha:
+        out['alpha_map'] = torch.full((B, S, S), float('nan'), device='cuda')
+    wsb = lib.nr_forward_workspace_bytes(B, F, S)
+    ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+    _lib.check(lib.nr_forward_rasterize(
+        f.data_ptr(), _lib.ptr(t), out['face_index_map'].data_ptr(), out['weight_map'].data_ptr(),
+        out['depth_map'].data_ptr(), _lib.ptr(out.get('rgb_map')), _lib.ptr(out.get('alpha_map')), _lib.ptr(bg),
+        per_batch, B, F, S, ts, near, far, eps, flags, ws.data_ptr(), wsb, _stream()), 'fwd fused')
+    torch.cuda.synchronize()
+    out.update(B=B, F=F, S=S, ts=ts, eps=eps, flags=flags, textures=t)
+    return out

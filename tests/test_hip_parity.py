@@ -388,3 +388,15 @@ def test_fused_backward_equals_stage_calls(modes):
     np.testing.assert_array_equal(abi.host(gf_a), abi.host(gf_b))
     if rgb:
         np.testing.assert_array_equal(abi.host(gt_a), abi.host(gt_b))
+
+
+def test_fused_forward_equals_stage_calls():
+    """nr_forward_rasterize == nr_forward_face_index_map + nr_forward_texture_sampling, bit for bit."""
+    faces, _ = H.teapot_views(3, 100)
+    rng = np.random.default_rng(43)
+    textures = rng.uniform(0, 1, (3, faces.shape[1], 4, 4, 4, 3)).astype(np.float32)
+    bg = rng.uniform(0, 1, (3, 3)).astype(np.float32)
+    a = abi.forward(faces, textures, 100, 0.1, 100.0, 1e-3, bg, 1, True, True, True)
+    b = abi.forward_fused(faces, textures, 100, 0.1, 100.0, 1e-3, bg, 1, True, True, True)
+    for k in ('face_index_map', 'weight_map', 'depth_map', 'rgb_map', 'alpha_map'):
+        np.testing.assert_array_equal(abi.host(a[k]), abi.host(b[k]), err_msg=k)
