@@ -31,13 +31,16 @@ __device__ __forceinline__ float group_sum(float v, int width)
 // B2: one face per group of L lanes (L = 16 | 64 | 256, a power of two; 256 / L faces per workgroup).
 // TS2 = true: texture_size == 2 and eps > 0, so every tap index is static: corner pn -> texel
 // (pn & 1) * 4 + ((pn >> 1) & 1) * 2 + ((pn >> 2) & 1)   (floor(tif) == 0 because tif <= 1 - eps, :402).
-template <bool TS2>
+// DEPTH = true additionally evaluates K8 (backward_depth_map) for the same owned pixels and adds the face's 9
+// sums onto grad_faces, so that one walk of the screen box serves both gradients (fused backward only).
+template <bool TS2, bool DEPTH>
 __global__ __launch_bounds__(256) void k_backward_textures_face(
     const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
     const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
     const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
     float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z, int L,
-    const int *__restrict__ vis_list, const int *__restrict__ vis_count)
+    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
+    float *__restrict__ grad_faces)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
 
@@ -56,6 +59,10 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     float acc[24];
 #pragma unroll
     for (int k = 0; k < 24; k++) acc[k] = 0.0f;
+    float dacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) dacc[k] = 0.0f;
+    bool any_box = false;
     if (!TS2) {
         for (int k = sub; k < n_tex; k += L) acc_l[k] = 0.0;
         __syncthreads();
@@ -66,6 +73,16 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         const float *f = faces + (size_t)gi * 9;
         const BBox bb = face_bbox(f[0], f[1], f[3], f[4], f[6], f[7], S);
         if (bb.x_lo <= bb.x_hi) {
+            any_box = true;
+            float inv[9], fv[9];
+            if (DEPTH) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) fv[k] = f[k];
+                const float fs = (float)S;
+                const float px[3] = {to_pixel(fv[0], fs), to_pixel(fv[3], fs), to_pixel(fv[6], fs)};
+                const float py[3] = {to_pixel(fv[1], fs), to_pixel(fv[4], fs), to_pixel(fv[7], fs)};
+                compute_face_inv(px, py, inv);
+            }
             // z of the three vertices as the forward sampled them: batch 0's geometry unless fixed (:389, Q1)
             const float *fz = faces + ((size_t)(fix_batch_z ? b : 0) * F + fn) * 9;
             const float face_z[9] = {0, 0, fz[2], 0, 0, fz[5], 0, 0, fz[8]};
@@ -86,6 +103,26 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                 } else {
                     const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
                     compute_taps(face_z, w, depth_map[p], ts, eps, t);
+                }
+                if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
+                    const float depth = depth_map[p];
+                    const float depth2 = depth * depth;
+                    const float wk[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                    const float gd = g_depth[p];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const float z_k = fv[3 * k + 2];
+                        dacc[3 * k + 2] += gd * wk[k] * depth2 / (z_k * z_k);
+                    }
+                    float tmp[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int l = 0; l < 3; l++) tmp[k] += -inv[3 * l + k] / fv[3 * l + 2];
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int l = 0; l < 2; l++) dacc[3 * k + l] += -gd * tmp[l] * wk[k] * depth2 * (float)S / 2.0f;
                 }
                 const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
 #pragma unroll
@@ -127,6 +164,16 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         if (face_ok) {
             float *dst = grad_textures + (size_t)gi * n_tex;
             for (int k = sub; k < n_tex; k += L) dst[k] = (float)acc_l[k];
+        }
+    }
+    if (DEPTH) {  // L <= 64 here (the host only fuses when a face group fits in one wave)
+        if (__ballot(any_box) == 0ull) return;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dacc[k] = group_sum(dacc[k], L);
+        if (face_ok && any_box && sub == 0) {
+            float *gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) gf[k] += dacc[k];
         }
     }
 }
@@ -259,8 +306,9 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
                               const int32_t *sampling_index_map, const float *faces, const float *weight_map,
                               const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F,
                               int S, int ts, double eps, int flags, const int *vis_list, const int *vis_count,
-                              hipStream_t st)
+                              hipStream_t st, const float *g_depth, float *grad_faces, int *depth_done)
 {
+    if (depth_done) *depth_done = 0;
     if (!face_index_map || !grad_rgb_map || !grad_textures || !faces) return NR_E_NULL;
     if ((sampling_index_map == nullptr) != (sampling_weight_map == nullptr)) return NR_E_MODE;
     if (!sampling_weight_map && (!weight_map || !depth_map)) return NR_E_NULL;
@@ -270,6 +318,9 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     const int n = B * F;
     const size_t n_tex = (size_t)ts * ts * ts * 3;
     if (ts > 13) vis_list = nullptr;  // the atomic fallback walks pixels, not faces
+    if (ts > 8 || sampling_weight_map || !grad_faces) g_depth = nullptr;  // K8 is fused only into the one-wave-per-group gathers
+    if (ts == 2 && !(eps > 0.0)) g_depth = nullptr;
+    if (g_depth && depth_done) *depth_done = 1;
     if (vis_list) {
         // only visible faces are visited: everything else is zero
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
@@ -277,17 +328,27 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     }
     if (ts == 2 && eps > 0.0 && !sampling_weight_map) {
         const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
-        hipLaunchKernelGGL((k_backward_textures_face<true>), grid, dim3(256), 0, st, face_index_map,
-                           sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
-                           grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count);
+        if (g_depth)
+            hipLaunchKernelGGL((k_backward_textures_face<true, true>), grid, dim3(256), 0, st, face_index_map,
+                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces);
+        else
+            hipLaunchKernelGGL((k_backward_textures_face<true, false>), grid, dim3(256), 0, st, face_index_map,
+                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, nullptr, nullptr);
     } else if (ts <= 13) {
         const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
         const int per = 256 / L;
         const size_t lds = (size_t)per * n_tex * sizeof(double);
         const dim3 grid = vis_list ? dim3((unsigned)((F + per - 1) / per), (unsigned)B) : dim3((unsigned)((n + per - 1) / per));
-        hipLaunchKernelGGL((k_backward_textures_face<false>), grid, dim3(256), lds, st, face_index_map,
-                           sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
-                           grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count);
+        if (g_depth && L <= 64)
+            hipLaunchKernelGGL((k_backward_textures_face<false, true>), grid, dim3(256), lds, st, face_index_map,
+                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces);
+        else
+            hipLaunchKernelGGL((k_backward_textures_face<false, false>), grid, dim3(256), lds, st, face_index_map,
+                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, nullptr, nullptr);
     } else {
         // huge cubes: the reference's per-pixel scatter with hardware atomics
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
@@ -321,7 +382,7 @@ NR_API int nr_backward_textures(const int32_t *face_index_map, const float *samp
 {
     return run_backward_textures(face_index_map, sampling_weight_map, sampling_index_map, faces, weight_map, depth_map,
                                  grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, nullptr, nullptr,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 NR_API int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,

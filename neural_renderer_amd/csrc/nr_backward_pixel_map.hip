@@ -819,12 +819,15 @@ NR_API int nr_backward_rasterize(const float *faces, const int32_t *face_index_m
         const hipError_t e = hipMemsetAsync(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
         if (e != hipSuccess) return (int)e;
     }
+    int depth_done = 0;
     if (use_rgb && grad_textures) {
+        // when both gradients are wanted, K8 rides along in the K7 gather (one walk of each face's screen box)
         if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, weight_map, depth_map, grad_rgb_map,
-                                           grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st))
+                                           grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
+                                           use_depth ? grad_depth_map : nullptr, grad_faces, &depth_done))
             return rc;
     }
-    if (use_depth) {
+    if (use_depth && !depth_done) {
         if (int rc = run_backward_depth_map(faces, depth_map, face_index_map, nullptr, weight_map, grad_depth_map,
                                             grad_faces, B, F, S, vis_list, vis_count, st))
             return rc;

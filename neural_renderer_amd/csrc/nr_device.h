@@ -178,7 +178,8 @@ int run_backward_pixel_map(const float *faces, const int32_t *face_index_map, co
 int run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
                           const int32_t *sampling_index_map, const float *faces, const float *weight_map,
                           const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F, int S,
-                          int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st);
+                          int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st,
+                          const float *g_depth_fused, float *grad_faces_fused, int *depth_done);
 int run_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                            const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
                            float *grad_faces, int B, int F, int S, const int *vis_list, const int *vis_count,

@@ -1,2 +1,4 @@
-timeout 600 python -m pytest tests -m gpu -q -k "backward or fused" 2>&1 | tail -3
-for kb in 80 53 48 40; do NR_K6_LDS_KB=$kb TAG=lds$kb ITERS=10 python scripts/stage_times.py 2>&1 | tail -1 | cut -c60-150; done
+timeout 300 python bench.py --steps 20 --warmup 3 --cpu-sample-views 0 2> gpurun_out/bench.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['launch_mode'], d['eager_ms_per_step']); print(d['stages_us']); print(d['grad_check'])"
+tail -3 gpurun_out/bench.err
