@@ -92,7 +92,15 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
             for (int i = sub; i < n_px; i += L) {
                 const int yy = i / bw;
                 const size_t p = img + (size_t)(bb.y_lo + yy) * S + (bb.x_lo + (i - yy * bw));
-                if (face_index_map[p] != fn) continue;
+                // every operand of the pixel is requested before the ownership test: one memory round trip per
+                // box pixel instead of two dependent ones (the kernel is bound by that latency, not by bandwidth)
+                const int fi_p = face_index_map[p];
+                float wk[3] = {0.0f, 0.0f, 0.0f}, depth = 0.0f, gd = 0.0f;
+                if (weight_map) { wk[0] = weight_map[3 * p]; wk[1] = weight_map[3 * p + 1]; wk[2] = weight_map[3 * p + 2]; }
+                if (depth_map) depth = depth_map[p];
+                if (DEPTH) gd = g_depth[p];
+                const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
+                if (fi_p != fn) continue;
                 Taps t;
                 if (sampling_weight_map) {
 #pragma unroll
@@ -101,14 +109,10 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                         t.isc[pn] = sampling_index_map[8 * p + pn];
                     }
                 } else {
-                    const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
-                    compute_taps(face_z, w, depth_map[p], ts, eps, t);
+                    compute_taps(face_z, wk, depth, ts, eps, t);
                 }
                 if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
-                    const float depth = depth_map[p];
                     const float depth2 = depth * depth;
-                    const float wk[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
-                    const float gd = g_depth[p];
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const float z_k = fv[3 * k + 2];
@@ -124,7 +128,6 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 #pragma unroll
                         for (int l = 0; l < 2; l++) dacc[3 * k + l] += -gd * tmp[l] * wk[k] * depth2 * (float)S / 2.0f;
                 }
-                const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
 #pragma unroll
                 for (int pn = 0; pn < 8; pn++) {
                     if (TS2) {
@@ -261,15 +264,16 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
             for (int i = sub; i < n_px; i += L) {
                 const int yy = i / bw;
                 const size_t p = img + (size_t)(bb.y_lo + yy) * S + (bb.x_lo + (i - yy * bw));
-                if (face_index_map[p] != fn) continue;
+                const int fi_p = face_index_map[p];  // operands requested before the ownership test (see K7)
+                const float depth = depth_map[p];
+                const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                const float gd = g_depth[p];
+                if (fi_p != fn) continue;
                 if (face_inv_map) {
 #pragma unroll
                     for (int k = 0; k < 9; k++) inv[k] = face_inv_map[9 * p + k];
                 }
-                const float depth = depth_map[p];
                 const float depth2 = depth * depth;
-                const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
-                const float gd = g_depth[p];
                 // :824-827
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
