@@ -265,33 +265,58 @@ __global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict_
     if (fi >= 0) flags[(i / SS) * F + fi] = 1;
 }
 
-__global__ __launch_bounds__(1024) void k_compact_visible(const unsigned char *__restrict__ flags,
-                                                          int *__restrict__ vis_list, int *__restrict__ vis_count,
-                                                          int F)
+// Ordered compaction in two launches so that a single huge mesh (config 5: 655 360 faces, B = 1) is not
+// serialised in one workgroup: k_count_visible counts the flags of each 1024-face chunk, k_compact_visible
+// turns the counts of the preceding chunks into the chunk's offset and writes the face indices in order.
+constexpr int VIS_CHUNK = 1024;
+
+__global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char *__restrict__ flags,
+                                                             int *__restrict__ chunk_count, int F, int n_chunks)
 {
-    __shared__ int s_wcnt[16];
-    __shared__ int s_base;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_base = 0;
+    __shared__ int s_wcnt[VIS_CHUNK / 64];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fn = chunk * VIS_CHUNK + tid;
+    const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
+    const unsigned long long m = __ballot(v);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
     __syncthreads();
-    for (int base = 0; base < F; base += 1024) {
-        const int fn = base + tid;
-        const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
-        const unsigned long long m = __ballot(v);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
-        if (v) vis_list[(size_t)b * F + off + __popcll(m & ((1ull << lane) - 1ull))] = fn;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w) tot += s_wcnt[w];
-            s_base += tot;
-        }
-        __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < VIS_CHUNK / 64; ++w) tot += s_wcnt[w];
+        chunk_count[(size_t)b * n_chunks + chunk] = tot;
     }
-    if (tid == 0) vis_count[b] = s_base;
+}
+
+__global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned char *__restrict__ flags,
+                                                               const int *__restrict__ chunk_count,
+                                                               int *__restrict__ vis_list, int *__restrict__ vis_count,
+                                                               int F, int n_chunks)
+{
+    __shared__ int s_wcnt[VIS_CHUNK / 64];
+    __shared__ int s_part[VIS_CHUNK / 64];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // offset of this chunk = sum of the counts of the chunks before it
+    int part = 0;
+    for (int c = tid; c < chunk; c += VIS_CHUNK) part += chunk_count[(size_t)b * n_chunks + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+    const int fn = chunk * VIS_CHUNK + tid;
+    const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
+    const unsigned long long m = __ballot(v);
+    if (lane == 0) { s_part[wave] = part; s_wcnt[wave] = __popcll(m); }
+    __syncthreads();
+    int off = 0, own = 0;
+    for (int w = 0; w < VIS_CHUNK / 64; ++w) {
+        off += s_part[w];
+        if (w < wave) off += s_wcnt[w];
+        own += s_wcnt[w];
+    }
+    if (v) vis_list[(size_t)b * F + off + __popcll(m & ((1ull << lane) - 1ull))] = fn;
+    if (chunk == n_chunks - 1 && tid == 0) {
+        int base = 0;
+        for (int w = 0; w < VIS_CHUNK / 64; ++w) base += s_part[w];
+        vis_count[b] = base + own;
+    }
 }
 
 // exclusive scan of one int per thread over the workgroup; returns the exclusive prefix, *total = sum
@@ -656,7 +681,8 @@ __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__
 // ====================================================================================================
 
 struct BpmLayout {
-    size_t flags_off, scratch_off, count_off, list_off, total, zero_bytes;
+    size_t flags_off, scratch_off, count_off, chunk_off, list_off, total, zero_bytes;
+    int n_chunks;
 };
 
 BpmLayout bpm_layout(int B, int F)
@@ -667,7 +693,9 @@ BpmLayout bpm_layout(int B, int F)
     L.scratch_off = align_up(n, 256);                       // flags: n bytes
     L.zero_bytes = L.scratch_off + n * 6 * sizeof(double);  // flags + scratch are zeroed by one memset
     L.count_off = align_up(L.zero_bytes, 256);
-    L.list_off = L.count_off + align_up((size_t)B * sizeof(int), 256);
+    L.n_chunks = (F + VIS_CHUNK - 1) / VIS_CHUNK;
+    L.chunk_off = L.count_off + align_up((size_t)B * sizeof(int), 256);
+    L.list_off = L.chunk_off + align_up((size_t)B * L.n_chunks * sizeof(int), 256);
     L.total = L.list_off + n * sizeof(int);
     return L;
 }
@@ -769,7 +797,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const size_t P = (size_t)B * S * S;
     hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, face_index_map, flags, F,
                        S * S, P);
-    hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)B), dim3(1024), 0, st, flags, vis_list, vis_count, F);
+    int *chunk_count = (int *)(ws + L.chunk_off);
+    hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, flags,
+                       chunk_count, F, L.n_chunks);
+    hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, flags,
+                       chunk_count, vis_list, vis_count, F, L.n_chunks);
     const char *fa = getenv("NR_K6_FAST");  // 1: hardware reciprocal + per-segment float sums (-7 % time)
     const bool exact = !(fa && atoi(fa));
     int rc;
