@@ -710,7 +710,9 @@ int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes)
     const char *env = getenv("NR_K6_LDS_KB");  // tuning knob: LDS budget per workgroup (default: two per CU)
     const size_t budget = (env ? (size_t)atoi(env) : 80) * 1024;
     const size_t SP = (size_t)S + 4;
-    for (int W = 16; W >= 1; W >>= 1) {
+    // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
+    // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
+    for (int W = 4; W >= 1; W >>= 1) {
         const size_t need = (size_t)W * SP * per_px + BAND_FIXED_LDS;
         if (need <= budget || (W == 1 && need <= 160 * 1024)) {
             *lds_bytes = need;
