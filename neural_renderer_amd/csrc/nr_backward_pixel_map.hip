@@ -244,6 +244,7 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 // atomic order are ~1e-16 relative and do not survive the final rounding in practice).
 constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per pass
+constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
 constexpr int SEG = 15;          // pixels of a sweep walked by one thread (odd: consecutive segments of a
                                  // sweep start 15 dwords apart, i.e. on different LDS banks)
 
@@ -342,8 +343,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int *total)
     return woff + inc - v;
 }
 
-template <bool RGB, bool ALPHA, bool EXACT>
-__global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
+// POW2: S is a power of two (x * 2. / S is then one exact float multiply; the generic instantiation carries a
+// double-precision division whose register footprint would otherwise cap the occupancy of the common case).
+template <bool RGB, bool ALPHA, bool EXACT, bool POW2>
+__global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void k_bpm_band(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, double *__restrict__ scratch, int F, int S,
@@ -366,9 +369,9 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
     BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * BAND_WIN);
     int *s_rec = (int *)carve(4 * BAND_WIN);
     int *s_pref = (int *)carve(4 * BAND_WIN);
-    float *s_fp = (float *)carve(4 * 6 * BAND_THREADS);  // [slot][px0 px1 px2 py0 py1 py2]
-    int *s_ffn = (int *)carve(4 * BAND_THREADS);
-    double *s_acc = (double *)carve(8 * 3 * BAND_THREADS);
+    int *s_recfn = (int *)carve(4 * BAND_WIN);           // face index of each line record
+    double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);  // per-face sums of the faces that have lines in this band
+    int *s_slotfn = (int *)carve(4 * ACC_SLOTS);
     int *s_tmp = (int *)carve(4 * 16);
 
     // ---- 1. stage the band: LDS[(ld, d1)] = map[b][d0 = band_lo + ld][d1] (axis 1) or map[b][d1][d0] (axis 0)
@@ -449,12 +452,11 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
             }
         }
     }
-    s_acc[3 * tid] = 0.0; s_acc[3 * tid + 1] = 0.0; s_acc[3 * tid + 2] = 0.0;
+    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
     __syncthreads();
 
     const float fs = (float)S;
     const double s_d = (double)S, two_over_s = 2.0 / (double)S;
-    const bool s_pow2 = (S & (S - 1)) == 0;
     const int n_vis = vis_count[b];
 
     for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
@@ -468,9 +470,6 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
 #pragma unroll
             for (int k = 0; k < 3; k++) { px[k] = to_pixel(f[3 * k], fs); py[k] = to_pixel(f[3 * k + 1], fs); }
 #pragma unroll
-            for (int k = 0; k < 3; k++) { s_fp[6 * tid + k] = px[k]; s_fp[6 * tid + 3 + k] = py[k]; }
-            s_ffn[tid] = fn;
-#pragma unroll
             for (int e = 0; e < 3; e++) {
                 const int i0 = e, i1 = (e + 1) % 3;
                 const float p0x = axis ? py[i0] : px[i0], p1x = axis ? py[i1] : px[i1];
@@ -481,8 +480,12 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
                 if (p0x != p1x && hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
             }
         }
-        int total_lines = 0;
-        const int line_off = block_excl_scan(nl, s_tmp, &total_lines);
+        // one scan for two prefixes: lines in the low 20 bits (<= 512 * 3 * W), faces-with-lines above
+        int total_packed = 0;
+        const int packed_off = block_excl_scan(nl | ((nl > 0) << 20), s_tmp, &total_packed);
+        const int line_off = packed_off & 0xfffff, slot = packed_off >> 20;
+        const int total_lines = total_packed & 0xfffff;
+        if (nl > 0 && slot < ACC_SLOTS) s_slotfn[slot] = fn;
 
         for (int win = 0; win < ((dbg & 4) ? 0 : total_lines); win += BAND_WIN) {
             // ---- compact records of the lines that fall into this window
@@ -491,7 +494,10 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
 #pragma unroll
                 for (int e = 0; e < 3; e++)
                     for (int j = 0; j < e_n[e]; j++, k++)
-                        if (k >= win && k < win + BAND_WIN) s_rec[k - win] = tid | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
+                        if (k >= win && k < win + BAND_WIN) {
+                            s_rec[k - win] = slot | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
+                            s_recfn[k - win] = fn;
+                        }
             }
             __syncthreads();
             const int n_win = min(total_lines - win, BAND_WIN);
@@ -501,7 +507,13 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
                 const int rec = s_rec[tid];
                 const int slot = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
                 const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
-                const float *fp = s_fp + 6 * slot;
+                // the face's vertices come from global memory again (24 B per line, L2 hits) instead of an LDS copy:
+                // the 12 KB that copy took are what lets a third workgroup fit on the CU
+                const int rfn = s_recfn[tid];
+                const float *fv = faces + ((size_t)b * F + rfn) * 9;
+                float fp[6];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { fp[k] = to_pixel(fv[3 * k], fs); fp[3 + k] = to_pixel(fv[3 * k + 1], fs); }
                 const int ox = axis ? 3 : 0, oy = axis ? 0 : 3;  // p[num][dim] = pp[num][(dim + axis) % 2] (:556)
                 const float p0x = fp[ox + i0], p0y = fp[oy + i0], p1x = fp[ox + i1], p1y = fp[oy + i1];
                 const float p2x = fp[ox + i2], p2y = fp[oy + i2];
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
                 BandLine r;
                 r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = slot | (i0 << 16) | (i1 << 18);
                 r.cross = r.c0 = r.c1 = 0.0f;
-                r.fn = s_ffn[slot];
+                r.fn = rfn;
                 const float d1_cross = (p1y - p0y) / (p1x - p0x) * (d0f - p0x) + p0y;                  // :573
                 const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);     // :574
                 const int d1_out = d1_in + direction;                                                 // :575
@@ -620,13 +632,13 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
                     const float t = (float)d1 - cross;
                     if (has0) {  // :648-652 (x * 2. / S: an exact scaling when S is a power of two)
                         const float ct = c0 * t;
-                        float dist = s_pow2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
+                        float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
                         dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
                         if (EXACT) d0acc -= (double)(diff / dist); else f0 -= diff * __builtin_amdgcn_rcpf(dist);
                     }
                     if (has1) {  // :653-657
                         const float ct = c1 * t;
-                        float dist = s_pow2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
+                        float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
                         dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
                         if (EXACT) d1acc -= (double)(diff / dist); else f1 -= diff * __builtin_amdgcn_rcpf(dist);
                     }
@@ -642,21 +654,27 @@ __global__ __launch_bounds__(BAND_THREADS) void k_bpm_band(
                 }
                 if (d1 <= s_to) visit(pa, d1);
                 const double a0 = (double)f0 + d0acc, a1 = (double)f1 + d1acc;
-                const int slot = h.w & 0xffff;
-                if (a0 != 0.0) atomicAdd(&s_acc[3 * slot + ((h.w >> 16) & 3)], a0);
-                if (a1 != 0.0) atomicAdd(&s_acc[3 * slot + ((h.w >> 18) & 3)], a1);
+                const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
+                if (slot < ACC_SLOTS) {
+                    if (a0 != 0.0) atomicAdd(&s_acc[3 * slot + v0], a0);
+                    if (a1 != 0.0) atomicAdd(&s_acc[3 * slot + v1], a1);
+                } else {  // more faces with lines in this pass than LDS slots: straight to the global sums
+                    double *dst = scratch + ((size_t)b * F + fnr) * 6 + (1 - axis);
+                    if (a0 != 0.0) atomicAdd(dst + 2 * v0, a0);
+                    if (a1 != 0.0) atomicAdd(dst + 2 * v1, a1);
+                }
             }
             __syncthreads();
         }
 
         // ---- 5. per-face sums of this chunk -> global double scratch [face][vertex][x|y]
-        if (fn >= 0) {
-            double *dst = scratch + ((size_t)b * F + fn) * 6 + (1 - axis);
-#pragma unroll
-            for (int v = 0; v < 3; v++) {
-                const double a = s_acc[3 * tid + v];
-                if (a != 0.0) atomicAdd(dst + 2 * v, a);
-                s_acc[3 * tid + v] = 0.0;
+        {
+            const int n_slots = min(total_packed >> 20, ACC_SLOTS);
+            if (tid < 3 * n_slots) {
+                const int sl = tid / 3, v = tid - 3 * sl;
+                const double a = s_acc[tid];
+                if (a != 0.0) atomicAdd(scratch + ((size_t)b * F + s_slotfn[sl]) * 6 + 2 * v + (1 - axis), a);
+                s_acc[tid] = 0.0;
             }
         }
         __syncthreads();
@@ -700,15 +718,15 @@ BpmLayout bpm_layout(int B, int F)
     return L;
 }
 
-constexpr size_t BAND_FIXED_LDS = sizeof(BandLine) * BAND_WIN + 8 * BAND_WIN + 4 * 6 * BAND_THREADS + 4 * BAND_THREADS +
-                                  8 * 3 * BAND_THREADS + 64 + 8 * 16;
+constexpr size_t BAND_FIXED_LDS = sizeof(BandLine) * BAND_WIN + 12 * BAND_WIN + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 +
+                                  8 * 16;
 
 // band width (lines per workgroup) for the given raster size and modes; 0 = does not fit (global fallback)
 int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes)
 {
     const size_t per_px = 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0);
     const char *env = getenv("NR_K6_LDS_KB");  // tuning knob: LDS budget per workgroup (default: two per CU)
-    const size_t budget = (env ? (size_t)atoi(env) : 80) * 1024;
+    const size_t budget = env ? (size_t)atoi(env) * 1024 : 53 * 1024 + 512;  // three workgroups per 160 KB CU
     const size_t SP = (size_t)S + 4;
     // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
     // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
@@ -722,12 +740,12 @@ int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes)
     return 0;
 }
 
-template <bool RGB, bool ALPHA, bool EXACT>
+template <bool RGB, bool ALPHA, bool EXACT, bool POW2>
 int launch_band(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, double *scratch, int B, int F, int S,
                 int W, size_t lds, double eps, hipStream_t st)
 {
-    auto kern = k_bpm_band<RGB, ALPHA, EXACT>;
+    auto kern = k_bpm_band<RGB, ALPHA, EXACT, POW2>;
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -807,9 +825,12 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const char *fa = getenv("NR_K6_FAST");  // 1: hardware reciprocal + per-segment float sums (-7 % time)
     const bool exact = !(fa && atoi(fa));
     int rc;
+    const bool pow2 = (S & (S - 1)) == 0;
 #define NR_BAND(R, A, E)                                                                                          \
-    launch_band<R, A, E>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list,     \
-                         vis_count, scratch, B, F, S, W, lds, eps, st)
+    (pow2 ? launch_band<R, A, E, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,   \
+                                       vis_list, vis_count, scratch, B, F, S, W, lds, eps, st)                     \
+          : launch_band<R, A, E, false>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,  \
+                                        vis_list, vis_count, scratch, B, F, S, W, lds, eps, st))
     if (rgb && alpha) rc = exact ? NR_BAND(true, true, true) : NR_BAND(true, true, false);
     else if (rgb) rc = exact ? NR_BAND(true, false, true) : NR_BAND(true, false, false);
     else rc = exact ? NR_BAND(false, true, true) : NR_BAND(false, true, false);
