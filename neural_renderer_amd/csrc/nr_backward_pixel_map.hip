@@ -643,16 +643,13 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
                         if (EXACT) d1acc -= (double)(diff / dist); else f1 -= diff * __builtin_amdgcn_rcpf(dist);
                     }
                 };
-                // two pixels per iteration with ping-pong registers (no register-to-register copies)
-                Px pa = fetch(s_from), pb;
-                int d1 = s_from;
-                for (; d1 + 1 <= s_to; d1 += 2) {
-                    pb = fetch(d1 + 1);
-                    visit(pa, d1);
-                    if (d1 + 2 <= s_to) pa = fetch(d1 + 2);
-                    visit(pb, d1 + 1);
+                Px cur = fetch(s_from);
+                for (int d1 = s_from; d1 <= s_to; ++d1) {
+                    Px nxt = cur;
+                    if (d1 < s_to) nxt = fetch(d1 + 1);
+                    visit(cur, d1);
+                    cur = nxt;
                 }
-                if (d1 <= s_to) visit(pa, d1);
                 const double a0 = (double)f0 + d0acc, a1 = (double)f1 + d1acc;
                 const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
                 if (slot < ACC_SLOTS) {
