@@ -15,6 +15,7 @@
  *   nr_backward_depth_map        <- Rasterize.backward_depth_map_gpu        rasterize.py:794-847 (K8)
  *   nr_forward_rasterize         <- Rasterize.forward_gpu  (K1+K2 -> K4+K5 fused) rasterize.py:467-513
  *   nr_backward_rasterize        <- Rasterize.backward_gpu (K6 -> K7 -> K8 fused)  rasterize.py:849-889
+ *   nr_vertices_to_faces[_backward] <- vertices_to_faces + its get_item backward    vertices_to_faces.py:4-21
  *
  * Conventions
  *   - plain device pointers (hipMalloc / torch caching allocator memory), C-contiguous, float32 / int32;
@@ -151,6 +152,18 @@ int nr_backward_rasterize(const float *faces, const int32_t *face_index_map, con
                           float *grad_faces, float *grad_textures, int32_t batch_size, int32_t num_faces,
                           int32_t image_size, int32_t texture_size, double eps, int32_t flags, void *workspace,
                           size_t workspace_bytes, void *stream);
+
+/*
+ * vertices_to_faces (reference neural_renderer/vertices_to_faces.py:4-21): faces_out[b,f,k,:] = vertices[b, faces_idx[.,f,k], :]
+ * and its backward (Chainer's get_item backward = scatter-add): grad_vertices[b, faces_idx[.,f,k], :] += grad_faces[b,f,k,:]
+ * with hardware float atomics; grad_vertices [B,Nv,3] is zero-filled by the call.  faces_idx is [B,Nf,3] int32 when
+ * idx_per_batch != 0, else one [Nf,3] topology shared by the batch.  Indices must lie in [0, Nv).
+ */
+int nr_vertices_to_faces(const float *vertices, const int32_t *faces_idx, float *faces_out, int32_t batch_size,
+                         int32_t num_vertices, int32_t num_faces, int32_t idx_per_batch, void *stream);
+int nr_vertices_to_faces_backward(const float *grad_faces, const int32_t *faces_idx, float *grad_vertices,
+                                  int32_t batch_size, int32_t num_vertices, int32_t num_faces, int32_t idx_per_batch,
+                                  void *stream);
 
 #ifdef __cplusplus
 }

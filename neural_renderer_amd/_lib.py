@@ -23,6 +23,8 @@ SIGNATURES = {
                                         _vp]),
     'nr_backward_depth_map': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'nr_forward_rasterize': (_c.c_int, [_vp] * 8 + [_i32] * 5 + [_f64] * 3 + [_i32, _vp, _sz, _vp]),
+    'nr_vertices_to_faces': (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'nr_vertices_to_faces_backward': (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'nr_backward_rasterize': (_c.c_int, [_vp] * 11 + [_i32] * 4 + [_f64, _i32, _vp, _sz, _vp]),
 }
 

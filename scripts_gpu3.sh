@@ -1,2 +1,1 @@
-python scripts/k6_modes.py 2>&1 | tail -1
-TAG=now ITERS=10 python scripts/stage_times.py 2>&1 | tail -1 | cut -c75-115
+timeout 900 python -m pytest tests -m gpu -q -k vertices_to_faces 2>&1 | grep -E "Error|error|assert|^E" | head -12

@@ -400,3 +400,26 @@ def test_fused_forward_equals_stage_calls():
     b = abi.forward_fused(faces, textures, 100, 0.1, 100.0, 1e-3, bg, 1, True, True, True)
     for k in ('face_index_map', 'weight_map', 'depth_map', 'rgb_map', 'alpha_map'):
         np.testing.assert_array_equal(abi.host(a[k]), abi.host(b[k]), err_msg=k)
+
+
+def test_vertices_to_faces_gather_and_atomic_scatter():
+    """nr_vertices_to_faces / _backward (reference vertices_to_faces.py:4-21 + Chainer get_item backward) through the
+    torch-facing function: the gather is exact, the scatter-add matches np.add.at up to float summation order."""
+    import neural_renderer_amd as nr
+    rng = np.random.default_rng(51)
+    v, f = H.teapot()
+    f2 = np.concatenate((f, f[:, ::-1]), axis=0)
+    B = 3
+    vb = rng.normal(size=(B,) + v.shape).astype(np.float32)
+    fb = np.repeat(f2[None], B, axis=0)
+    vt = torch.tensor(vb, device='cuda', requires_grad=True)
+    out = nr.vertices_to_faces(vt, torch.tensor(fb, device='cuda'))
+    ref = O.vertices_to_faces(vb, fb)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    g = rng.normal(size=ref.shape).astype(np.float32)
+    out.backward(torch.tensor(g, device='cuda'))
+    gref = np.zeros_like(vb, dtype=np.float64)
+    for b in range(B):
+        np.add.at(gref[b], fb[b].reshape(-1), g[b].reshape(-1, 3).astype(np.float64))
+    # ~12 float atomics per vertex in arbitrary order (as in the reference's scatter_add): float-sum noise only
+    assert H.rel_err(vt.grad.cpu().numpy(), gref) <= RTOL
