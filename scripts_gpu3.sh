@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests -m gpu -q -k vertices_to_faces 2>&1 | grep -E "Error|error|assert|^E" | head -12
+python scripts/glue_profile.py 2>&1 | grep -v "^-" | cut -c1-72,100-175 | grep -A13 "=====" | head -40
