@@ -423,3 +423,46 @@ def test_vertices_to_faces_gather_and_atomic_scatter():
         np.add.at(gref[b], fb[b].reshape(-1), g[b].reshape(-1, 3).astype(np.float64))
     # ~12 float atomics per vertex in arbitrary order (as in the reference's scatter_add): float-sum noise only
     assert H.rel_err(vt.grad.cpu().numpy(), gref) <= RTOL
+
+
+@pytest.mark.parametrize('aa', [False, True], ids=['no_aa', 'aa'])
+def test_public_api_rasterize_rgbad_matches_oracle(aa):
+    """The torch-facing `rasterize_rgbad` (2x super-sampling + average pooling, vertical flip, NHWC -> NCHW;
+    reference rasterize.py:900-977) against the oracle's restatement, images and gradients."""
+    import neural_renderer_amd as nr
+    faces, _ = H.teapot_views(2, 64)
+    rng = np.random.default_rng(61)
+    textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    ft = torch.tensor(faces, device='cuda', requires_grad=True)
+    tt = torch.tensor(textures, device='cuda', requires_grad=True)
+    out = nr.rasterize_rgbad(ft, tt, 64, aa, 0.1, 100, 1e-3, (0.3, 0.2, 0.1), True, True, True)
+    ref = O.rasterize_rgbad(faces, textures, 64, aa, 0.1, 100, 1e-3, (0.3, 0.2, 0.1), True, True, True,
+                            return_function=True)
+    for k in ('rgb', 'alpha', 'depth'):
+        assert out[k].shape == ref[k].shape
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), ref[k], rtol=1e-6, atol=1e-6, err_msg=k)
+    g = {k: rng.normal(size=ref[k].shape).astype(np.float32) for k in ('rgb', 'alpha', 'depth')}
+    torch.autograd.backward([out['rgb'], out['alpha'], out['depth']],
+                            [torch.tensor(g[k], device='cuda') for k in ('rgb', 'alpha', 'depth')])
+    gf, gt = O.rgbad_backward(ref['function'], aa, g['rgb'], g['alpha'], g['depth'])
+    assert H.rel_err(ft.grad.cpu().numpy(), gf) <= RTOL
+    assert H.rel_err(tt.grad.cpu().numpy(), gt) <= RTOL
+
+
+def test_none_gradients_and_unused_outputs():
+    """A loss that uses only some outputs: the others receive `None` gradients, which the reference replaces by
+    zeros (rasterize.py:858-878)."""
+    import neural_renderer_amd as nr
+    faces, _ = H.teapot_views(2, 64)
+    rng = np.random.default_rng(62)
+    textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    ft = torch.tensor(faces, device='cuda', requires_grad=True)
+    tt = torch.tensor(textures, device='cuda', requires_grad=True)
+    rgb, alpha, depth = nr.Rasterize(64, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)(ft, tt)
+    g_alpha = rng.normal(size=(2, 64, 64)).astype(np.float32)
+    alpha.backward(torch.tensor(g_alpha, device='cuda'))
+    ref = oracle_forward(faces, textures, 64, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
+    gf, gt = ref.backward(None, g_alpha, None)
+    assert H.rel_err(ft.grad.cpu().numpy(), gf) <= RTOL
+    assert tt.grad is None or float(tt.grad.abs().max()) == 0.0
+    assert np.all(gt == 0)
