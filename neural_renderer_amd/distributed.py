@@ -29,6 +29,11 @@ def init_from_env(backend=None):
     """Initialise torch.distributed from the torchrun environment. Returns (rank, world, device)."""
     rank, world, local_rank = env_rank_world()
     use_cuda = torch.cuda.is_available()
+    # test hooks: NR_DIST_DEVICE pins every rank to one device and NR_DIST_BACKEND picks the backend, so that the
+    # multi-process control flow can be exercised on a single-GPU box (RCCL refuses two ranks on one device)
+    if 'NR_DIST_DEVICE' in os.environ:
+        local_rank = int(os.environ['NR_DIST_DEVICE'])
+    backend = backend or os.environ.get('NR_DIST_BACKEND')
     device = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
     if use_cuda:
         torch.cuda.set_device(device)
@@ -36,7 +41,7 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         kwargs = {}
-        if use_cuda:
+        if use_cuda and (backend or 'nccl') == 'nccl':
             kwargs['device_id'] = device
         dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), rank=rank, world_size=world, **kwargs)
     return rank, world, device
