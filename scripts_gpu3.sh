@@ -1,2 +1,3 @@
-NR_DIST_DEVICE=0 NR_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --cpu-sample-views 0 2>&1 | tail -3 | cut -c1-400
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-sample-views 0 2>&1 | tail -1 | cut -c1-200
+timeout 900 python -m pytest tests -m gpu -q -k "backward or fused or determinism or headline or known or public" 2>&1 | tail -3
+python scripts/k6_modes.py 2>&1 | tail -1
+for d in 0 1 4; do NR_K6_DEBUG=$d TAG=k6dbg$d ITERS=10 python scripts/stage_times.py 2>&1 | tail -1 | cut -c75-115; done
