@@ -42,7 +42,7 @@ template <bool RGB, bool ALPHA>
 __global__ __launch_bounds__(WAVE) void k_bpm_global(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
-    float *__restrict__ grad_faces, int F, int S, double eps, int axis_mask)
+    float *__restrict__ grad_faces, int F, int S, double eps)
 {
     __shared__ LineRec recs[NGRP][GRP];
 
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
     const int d0_to = (int)fmin((double)fmaxf(p0x, p1x), S - 1.0);           // :569
     int n_lines = 0;
     // p0x == p1x: the only possible d0 equals both, so both contributions are skipped (:648, :653)
-    if (lane_on && p0x != p1x && d0_to >= d0_from && ((axis_mask >> axis) & 1)) n_lines = d0_to - d0_from + 1;
+    if (lane_on && p0x != p1x && d0_to >= d0_from) n_lines = d0_to - d0_from + 1;
     const float slope = (p1y - p0y) / (p1x - p0x);  // :573, invariant along the edge
     // strides of d0 / d1 in the row-major maps (:587-593)
     const int sd0 = axis ? S : 1, sd1 = axis ? 1 : S;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, double *__restrict__ scratch, int F, int S,
-    int W, int SP, double eps, int dbg)
+    int W, int SP, double eps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
         const int total_lines = total_packed & 0xfffff;
         if (nl > 0 && slot < ACC_SLOTS) s_slotfn[slot] = fn;
 
-        for (int win = 0; win < ((dbg & 4) ? 0 : total_lines); win += BAND_WIN) {
+        for (int win = 0; win < total_lines; win += BAND_WIN) {
             // ---- compact records of the lines that fall into this window
             if (nl > 0 && line_off < win + BAND_WIN && line_off + nl > win) {
                 int k = line_off;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
             const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
             if (tid < n_win) s_pref[tid] = seg_off;
             __syncthreads();
-            for (int sid = tid; sid < ((dbg & 1) ? 0 : total_seg); sid += BAND_THREADS) {
+            for (int sid = tid; sid < total_seg; sid += BAND_THREADS) {
                 // last line l with s_pref[l] <= sid
                 int lo = 0, hi = n_win - 1;
                 while (lo < hi) {
@@ -749,7 +749,7 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
     }
     const dim3 grid((unsigned)((S + W - 1) / W), 2, (unsigned)B);
     hipLaunchKernelGGL(kern, grid, dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha, vis_list,
-                       vis_count, scratch, F, S, W, S + 4, eps, getenv("NR_K6_DEBUG") ? atoi(getenv("NR_K6_DEBUG")) : 0);
+                       vis_count, scratch, F, S, W, S + 4, eps);
     return 0;
 }
 
@@ -784,18 +784,16 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const char *force = getenv("NR_K6_GLOBAL");  // experiment knob: force the global-memory kernel
     {
         if (W == 0 || (force && atoi(force))) {
-            const char *am = getenv("NR_K6_AXIS_MASK");
-            const int axis_mask = am ? atoi(am) : 3;
             const dim3 grid((unsigned)n), block(WAVE);
             if (rgb && alpha)
                 hipLaunchKernelGGL((k_bpm_global<true, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
             else if (rgb)
                 hipLaunchKernelGGL((k_bpm_global<true, false>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
             else
                 hipLaunchKernelGGL((k_bpm_global<false, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps, axis_mask);
+                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
             return launch_status();
         }
     }
