@@ -184,6 +184,22 @@ def test_teapot_views_backward(modes):
     check_backward(faces, textures, 128, 1e-3, modes, seed=6)
 
 
+def test_baseline_config1_teapot_64_silhouette():
+    """BASELINE.json configs[0]: teapot, 1 view, 64x64 silhouette (the case tests/test_numpy_naive.py runs through the
+    naive NumPy per-pixel loop on the CPU)."""
+    faces, _ = H.teapot_views(1, 64)
+    check_backward(faces, None, 64, 1e-4, (False, True, False), seed=21)
+
+
+def test_baseline_config2_teapot_16_views_full_size():
+    """BASELINE.json configs[1] at full size: 16 azimuth views, 256x256, RGB + depth + silhouette, fwd + bwd, every
+    element against the oracle."""
+    faces, _ = H.teapot_views(16, 256)
+    rng = np.random.default_rng(22)
+    textures = rng.uniform(0, 1, (16, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    check_backward(faces, textures, 256, 1e-3, (True, True, True), seed=23)
+
+
 def test_backward_with_reference_style_residual_maps():
     """K7 fed by sampling maps and K8 fed by face_inv_map (the reference's residuals) instead of recomputation."""
     faces, _ = H.teapot_views(2, 64)
