@@ -16,6 +16,9 @@
  *   nr_forward_rasterize         <- Rasterize.forward_gpu  (K1+K2 -> K4+K5 fused) rasterize.py:467-513
  *   nr_backward_rasterize        <- Rasterize.backward_gpu (K6 -> K7 -> K8 fused)  rasterize.py:849-889
  *   nr_vertices_to_faces[_backward] <- vertices_to_faces + its get_item backward    vertices_to_faces.py:4-21
+ *   nr_image_epilogue[_backward]  <- transpose + flip + average_pooling_2d of rasterize_rgbad   rasterize.py:953-969
+ *   nr_frontend_forward/_backward <- fill_back + lighting + look_at/look + perspective + vertices_to_faces
+ *                                    of Renderer.render*                                  renderer.py:35-107
  *
  * Conventions
  *   - plain device pointers (hipMalloc / torch caching allocator memory), C-contiguous, float32 / int32;
@@ -45,7 +48,7 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 100 /* 0.1.0 */
+#define NR_VERSION 110 /* 0.1.1 */
 
 /* argument errors */
 #define NR_E_NULL (-1)      /* a required pointer is NULL */
@@ -164,6 +167,71 @@ int nr_vertices_to_faces(const float *vertices, const int32_t *faces_idx, float 
 int nr_vertices_to_faces_backward(const float *grad_faces, const int32_t *faces_idx, float *grad_vertices,
                                   int32_t batch_size, int32_t num_vertices, int32_t num_faces, int32_t idx_per_batch,
                                   void *stream);
+
+/*
+ * Image epilogue of rasterize_rgbad (reference rasterize.py:953-969), one bandwidth-bound kernel per direction:
+ * rgb [B,S,S,3] -> [B,3,is,is] (NHWC -> NCHW), alpha / depth [B,S,S] -> [B,is,is], every output flipped vertically
+ * (row 0 of the maps is the bottom row, row 0 of the images the top row) and, when anti_aliasing != 0, averaged over
+ * 2x2 blocks (is = S/2, S even; else is = S).  Each map / image pair is optional (both NULL = not requested).
+ * The backward writes every element of the requested map gradients.
+ */
+int nr_image_epilogue(const float *rgb_map, const float *alpha_map, const float *depth_map, float *rgb_out,
+                      float *alpha_out, float *depth_out, int32_t batch_size, int32_t image_size, int32_t anti_aliasing,
+                      void *stream);
+int nr_image_epilogue_backward(const float *grad_rgb_out, const float *grad_alpha_out, const float *grad_depth_out,
+                               float *grad_rgb_map, float *grad_alpha_map, float *grad_depth_map, int32_t batch_size,
+                               int32_t image_size, int32_t anti_aliasing, void *stream);
+
+/*
+ * Fused geometry + lighting front-end of Renderer.render / render_silhouettes / render_depth
+ * (reference renderer.py:35-107): fill_back (:37-38, :77-79), lighting (lighting.py:8-51), look_at (look_at.py:7-46) or
+ * look (look.py:7-45), perspective (perspective.py:5-19) and vertices_to_faces (vertices_to_faces.py:4-21) in one kernel,
+ * and their whole backward (including the light -> normal -> vertex path, the face -> vertex scatter and the gradient of
+ * the camera position) in one kernel plus a per-image camera kernel.
+ *
+ *   vertices [B,Nv,3] world space; faces_idx int32 [B,Nf,3] (idx_per_batch != 0) or [Nf,3]; textures [B,Nf,ts,ts,ts,3] or
+ *   NULL (silhouette / depth rendering: no lighting); eye: DEVICE pointer, [B,3] (eye_per_batch != 0) or [3];
+ *   faces_out [B,F,3,3] with F = Nf * (fill_back ? 2 : 1): face f and, at Nf + f, its copy with reversed vertex order;
+ *   textures_out [B,F,ts,ts,ts,3]: textures * light and, at Nf + f, the (i,j,k) -> (k,j,i) transposed textures * the
+ *   light of the reversed face.  nr_camera / nr_light live in HOST memory and are read during the call.
+ */
+#define NR_CAMERA_LOOK_AT 1 /* rotation from eye -> target, target = `at` (look_at.py) */
+#define NR_CAMERA_LOOK 2    /* rotation from a fixed viewing direction, target = `direction` (look.py) */
+
+typedef struct nr_camera {
+    int32_t mode;        /* NR_CAMERA_LOOK_AT or NR_CAMERA_LOOK */
+    int32_t perspective; /* != 0: x/z/width, y/z/width (perspective.py:15-17) */
+    float target[3];     /* `at` or `direction` */
+    float up[3];
+    float width;         /* tan(viewing_angle / 180 * 3.1416), computed by the host in float32 (perspective.py:10-13) */
+} nr_camera;
+
+typedef struct nr_light { /* lighting.py:9-13 */
+    float intensity_ambient, intensity_directional;
+    float color_ambient[3], color_directional[3], direction[3];
+} nr_light;
+
+/* Scratch for nr_frontend_backward when grad_eye is requested (per-image camera sums). */
+size_t nr_frontend_workspace_bytes(int32_t batch_size);
+
+int nr_frontend_forward(const float *vertices, const int32_t *faces_idx, const float *textures, const float *eye,
+                        float *faces_out, float *textures_out, int32_t batch_size, int32_t num_vertices,
+                        int32_t num_faces, int32_t texture_size, int32_t idx_per_batch, int32_t eye_per_batch,
+                        int32_t fill_back, const nr_camera *camera, const nr_light *light, void *stream);
+
+/*
+ * grad_faces [B,F,3,3] and grad_textures_out [B,F,ts,ts,ts,3] (NULL = the lit textures received no gradient) are the
+ * gradients of the two outputs.  Each result is optional (NULL = not needed): grad_vertices [B,Nv,3] (zero-filled by the
+ * call, accumulated with hardware float atomics), grad_textures [B,Nf,ts,ts,ts,3] (every element stored; needs
+ * grad_textures_out), grad_eye [B,3] or [3] (needs grad_vertices and the workspace).  `at`, `up`, `direction`, the
+ * viewing angle and the light parameters are constants of the call (no gradients), as in Renderer.
+ */
+int nr_frontend_backward(const float *vertices, const int32_t *faces_idx, const float *textures, const float *eye,
+                         const float *grad_faces, const float *grad_textures_out, float *grad_vertices,
+                         float *grad_textures, float *grad_eye, int32_t batch_size, int32_t num_vertices,
+                         int32_t num_faces, int32_t texture_size, int32_t idx_per_batch, int32_t eye_per_batch,
+                         int32_t fill_back, const nr_camera *camera, const nr_light *light, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

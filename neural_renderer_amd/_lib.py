@@ -8,6 +8,22 @@ from . import _build
 _c = ctypes
 _vp, _i32, _f64, _sz = _c.c_void_p, _c.c_int32, _c.c_double, _c.c_size_t
 
+
+
+class Camera(_c.Structure):
+    """struct nr_camera (include/nr_hip.h)."""
+    _fields_ = [('mode', _i32), ('perspective', _i32), ('target', _c.c_float * 3), ('up', _c.c_float * 3),
+                ('width', _c.c_float)]
+
+
+class Light(_c.Structure):
+    """struct nr_light (include/nr_hip.h)."""
+    _fields_ = [('intensity_ambient', _c.c_float), ('intensity_directional', _c.c_float),
+                ('color_ambient', _c.c_float * 3), ('color_directional', _c.c_float * 3), ('direction', _c.c_float * 3)]
+
+
+_cam_p, _light_p = _c.POINTER(Camera), _c.POINTER(Light)
+
 # name -> (restype, argtypes); mirrors include/nr_hip.h one to one
 SIGNATURES = {
     'nr_version': (_c.c_int, []),
@@ -26,9 +42,16 @@ SIGNATURES = {
     'nr_vertices_to_faces': (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'nr_vertices_to_faces_backward': (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'nr_backward_rasterize': (_c.c_int, [_vp] * 11 + [_i32] * 4 + [_f64, _i32, _vp, _sz, _vp]),
+    'nr_image_epilogue': (_c.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
+    'nr_image_epilogue_backward': (_c.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
+    'nr_frontend_workspace_bytes': (_sz, [_i32]),
+    'nr_frontend_forward': (_c.c_int, [_vp] * 6 + [_i32] * 7 + [_cam_p, _light_p, _vp]),
+    'nr_frontend_backward': (_c.c_int, [_vp] * 9 + [_i32] * 7 + [_cam_p, _light_p, _vp, _sz, _vp]),
 }
 
 NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
+NR_CAMERA_LOOK_AT = 1
+NR_CAMERA_LOOK = 2
 
 _lib = None
 

@@ -14,7 +14,6 @@ import os
 
 import numpy as np
 import torch
-import torch.nn.functional as F_
 
 from . import _lib
 
@@ -119,6 +118,7 @@ class _RasterizeFunction(torch.autograd.Function):
                 ws_bytes, stream), 'nr_forward_rasterize')
 
         ctx.cfg = dict(cfg, B=B, F=F, S=S, ts=ts, flags=flags)
+        ctx.set_materialize_grads(False)  # an unused output arrives as `None` in backward and its terms are skipped
         # residuals (the reference keeps them on `self`, rasterize.py:39-58); outputs among them go through
         # save_for_backward so that in-place edits by the caller are detected
         ctx.save_for_backward(faces_c, face_index_map, weight_map, depth_map, rgb_map, alpha_map)
@@ -139,6 +139,8 @@ class _RasterizeFunction(torch.autograd.Function):
         use_rgb = cfg['return_rgb'] and g_rgb is not None
         use_alpha = cfg['return_alpha'] and g_alpha is not None
         use_depth = cfg['return_depth'] and g_depth is not None
+        if not (use_rgb or use_alpha or use_depth):
+            return None, None, None
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             if use_rgb:
@@ -162,6 +164,51 @@ class _RasterizeFunction(torch.autograd.Function):
                 B, F, S, ts, float(cfg['eps']), cfg['flags'], workspace.data_ptr(), ws_bytes, stream),
                 'nr_backward_rasterize')
         return grad_faces, grad_textures, None
+
+
+class _ImageEpilogue(torch.autograd.Function):
+    """rgb_map [B,S,S,3] -> [B,3,is,is], alpha / depth maps [B,S,S] -> [B,is,is]: NHWC -> NCHW, vertical flip and (with
+    anti-aliasing) the 2x2 mean of rasterize.py:953-969, forward and backward each as one kernel (csrc/nr_image.hip)."""
+
+    @staticmethod
+    def forward(ctx, rgb_map, alpha_map, depth_map, anti_aliasing):
+        lib = _lib.load()
+        maps = [m.detach().contiguous() if m is not None else None for m in (rgb_map, alpha_map, depth_map)]
+        ref = next(m for m in maps if m is not None)
+        dev = ref.device
+        B, S = ref.shape[0], ref.shape[1]
+        if anti_aliasing and S % 2:
+            raise ValueError('anti-aliasing needs an even raster size, got %d' % S)
+        size = S // 2 if anti_aliasing else S
+        outs = [None if maps[0] is None else torch.empty((B, 3, size, size), dtype=torch.float32, device=dev),
+                None if maps[1] is None else torch.empty((B, size, size), dtype=torch.float32, device=dev),
+                None if maps[2] is None else torch.empty((B, size, size), dtype=torch.float32, device=dev)]
+        with torch.cuda.device(dev):
+            _lib.check(lib.nr_image_epilogue(_lib.ptr(maps[0]), _lib.ptr(maps[1]), _lib.ptr(maps[2]), _lib.ptr(outs[0]),
+                                             _lib.ptr(outs[1]), _lib.ptr(outs[2]), B, S, int(anti_aliasing),
+                                             _stream_ptr(dev)), 'nr_image_epilogue')
+        ctx.dims = (B, S, bool(anti_aliasing))
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth):
+        lib = _lib.load()
+        B, S, aa = ctx.dims
+        grads = [g.contiguous() if g is not None else None for g in (g_rgb, g_alpha, g_depth)]
+        ref = next((g for g in grads if g is not None), None)
+        if ref is None:
+            return None, None, None, None
+        dev = ref.device
+        # an output without gradient keeps `None`, so that the rasterizer's backward skips its terms altogether
+        outs = [None if grads[0] is None else torch.empty((B, S, S, 3), dtype=torch.float32, device=dev),
+                None if grads[1] is None else torch.empty((B, S, S), dtype=torch.float32, device=dev),
+                None if grads[2] is None else torch.empty((B, S, S), dtype=torch.float32, device=dev)]
+        with torch.cuda.device(dev):
+            _lib.check(lib.nr_image_epilogue_backward(_lib.ptr(grads[0]), _lib.ptr(grads[1]), _lib.ptr(grads[2]),
+                                                      _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), B, S,
+                                                      int(aa), _stream_ptr(dev)), 'nr_image_epilogue_backward')
+        return outs[0], outs[1], outs[2], None
 
 
 class Rasterize(object):
@@ -220,20 +267,8 @@ def rasterize_rgbad(
     size = image_size * 2 if anti_aliasing else image_size  # 2x super-sampling, :945-951
     rgb, alpha, depth = Rasterize(size, near, far, eps, background_color, return_rgb, return_alpha,
                                   return_depth)(*inputs)
-    # transpose & vertical flip, :953-960
-    if return_rgb:
-        rgb = torch.flip(rgb.permute(0, 3, 1, 2), dims=[2])
-    if return_alpha:
-        alpha = torch.flip(alpha, dims=[1])
-    if return_depth:
-        depth = torch.flip(depth, dims=[1])
-    if anti_aliasing:  # 0.5x down-sampling, :962-969
-        if return_rgb:
-            rgb = F_.avg_pool2d(rgb, 2, 2)
-        if return_alpha:
-            alpha = F_.avg_pool2d(alpha[:, None, :, :], 2, 2)[:, 0]
-        if return_depth:
-            depth = F_.avg_pool2d(depth[:, None, :, :], 2, 2)[:, 0]
+    # transpose & vertical flip (:953-960) and 0.5x down-sampling (:962-969): one HIP kernel per direction
+    rgb, alpha, depth = _ImageEpilogue.apply(rgb, alpha, depth, bool(anti_aliasing))
     return {
         'rgb': rgb if return_rgb else None,
         'alpha': alpha if return_alpha else None,

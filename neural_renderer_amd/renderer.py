@@ -1,8 +1,13 @@
-"""Renderer facade -- reference neural_renderer/renderer.py:8-107 (same attributes, defaults and methods)."""
+"""Renderer facade -- reference neural_renderer/renderer.py:8-107 (same attributes, defaults and methods).
+
+On CUDA tensors with the usual parameter types the chain in front of the rasterizer (fill_back, lighting, look_at / look,
+perspective, vertices_to_faces) runs as one fused HIP kernel per direction (frontend.py); any other input keeps the
+module-by-module path below, which mirrors the reference line by line."""
 import math
 
 import torch
 
+from . import frontend
 from .lighting import lighting
 from .look import look
 from .look_at import look_at
@@ -48,36 +53,41 @@ class Renderer(object):
             vertices = perspective(vertices, angle=self.viewing_angle)
         return vertices_to_faces(vertices, faces)
 
+    def _frontend_torch(self, vertices, faces, textures=None):
+        """Everything in front of the rasterizer, module by module as in the reference (renderer.py:37-51, :77-103)."""
+        if self.fill_back:  # renderer.py:37-38, :77-79
+            faces = torch.cat((faces, torch.flip(faces, dims=[2])), dim=1).detach()
+            if textures is not None:
+                textures = torch.cat((textures, textures.permute(0, 1, 4, 3, 2, 5)), dim=1)
+        if textures is not None:  # lighting in world space (renderer.py:82-90)
+            faces_lighting = vertices_to_faces(vertices, faces)
+            textures = lighting(
+                faces_lighting,
+                textures,
+                self.light_intensity_ambient,
+                self.light_intensity_directional,
+                self.light_color_ambient,
+                self.light_color_directional,
+                self.light_direction)
+        return self._project(vertices, faces), textures
+
+    def _frontend(self, vertices, faces, textures=None):
+        """-> (faces [B,F,3,3], lit textures | None): the fused HIP front-end when the call fits it, else torch."""
+        if frontend.fusable(self, vertices, faces, textures):
+            return frontend.project_and_light(self, vertices, faces, textures)
+        return self._frontend_torch(vertices, faces, textures)
+
     def render_silhouettes(self, vertices, faces):
-        if self.fill_back:
-            faces = torch.cat((faces, torch.flip(faces, dims=[2])), dim=1).detach()  # renderer.py:38
-        faces = self._project(vertices, faces)
+        faces, _ = self._frontend(vertices, faces)
         # NB: near / far / rasterizer_eps are NOT forwarded here (renderer.py:52, SURVEY quirk Q2)
         return rasterize_silhouettes(faces, self.image_size, self.anti_aliasing)
 
     def render_depth(self, vertices, faces):
-        if self.fill_back:
-            faces = torch.cat((faces, torch.flip(faces, dims=[2])), dim=1).detach()  # renderer.py:58
-        faces = self._project(vertices, faces)
+        faces, _ = self._frontend(vertices, faces)
         return rasterize_depth(faces, self.image_size, self.anti_aliasing)  # renderer.py:72 (Q2)
 
     def render(self, vertices, faces, textures):
-        if self.fill_back:  # renderer.py:77-79
-            faces = torch.cat((faces, torch.flip(faces, dims=[2])), dim=1).detach()
-            textures = torch.cat((textures, textures.permute(0, 1, 4, 3, 2, 5)), dim=1)
-
-        # lighting in world space (renderer.py:82-90)
-        faces_lighting = vertices_to_faces(vertices, faces)
-        textures = lighting(
-            faces_lighting,
-            textures,
-            self.light_intensity_ambient,
-            self.light_intensity_directional,
-            self.light_color_ambient,
-            self.light_color_directional,
-            self.light_direction)
-
-        faces = self._project(vertices, faces)
+        faces, textures = self._frontend(vertices, faces, textures)
         return rasterize(
             faces, textures, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
             self.background_color)

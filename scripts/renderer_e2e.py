@@ -20,7 +20,10 @@ def t(fn, n=10):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-for aa in (False, True):
+from neural_renderer_amd import frontend
+_fusable = frontend.fusable
+for fused, aa in ((True, False), (False, False), (True, True), (False, True)):
+    frontend.fusable = _fusable if fused else (lambda *a: False)   # False: module-by-module torch front-end
     r.anti_aliasing = aa
     def rgb():
         vertices.grad = None; textures.grad = None
@@ -28,4 +31,4 @@ for aa in (False, True):
     def sil():
         vertices.grad = None
         img = r.render_silhouettes(vertices, faces); img.square().sum().backward()
-    print(json.dumps({'anti_aliasing': aa, 'render_fwd_bwd_ms': round(t(rgb), 3), 'silhouettes_fwd_bwd_ms': round(t(sil), 3)}))
+    print(json.dumps({'fused_frontend': fused, 'anti_aliasing': aa, 'render_fwd_bwd_ms': round(t(rgb), 3), 'silhouettes_fwd_bwd_ms': round(t(sil), 3)}))

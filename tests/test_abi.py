@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_host_only_entry_points(lib_path):
     lib = _lib.load()
-    assert lib.nr_version() == 100
+    assert lib.nr_version() == 110
     assert lib.nr_error_string(0) == b'success'
     assert b'workspace' in lib.nr_error_string(-3)
     assert lib.nr_forward_workspace_bytes(64, 4928, 256) >= 64 * 4928 * (36 + 8)
