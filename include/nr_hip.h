@@ -17,6 +17,8 @@
  *   nr_backward_rasterize        <- Rasterize.backward_gpu (K6 -> K7 -> K8 fused)  rasterize.py:849-889
  *   nr_vertices_to_faces[_backward] <- vertices_to_faces + its get_item backward    vertices_to_faces.py:4-21
  *   nr_image_epilogue[_backward]  <- transpose + flip + average_pooling_2d of rasterize_rgbad   rasterize.py:953-969
+ *   nr_load_textures              <- load_textures kernel of load_obj(load_texture=True)      load_obj.py:87-144
+ *   nr_create_texture_image       <- create_texture_image kernels of save_obj(textures=...)   save_obj.py:32-146
  *   nr_frontend_forward/_backward <- fill_back + lighting + look_at/look + perspective + vertices_to_faces
  *                                    of Renderer.render*                                  renderer.py:35-107
  *
@@ -232,6 +234,25 @@ int nr_frontend_backward(const float *vertices, const int32_t *faces_idx, const 
                          int32_t num_faces, int32_t texture_size, int32_t idx_per_batch, int32_t eye_per_batch,
                          int32_t fill_back, const nr_camera *camera, const nr_light *light, void *workspace,
                          size_t workspace_bytes, void *stream);
+
+/*
+ * Texture baking of load_obj(load_texture=True) (K10, reference load_obj.py:87-144): for every texel (i0,i1,i2) of every
+ * face with is_update[f] != 0, textures[f,i0,i1,i2,:] = bilinear lookup of `image` at the barycentric point
+ * (i0,i1,i2)/(i0+i1+i2) of the face's uv triangle.  image [H,W,3] float32 in [0,1], ALREADY flipped vertically (:85);
+ * faces_uv [Nf,3,2]; textures [Nf,ts,ts,ts,3] in/out (other faces untouched).  Texel (0,0,0) of an updated face is NaN, as
+ * in the reference (0/0); reads outside the image are clamped to the nearest pixel (zero weight when the reference is defined).
+ */
+int nr_load_textures(const float *image, const float *faces_uv, const int32_t *is_update, float *textures,
+                     int32_t num_faces, int32_t texture_size, int32_t image_height, int32_t image_width, void *stream);
+
+/*
+ * Texture atlas of save_obj(..., textures) (K11, reference save_obj.py:10-146): image [tile_height*tso, tile_width*tso, 3]
+ * (NOT yet flipped) from textures [Nf,tsi,tsi,tsi,3] and the per-face tile triangles tile_vertices [Nf,3,2] in atlas pixel
+ * coordinates (save_obj.py:17-25); tiles beyond the last face are written as 0.  Includes the seam pass (:115-146).
+ */
+int nr_create_texture_image(const float *textures, const float *tile_vertices, float *image, int32_t num_faces,
+                            int32_t texture_size_in, int32_t texture_size_out, int32_t tile_width, int32_t tile_height,
+                            void *stream);
 
 #ifdef __cplusplus
 }

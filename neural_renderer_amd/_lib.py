@@ -44,6 +44,8 @@ SIGNATURES = {
     'nr_backward_rasterize': (_c.c_int, [_vp] * 11 + [_i32] * 4 + [_f64, _i32, _vp, _sz, _vp]),
     'nr_image_epilogue': (_c.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
     'nr_image_epilogue_backward': (_c.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
+    'nr_load_textures': (_c.c_int, [_vp] * 4 + [_i32] * 4 + [_vp]),
+    'nr_create_texture_image': (_c.c_int, [_vp] * 3 + [_i32] * 5 + [_vp]),
     'nr_frontend_workspace_bytes': (_sz, [_i32]),
     'nr_frontend_forward': (_c.c_int, [_vp] * 6 + [_i32] * 7 + [_cam_p, _light_p, _vp]),
     'nr_frontend_backward': (_c.c_int, [_vp] * 9 + [_i32] * 7 + [_cam_p, _light_p, _vp, _sz, _vp]),

@@ -266,25 +266,261 @@ def rasterize_depth(faces, image_size=DEFAULT_IMAGE_SIZE, anti_aliasing=DEFAULT_
 
 # ----------------------------------------------------------------------------------------------------
 # glue (float32 NumPy restatements of the Chainer graph around the rasterizer)
-def load_obj(filename_obj, normalization=True):
-    """neural_renderer/load_obj.py:147-197 (vertices + fan-triangulated faces; no textures)."""
-    vertices, faces = [], []
-    with open(filename_obj) as f:
+def _read_image(path):
+    """skimage.io.imread(path) as the reference uses it (load_obj.py:83): uint8 [H,W,3]."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'))
+
+
+def load_mtl(filename_mtl):
+    """load_obj.py:9-22: diffuse colour (Kd) and texture file (map_Kd) per material."""
+    texture_filenames, colors = {}, {}
+    material_name = ''
+    with open(filename_mtl) as f:
         for line in f:
             t = line.split()
             if not t:
                 continue
-            if t[0] == 'v':
-                vertices.append([float(v) for v in t[1:4]])
-            elif t[0] == 'f':
-                vs = [int(s.split('/')[0]) for s in t[1:]]
-                for i in range(len(vs) - 2):
-                    faces.append((vs[0], vs[i + 1], vs[i + 2]))
+            if t[0] == 'newmtl':
+                material_name = t[1]
+            if t[0] == 'map_Kd':
+                texture_filenames[material_name] = t[1]
+            if t[0] == 'Kd':
+                colors[material_name] = np.array([float(x) for x in t[1:4]])
+    return colors, texture_filenames
+
+
+def bake_texture_image(image, faces_uv, is_update, textures):
+    """K10, load_obj.py:87-144: for every texel (i0,i1,i2) of every face with is_update != 0, the barycentric point
+    dim/sum(dim) of the face's uv triangle is looked up in `image` ([H,W,3] float32, ALREADY flipped vertically, :85) with
+    bilinear filtering.  In place on textures [Nf,ts,ts,ts,3].  Reads that the reference performs outside the image
+    (uv exactly 1, negative uv: undefined behaviour there) are clamped to the nearest valid flat index -- they carry a zero
+    weight whenever the reference's result is defined."""
+    nf, ts = textures.shape[:2]
+    h, w = image.shape[:2]
+    img = np.ascontiguousarray(image, np.float32).reshape(-1, 3)
+    idx = np.arange(ts, dtype=np.int64)
+    grid = (idx.astype(np.float64) / (ts - 1.)).astype(np.float32)                     # :98-100 (int / double -> float)
+    d0, d1, d2 = np.meshgrid(grid, grid, grid, indexing='ij')
+    with np.errstate(all='ignore'):
+        total = (d0 + d1) + d2                                                         # :103
+        d0, d1, d2 = d0 / total, d1 / total, d2 / total                                # :104-106 (0/0 = NaN at texel 0,0,0)
+        for fn in np.nonzero(np.asarray(is_update) != 0)[0]:                           # :110
+            f = faces_uv[fn]
+            pos_x = ((f[0, 0] * d0 + f[1, 0] * d1) + f[2, 0] * d2) * np.float32(w - 1)  # :112-113
+            pos_y = ((f[0, 1] * d0 + f[1, 1] * d1) + f[2, 1] * d2) * np.float32(h - 1)  # :114-115
+            xi, yi = _f2i_arr(pos_x), _f2i_arr(pos_y)
+            yi1 = _f2i_arr(pos_y + np.float32(1))
+            wx1 = pos_x - xi.astype(np.float32)                                        # :118-121
+            wx0 = np.float32(1) - wx1
+            wy1 = pos_y - yi.astype(np.float32)
+            wy0 = np.float32(1) - wy1
+
+            def px(row, col):
+                return img[np.clip(row * w + col, 0, h * w - 1)]
+            c = np.zeros(pos_x.shape + (3,), np.float32)                               # :123-128
+            c = c + px(yi, xi) * (wx0 * wy0)[..., None]
+            c = c + px(yi1, xi) * (wx0 * wy1)[..., None]
+            c = c + px(yi, xi + 1) * (wx1 * wy0)[..., None]
+            c = c + px(yi1, xi + 1) * (wx1 * wy1)[..., None]
+            textures[fn] = c
+    return textures
+
+
+def _f2i_arr(x):
+    """CUDA (int)x on an array: truncate, saturate, NaN -> 0."""
+    x = np.asarray(x, np.float64)
+    return np.where(np.isnan(x), 0.0, np.clip(x, -2147483648.0, 2147483647.0)).astype(np.int64)
+
+
+def parse_obj_texture_faces(filename_obj):
+    """load_obj.py:26-62: uv coordinates per face corner and the material name in force at each face."""
+    uv = []
+    faces, material_names = [], []
+    material_name = ''
+    with open(filename_obj) as f:
+        lines = f.readlines()
+    for line in lines:
+        t = line.split()
+        if t and t[0] == 'vt':
+            uv.append([float(v) for v in t[1:3]])
+    uv = np.vstack(uv).astype('float32')
+    for line in lines:
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == 'f':
+            vs = t[1:]
+            ids = [int(v.split('/')[1]) if '/' in v else 0 for v in vs]                # :44-56
+            for i in range(len(vs) - 2):
+                faces.append((ids[0], ids[i + 1], ids[i + 2]))
+                material_names.append(material_name)
+        if t[0] == 'usemtl':
+            material_name = t[1]
+    faces = np.vstack(faces).astype('int32') - 1
+    faces_uv = uv[faces]                                                               # :62 (index -1 wraps like NumPy)
+    faces_uv[1 < faces_uv] = faces_uv[1 < faces_uv] % 1                                # :64
+    return faces_uv, material_names
+
+
+def load_textures(filename_obj, filename_mtl, texture_size):
+    """load_obj.py:25-144."""
+    faces_uv, material_names = parse_obj_texture_faces(filename_obj)
+    colors, texture_filenames = load_mtl(filename_mtl)
+    textures = np.zeros((faces_uv.shape[0], texture_size, texture_size, texture_size, 3), 'float32') + 0.5   # :69
+    names = np.array(material_names)
+    for material_name, color in colors.items():                                        # :73-77
+        textures[names == material_name] = color.astype(np.float32)[None, None, None, None, :]
+    for material_name, filename_texture in texture_filenames.items():                  # :80-143
+        path = os.path.join(os.path.dirname(filename_obj), filename_texture)
+        image = _read_image(path).astype('float32') / 255.                             # :83
+        image = image[::-1, ::1]                                                       # :85
+        bake_texture_image(image, faces_uv, (names == material_name).astype('int32'), textures)
+    return textures
+
+
+def load_obj(filename_obj, normalization=True, texture_size=4, load_texture=False):
+    """neural_renderer/load_obj.py:147-197 (vertices + fan-triangulated faces [+ baked textures])."""
+    vertices, faces = [], []
+    with open(filename_obj) as f:
+        lines = f.readlines()
+    for line in lines:
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == 'v':
+            vertices.append([float(v) for v in t[1:4]])
+        elif t[0] == 'f':
+            vs = [int(s.split('/')[0]) for s in t[1:]]
+            for i in range(len(vs) - 2):
+                faces.append((vs[0], vs[i + 1], vs[i + 2]))
     vertices = np.vstack(vertices).astype('float32')
     faces = np.vstack(faces).astype('int32') - 1
+    textures = None
+    if load_texture:                                                                   # :177-185
+        for line in lines:
+            if line.startswith('mtllib'):
+                filename_mtl = os.path.join(os.path.dirname(filename_obj), line.split()[1])
+                textures = load_textures(filename_obj, filename_mtl, texture_size)
+        if textures is None:
+            raise Exception('Failed to load textures.')
     if normalization:
         vertices = normalize_vertices(vertices)
+    if load_texture:
+        return vertices, faces, textures
     return vertices, faces
+
+
+def create_texture_image(textures, texture_size_out=16):
+    """save_obj.py:10-147 (K11): atlas image [tile_h*tso, tile_w*tso, 3] (flipped vertically, :143) and the per-face uv
+    triangles [Nf,3,2] normalised to [0,1] (:140-141).  Tiles beyond the last face stay 0."""
+    textures = _f32(textures)
+    num_faces, tsi = textures.shape[:2]
+    tso = texture_size_out
+    tile_width = int((num_faces - 1.) ** 0.5) + 1                                      # :12
+    tile_height = int((num_faces - 1.) / tile_width) + 1                               # :13
+    height, width = tile_height * tso, tile_width * tso
+    image = np.zeros((height, width, 3), 'float32')
+    vertices = np.zeros((num_faces, 3, 2), 'float32')                                  # :16-25
+    face_nums = np.arange(num_faces)
+    column = face_nums % tile_width
+    row = face_nums // tile_width
+    vertices[:, 0, 0] = column * tso
+    vertices[:, 0, 1] = row * tso
+    vertices[:, 1, 0] = column * tso
+    vertices[:, 1, 1] = (row + 1) * tso - 1
+    vertices[:, 2, 0] = (column + 1) * tso - 1
+    vertices[:, 2, 1] = (row + 1) * tso - 1
+
+    tex = textures.reshape(num_faces, tsi * tsi * tsi, 3)
+    ys, xs = np.meshgrid(np.arange(height), np.arange(width), indexing='ij')
+    fn = xs // tso + (ys // tso) * tile_width                                          # :39-41
+    valid = fn < num_faces
+    fnc = np.minimum(fn, num_faces - 1)
+    p0, p1, p2 = vertices[fnc, 0], vertices[fnc, 1], vertices[fnc, 2]
+    xf, yf = xs.astype(np.float32), ys.astype(np.float32)
+    with np.errstate(all='ignore'):
+        inv = [p1[..., 1] - p2[..., 1], p2[..., 0] - p1[..., 0], p1[..., 0] * p2[..., 1] - p2[..., 0] * p1[..., 1],   # :54-57
+               p2[..., 1] - p0[..., 1], p0[..., 0] - p2[..., 0], p2[..., 0] * p0[..., 1] - p0[..., 0] * p2[..., 1],
+               p0[..., 1] - p1[..., 1], p1[..., 0] - p0[..., 0], p0[..., 0] * p1[..., 1] - p1[..., 0] * p0[..., 1]]
+        den = (p2[..., 0] * (p0[..., 1] - p1[..., 1]) + p0[..., 0] * (p1[..., 1] - p2[..., 1])
+               + p1[..., 0] * (p2[..., 1] - p0[..., 1]))                                 # :58-61
+        inv = [m / den for m in inv]
+        weight = [inv[3 * k] * xf + inv[3 * k + 1] * yf + inv[3 * k + 2] for k in range(3)]   # :67
+        weight_sum = ((np.float32(0) + weight[0]) + weight[1]) + weight[2]
+        weight = [(w.astype(np.float64) / (weight_sum.astype(np.float64) + 1e-5)).astype(np.float32) for w in weight]  # :70
+        tif = []
+        for k in range(3):                                                             # :73-79
+            t = weight[k] * np.float32(tsi - 1)
+            t = np.fmax(t.astype(np.float64), 0.).astype(np.float32)
+            t = np.fmin(t.astype(np.float64), (tsi - 1) - 1e-5).astype(np.float32)
+            tif.append(t)
+        ti = [_f2i_arr(t) for t in tif]
+        frac = [t - i.astype(np.float32) for t, i in zip(tif, ti)]
+        pixel = np.zeros((height, width, 3), np.float32)
+        for pn in range(8):                                                            # :82-97
+            w = np.ones((height, width), np.float32)
+            idx = []
+            for k in range(3):
+                if (pn >> k) % 2 == 0:
+                    w = w * (np.float32(1) - frac[k])
+                    idx.append(ti[k])
+                else:
+                    w = w * frac[k]
+                    idx.append(ti[k] + 1)
+            isc = idx[0] * tsi * tsi + idx[1] * tsi + idx[2]
+            pixel = pixel + w[..., None] * tex[fnc, np.clip(isc, 0, tsi ** 3 - 1)]
+    image[valid] = pixel[valid]
+    seam = (ys % tso + 1) == (xs % tso)                                                # :129-132
+    src = image[ys, np.maximum(xs - 1, 0)]
+    image[seam] = src[seam]
+    vertices[:, :, 0] /= (image.shape[1] - 1)                                          # :140-141
+    vertices[:, :, 1] /= (image.shape[0] - 1)
+    return image[::-1, ::1], vertices
+
+
+def toimage_bytes(image, cmin=0.0, cmax=1.0):
+    """scipy.misc.toimage(image, cmin, cmax) byte scaling (save_obj.py:158): (x - cmin) * 255 / (cmax - cmin), clip, + 0.5."""
+    data = (np.asarray(image, np.float64) - cmin) * (255.0 / (cmax - cmin))
+    return (data.clip(0, 255) + 0.5).astype(np.uint8)
+
+
+def save_obj(filename, vertices, faces, textures=None):
+    """save_obj.py:150-191, byte for byte the reference's text format."""
+    from PIL import Image
+    assert vertices.ndim == 2
+    assert faces.ndim == 2
+    if textures is not None:
+        filename_mtl = filename[:-4] + '.mtl'
+        filename_texture = filename[:-4] + '.png'
+        material_name = 'material_1'
+        texture_image, vertices_textures = create_texture_image(textures)
+        Image.fromarray(toimage_bytes(texture_image)).save(filename_texture)
+    with open(filename, 'w') as f:
+        f.write('# %s\n' % os.path.basename(filename))
+        f.write('#\n')
+        f.write('\n')
+        if textures is not None:
+            f.write('mtllib %s\n\n' % os.path.basename(filename_mtl))
+        for vertex in vertices:
+            f.write('v %.8f %.8f %.8f\n' % (vertex[0], vertex[1], vertex[2]))
+        f.write('\n')
+        if textures is not None:
+            for vertex in vertices_textures.reshape((-1, 2)):
+                f.write('vt %.8f %.8f\n' % (vertex[0], vertex[1]))
+            f.write('\n')
+            f.write('usemtl %s\n' % material_name)
+            for i, face in enumerate(faces):
+                f.write('f %d/%d %d/%d %d/%d\n' % (
+                    face[0] + 1, 3 * i + 1, face[1] + 1, 3 * i + 2, face[2] + 1, 3 * i + 3))
+            f.write('\n')
+        else:
+            for face in faces:
+                f.write('f %d %d %d\n' % (face[0] + 1, face[1] + 1, face[2] + 1))
+    if textures is not None:
+        with open(filename_mtl, 'w') as f:
+            f.write('newmtl %s\n' % material_name)
+            f.write('map_Kd %s\n' % os.path.basename(filename_texture))
 
 
 def normalize_vertices(vertices):

@@ -23,6 +23,20 @@ ships, re-encoded losslessly into one .npz so that they t
   silhouettes_case{1,2} bool   [64,64]    tests/data/rasterize_silhouettes_case{1,2}.png (unused by the
                                          reference tests; images of the two backward-test triangles)
 
+and tests/golden/display_model.npz, the textured ShapeNet model of the reference's texture-loading test
+(tests/test_load_obj.py:51-59: tests/data/4e49873292196f02574b5684eaec43e9/model.obj + model.mtl + images/*.jpg -> display.png):
+
+  v            float32 [921,3]    `v` lines, before normalisation
+  vt           float32 [Nt,2]     `vt` lines
+  faces_v      int32   [3644,3]   vertex indices of the fan-triangulated faces (0-based)
+  faces_vt     int32   [3644,3]   `vt` indices of the same corners (0-based)
+  face_material int32  [3644]     index into `materials` of the `usemtl` in force at each face
+  materials    str     [7]        material names in model.mtl order;  kd float64 [7,3] their `Kd`;  map_kd str [7] their
+                                  `map_Kd` file ('' = none)
+  image_<file> uint8   [H,W,3]    the texture JPEGs decoded HERE with PIL/libjpeg-turbo (the reference decoded them with its
+                                  own skimage/libjpeg in 2018: decoders differ by a few levels, see tests/test_texture_io.py)
+  display_png  uint8   [256,256,3] tests/data/display.png, the reference's render of that model (test_load_obj.py:59)
+
 The hard-coded `grad_ref` constants of the backward tests are numbers in the reference's test
 source (tests/test_rasterize_silhouettes.py:47-51,79-83); they are restated, with that citation, in
 tests/test_oracle_golden.py rather than stored here.
@@ -83,5 +97,56 @@ def main():
     print('wrote', OUT, os.path.getsize(OUT), 'bytes')
 
 
+def display_model():
+    root = os.path.join(REF, 'tests/data/4e49873292196f02574b5684eaec43e9')
+    v, vt, fv, fvt, fmat = [], [], [], [], []
+    names, kd, map_kd = [], {}, {}
+    cur = ''
+    for line in open(os.path.join(root, 'model.mtl')):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == 'newmtl':
+            cur = t[1]
+            names.append(cur)
+        elif t[0] == 'Kd':
+            kd[cur] = [float(x) for x in t[1:4]]
+        elif t[0] == 'map_Kd':
+            map_kd[cur] = t[1]
+    cur = ''
+    for line in open(os.path.join(root, 'model.obj')):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == 'v':
+            v.append([float(x) for x in t[1:4]])
+        elif t[0] == 'vt':
+            vt.append([float(x) for x in t[1:3]])
+        elif t[0] == 'usemtl':
+            cur = t[1]
+        elif t[0] == 'f':
+            a = [int(c.split('/')[0]) for c in t[1:]]
+            b = [int(c.split('/')[1]) if '/' in c else 0 for c in t[1:]]   # no uv: 0, i.e. -1 below (load_obj.py:44-56)
+            for i in range(len(a) - 2):
+                fv.append((a[0], a[i + 1], a[i + 2]))
+                fvt.append((b[0], b[i + 1], b[i + 2]))
+                fmat.append(names.index(cur))
+    out = dict(
+        v=np.asarray(v, np.float32), vt=np.asarray(vt, np.float32), faces_v=np.asarray(fv, np.int32) - 1,
+        faces_vt=np.asarray(fvt, np.int32) - 1, face_material=np.asarray(fmat, np.int32), materials=np.asarray(names),
+        kd=np.asarray([kd[n] for n in names], np.float64), map_kd=np.asarray([map_kd.get(n, '') for n in names]),
+        display_png=img('tests/data/display.png'))
+    for n in names:
+        if n in map_kd:
+            key = 'image_' + os.path.basename(map_kd[n])
+            out[key] = np.asarray(Image.open(os.path.join(root, map_kd[n])).convert('RGB'))
+    path = os.path.join(os.path.dirname(OUT), 'display_model.npz')
+    for k, a in out.items():
+        print('%-22s %-8s %s' % (k, a.dtype, a.shape))
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 if __name__ == '__main__':
     main()
+    display_model()

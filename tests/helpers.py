@@ -74,3 +74,45 @@ def rel_err(a, b, floor=None):
     if floor is None:
         floor = 1e-3 * (np.abs(b).max() if b.size else 1.0) + 1e-30
     return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max()) if b.size else 0.0
+
+
+_display = None
+
+
+def display_model():
+    """tests/golden/display_model.npz: the textured ShapeNet model of the reference's tests/test_load_obj.py:51-59."""
+    global _display
+    if _display is None:
+        _display = dict(np.load(os.path.join(os.path.dirname(GOLDEN), 'display_model.npz')))
+    return _display
+
+
+def write_display_model(dirpath):
+    """Re-create model.obj / model.mtl / images/*.png from the fixture arrays (lossless: %.9g floats, PNG textures whose
+    pixels are the JPEGs as decoded when the fixture was made).  Returns the .obj path."""
+    from PIL import Image
+    g = display_model()
+    os.makedirs(os.path.join(dirpath, 'images'), exist_ok=True)
+    with open(os.path.join(dirpath, 'model.mtl'), 'w') as f:
+        for name, kd, tex in zip(g['materials'], g['kd'], g['map_kd']):
+            f.write('newmtl %s\nKa 0.000000 0.000000 0.000000\nKd %.6f %.6f %.6f\n' % ((name,) + tuple(kd)))
+            if tex:
+                png = os.path.splitext(os.path.basename(str(tex)))[0] + '.png'
+                Image.fromarray(g['image_' + os.path.basename(str(tex))]).save(os.path.join(dirpath, 'images', png))
+                f.write('map_Kd ./images/%s\n' % png)
+            f.write('\n')
+    path = os.path.join(dirpath, 'model.obj')
+    with open(path, 'w') as f:
+        f.write('mtllib model.mtl\n')
+        f.writelines('v %.9g %.9g %.9g\n' % tuple(v) for v in g['v'])
+        f.writelines('vt %.9g %.9g\n' % tuple(t) for t in g['vt'])
+        cur = -1
+        for fv, ft, m in zip(g['faces_v'], g['faces_vt'], g['face_material']):
+            if m != cur:
+                cur = m
+                f.write('usemtl %s\n' % g['materials'][m])
+            if ft[0] < 0:
+                f.write('f %d %d %d\n' % tuple(fv + 1))
+            else:
+                f.write('f %d/%d %d/%d %d/%d\n' % (fv[0] + 1, ft[0] + 1, fv[1] + 1, ft[1] + 1, fv[2] + 1, ft[2] + 1))
+    return path
