@@ -17,6 +17,7 @@
  *   nr_backward_rasterize        <- Rasterize.backward_gpu (K6 -> K7 -> K8 fused)  rasterize.py:849-889
  *   nr_vertices_to_faces[_backward] <- vertices_to_faces + its get_item backward    vertices_to_faces.py:4-21
  *   nr_image_epilogue[_backward]  <- transpose + flip + average_pooling_2d of rasterize_rgbad   rasterize.py:953-969
+ *   nr_adam_update                <- AdamRule.update_core_gpu                                  optimizers.py:17-34
  *   nr_load_textures              <- load_textures kernel of load_obj(load_texture=True)      load_obj.py:87-144
  *   nr_create_texture_image       <- create_texture_image kernels of save_obj(textures=...)   save_obj.py:32-146
  *   nr_frontend_forward/_backward <- fill_back + lighting + look_at/look + perspective + vertices_to_faces
@@ -253,6 +254,15 @@ int nr_load_textures(const float *image, const float *faces_uv, const int32_t *i
 int nr_create_texture_image(const float *textures, const float *tile_vertices, float *image, int32_t num_faces,
                             int32_t texture_size_in, int32_t texture_size_out, int32_t tile_width, int32_t tile_height,
                             void *stream);
+
+/*
+ * Masked Adam update (reference optimizers.py:17-34): for every element with grad != 0
+ *   m += one_minus_beta1 * (grad - m);  v += one_minus_beta2 * (grad * grad - v);  v = max(v, 0);
+ *   param -= lr * m / (sqrt(v) + eps);
+ * elements with a zero gradient keep parameter and moments.  float32, in place; `lr` = alpha_t * the parameter's multiplier.
+ */
+int nr_adam_update(float *param, const float *grad, float *m, float *v, size_t count, float lr, float one_minus_beta1,
+                   float one_minus_beta2, float eps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ SIGNATURES = {
     'nr_image_epilogue_backward': (_c.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
     'nr_load_textures': (_c.c_int, [_vp] * 4 + [_i32] * 4 + [_vp]),
     'nr_create_texture_image': (_c.c_int, [_vp] * 3 + [_i32] * 5 + [_vp]),
+    'nr_adam_update': (_c.c_int, [_vp] * 4 + [_sz] + [_c.c_float] * 4 + [_vp]),
     'nr_frontend_workspace_bytes': (_sz, [_i32]),
     'nr_frontend_forward': (_c.c_int, [_vp] * 6 + [_i32] * 7 + [_cam_p, _light_p, _vp]),
     'nr_frontend_backward': (_c.c_int, [_vp] * 9 + [_i32] * 7 + [_cam_p, _light_p, _vp, _sz, _vp]),

@@ -14,7 +14,8 @@ class Mesh(nn.Module):
         self.num_vertices = self.vertices.shape[0]
         self.num_faces = self.faces.shape[0]
         shape = (self.num_faces, texture_size, texture_size, texture_size, 3)
-        self.textures = nn.Parameter(torch.randn(shape, dtype=torch.float32))  # mesh.py:22-24 (normal init)
+        # mesh.py:22-24: chainer.initializers.Normal() = N(0, 0.05^2)
+        self.textures = nn.Parameter(torch.randn(shape, dtype=torch.float32) * 0.05)
         self.texture_size = texture_size
 
     def get_batch(self, batch_size):
@@ -23,3 +24,8 @@ class Mesh(nn.Module):
         faces = self.faces[None].expand(batch_size, *self.faces.shape)
         textures = torch.sigmoid(self.textures[None].expand(batch_size, *self.textures.shape))
         return vertices, faces, textures
+
+    def set_lr(self, lr_vertices, lr_textures):
+        """Per-parameter learning-rate multipliers read by neural_renderer_amd.Adam (mesh.py:36-38)."""
+        self.vertices.lr = lr_vertices
+        self.textures.lr = lr_textures

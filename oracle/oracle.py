@@ -663,3 +663,36 @@ class Renderer(object):
         faces = vertices_to_faces(self._camera(vertices), faces)
         return rasterize(faces, textures, self.image_size, self.anti_aliasing, self.near, self.far,
                          self.rasterizer_eps, self.background_color)
+
+
+# ----------------------------------------------------------------------------------------------------
+# optimizer                                                                  (optimizers.py:9-39)
+def adam_update(param, grad, m, v, lr, one_minus_beta1, one_minus_beta2, eps):
+    """optimizers.py:22-34 in float32, in place: elements with grad == 0 keep parameter and moments."""
+    lr, b1, b2, eps = np.float32(lr), np.float32(one_minus_beta1), np.float32(one_minus_beta2), np.float32(eps)
+    on = grad != 0
+    g = grad[on]
+    mi = m[on] + b1 * (g - m[on])
+    vi = v[on] + b2 * (g * g - v[on])
+    vi = np.where(vi < 0, np.float32(0), vi)
+    m[on], v[on] = mi, vi
+    param[on] = param[on] - lr * mi / (np.sqrt(vi) + eps)
+
+
+class Adam(object):
+    """chainer.optimizers.Adam with the reference's masked rule; `lr_mult` = the parameter's `.lr` (optimizers.py:20)."""
+
+    def __init__(self, alpha=0.001, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.alpha, self.beta1, self.beta2, self.eps, self.t = alpha, beta1, beta2, eps, 0
+        self.state = {}
+
+    def update(self, params, grads, lr_mult=None):
+        self.t += 1
+        lr_t = self.alpha * math.sqrt(1 - self.beta2 ** self.t) / (1 - self.beta1 ** self.t)
+        for k, (p, g) in enumerate(zip(params, grads)):
+            if g is None:
+                continue
+            m, v = self.state.setdefault(k, (np.zeros_like(p), np.zeros_like(p)))
+            lr = lr_t * (1.0 if lr_mult is None else lr_mult[k])
+            if lr != 0:
+                adam_update(p, g, m, v, lr, 1 - self.beta1, 1 - self.beta2, self.eps)
