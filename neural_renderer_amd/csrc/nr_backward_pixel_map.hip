@@ -555,35 +555,58 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
             }
             __syncthreads();
 
-            // ---- 4. sweeps, one SEGMENT (<= SEG pixels of one sweep) per thread.  Segment ids are dense:
-            //         line l owns ids [s_pref[l], s_pref[l + 1]): first its in-sweep pieces, then its out-sweep pieces.
+            // ---- 4. sweeps, one SEGMENT (<= SEG pixels of one sweep) per thread.  Segment ids are dense and ordered by
+            //         class: first every FULL segment (exactly SEG pixels) of every line, then the partial ones (the
+            //         remainders, i.e. all the short in-sweeps), so that the 64 lanes of a wave walk segments of (nearly)
+            //         equal length instead of idling behind one long out-sweep piece.  One packed scan gives both
+            //         prefixes: full segments in the low 16 bits (<= BAND_WIN * 2 * S / SEG), partial ones above.
             int n_seg = 0;
             if (tid < n_win) {
                 const BandLine &L = s_line[tid];
                 const int il = (L.in_rng >> 16) - (L.in_rng & 0xffff) + 1, ol = (L.out_rng >> 16) - (L.out_rng & 0xffff) + 1;
-                n_seg = (il > 0 ? (il + SEG - 1) / SEG : 0) + (ol > 0 ? (ol + SEG - 1) / SEG : 0);
+                const int full = (il > 0 ? il / SEG : 0) + (ol > 0 ? ol / SEG : 0);
+                const int part = (il > 0 && il % SEG != 0) + (ol > 0 && ol % SEG != 0);
+                n_seg = full | (part << 16);
             }
             int total_seg = 0;
             const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
             if (tid < n_win) s_pref[tid] = seg_off;
             __syncthreads();
-            for (int sid = tid; sid < total_seg; sid += BAND_THREADS) {
-                // last line l with s_pref[l] <= sid
+            const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
+            for (int sid = tid; sid < total_all; sid += BAND_THREADS) {
+                const bool is_full = sid < total_full;
+                const int id = is_full ? sid : sid - total_full;
+                const int shift = is_full ? 0 : 16;
+                // last line l whose prefix (of this class) is <= id
                 int lo = 0, hi = n_win - 1;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
-                    if (s_pref[mid] <= sid) lo = mid; else hi = mid - 1;
+                    if (((s_pref[mid] >> shift) & 0xffff) <= id) lo = mid; else hi = mid - 1;
                 }
                 const BandLine *L = &s_line[lo];
                 const int4 h = *reinterpret_cast<const int4 *>(L);
                 const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
-                int k = sid - s_pref[lo];
+                const int k = id - ((s_pref[lo] >> shift) & 0xffff);
                 const int in_from = h.x & 0xffff, in_to = h.x >> 16;
-                const int n_in = in_to >= in_from ? (in_to - in_from + SEG) / SEG : 0;
-                const bool mode_in = k < n_in;
-                if (!mode_in) k -= n_in;
-                const int s_from = (mode_in ? in_from : (h.y & 0xffff)) + k * SEG;
-                const int s_to = min(s_from + SEG - 1, mode_in ? in_to : (h.y >> 16));
+                const int il = in_to - in_from + 1;
+                const int n_in_full = il > 0 ? il / SEG : 0;
+                bool mode_in;
+                int s_from, s_to;
+                if (is_full) {
+                    mode_in = k < n_in_full;
+                    s_from = mode_in ? in_from + k * SEG : (h.y & 0xffff) + (k - n_in_full) * SEG;
+                    s_to = s_from + SEG - 1;
+                } else {
+                    mode_in = k == 0 && il > 0 && il % SEG != 0;
+                    if (mode_in) {
+                        s_from = in_from + n_in_full * SEG;
+                        s_to = in_to;
+                    } else {
+                        const int out_from = h.y & 0xffff, out_to = h.y >> 16;
+                        s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG;
+                        s_to = out_to;
+                    }
+                }
                 const int flags = (h.z >> 24) & 0xff;
                 const int ld = (h.z >> 16) & 0xff;
                 const int d1_in = h.z & 0xffff;
