@@ -139,6 +139,45 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
     return out
 
 
+def renderer_end_to_end(device, batch, first_view, total_views, image_size, texture_size, iters=10):
+    """SURVEY 8d "report end-to-end Renderer.render* time separately": the same scene through the public Renderer
+    (fused HIP front-end -> rasterizer -> HIP image epilogue, anti-aliasing off so that S = image_size) with a squared-sum
+    loss, forward + backward, wall clock per step."""
+    import neural_renderer_amd as nr
+    v, f = load_teapot()
+    vertices = torch.from_numpy(v).to(device)[None].repeat(batch, 1, 1).requires_grad_(True)
+    faces = torch.from_numpy(f).to(device)[None].repeat(batch, 1, 1)
+    textures = torch.ones((batch, f.shape[0], texture_size, texture_size, texture_size, 3), device=device,
+                          requires_grad=True)
+    r = nr.Renderer()
+    r.image_size, r.anti_aliasing = image_size, False
+    r.eye = torch.tensor([nr.get_points_from_angles(2.732, 30., 360.0 * (first_view + i) / total_views)
+                          for i in range(batch)], dtype=torch.float32, device=device)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    def rgb():
+        vertices.grad = None
+        textures.grad = None
+        r.render(vertices, faces, textures).square().sum().backward()
+
+    def sil():
+        vertices.grad = None
+        r.render_silhouettes(vertices, faces).square().sum().backward()
+
+    return {'render_fwd_bwd_ms': timed(rgb), 'render_silhouettes_fwd_bwd_ms': timed(sil),
+            'what': 'Renderer.render / render_silhouettes + squared-sum loss, forward + backward, %d views, %dx%d, '
+                    'anti_aliasing off' % (batch, image_size, image_size)}
+
+
 def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views):
     """The C oracle on `sample_views` views of the same workload, one host thread."""
     from oracle import oracle as O
@@ -315,6 +354,7 @@ def main():
                 'frac': sum(stage_bytes.values()) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
+        e2e = renderer_end_to_end(dev, B, rank * B, world * B, S, ts)
         cpu = None
         if args.cpu_sample_views > 0:
             cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
@@ -332,7 +372,7 @@ def main():
                                % (world, ' + all_gather(rgb)' if gather_buf is not None else ''),
             },
             'roofline': roofline, 'cpu_baseline': cpu, 'stages_us': stages, 'grad_check': grad_err,
-            'launch_mode': mode, 'eager_ms_per_step': eager_ms,
+            'launch_mode': mode, 'eager_ms_per_step': eager_ms, 'renderer_end_to_end': e2e,
         }
         print(json.dumps(line))
     if dist is not None:
