@@ -350,11 +350,19 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, double *__restrict__ scratch, int F, int S,
-    int W, int SP, double eps)
+    int W, int SP, double eps, int B)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int band = blockIdx.x, axis = blockIdx.y, b = blockIdx.z;
+    // XCD-aware placement: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with a private
+    // L2).  Bands of one image share cache lines -- 8 adjacent 4-column bands sit in the same 128-byte line of every map
+    // row, and the horizontal pass re-reads what the vertical pass just fetched -- so all 2 * n_bands workgroups of an
+    // image are given ids that land on ONE XCD: logical id = (physical % 8) * chunk + physical / 8.
+    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
+    const unsigned total_wg = n_bands * 2u * (unsigned)B, chunk = (total_wg + NUM_XCD - 1) / NUM_XCD;
+    const unsigned logical = (blockIdx.x % NUM_XCD) * chunk + blockIdx.x / NUM_XCD;
+    if (logical >= total_wg) return;
+    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
 
@@ -770,9 +778,10 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const dim3 grid((unsigned)((S + W - 1) / W), 2, (unsigned)B);
+    const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
+    const dim3 grid((total_wg + NUM_XCD - 1) / NUM_XCD * NUM_XCD);  // 1-D: the kernel maps ids to (image, axis, band) per XCD
     hipLaunchKernelGGL(kern, grid, dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha, vis_list,
-                       vis_count, scratch, F, S, W, S + 4, eps);
+                       vis_count, scratch, F, S, W, S + 4, eps, B);
     return 0;
 }
 

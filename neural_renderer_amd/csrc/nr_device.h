@@ -150,6 +150,8 @@ __device__ __forceinline__ void compute_taps(const float *__restrict__ face, con
 
 // --------------------------------------------------------------------------------------------------
 // host side helpers
+constexpr unsigned NUM_XCD = 8;  // MI355X: 8 accelerator dies, consecutive workgroup ids are dealt to them round-robin
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 inline int check_sizes(int B, int F, int S)
