@@ -150,7 +150,21 @@ __device__ __forceinline__ void compute_taps(const float *__restrict__ face, con
 
 // --------------------------------------------------------------------------------------------------
 // host side helpers
-constexpr unsigned NUM_XCD = 8;  // MI355X: 8 accelerator dies, consecutive workgroup ids are dealt to them round-robin
+// XCD-aware workgroup placement.  MI355X has 8 accelerator dies (XCDs), each with a private L2; the hardware deals
+// consecutive workgroup ids of a launch round-robin to them.  Work items that share data (the faces, maps and textures of one
+// image) should therefore NOT have consecutive ids: a 1-D grid of xcd_grid(n) workgroups is launched and the kernel uses
+// xcd_block(n) instead of blockIdx.x, which makes each XCD walk one contiguous 1/8 of the logical range.
+constexpr unsigned NUM_XCD = 8;
+inline unsigned xcd_grid(size_t n_blocks) { return (unsigned)((n_blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD); }
+#ifdef __HIPCC__
+// logical block id in [0, n_blocks), or n_blocks (= "no work") for the padding blocks
+__device__ __forceinline__ unsigned xcd_block(unsigned n_blocks)
+{
+    const unsigned chunk = (n_blocks + NUM_XCD - 1) / NUM_XCD;
+    const unsigned logical = (blockIdx.x % NUM_XCD) * chunk + blockIdx.x / NUM_XCD;
+    return logical < n_blocks ? logical : n_blocks;
+}
+#endif
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
