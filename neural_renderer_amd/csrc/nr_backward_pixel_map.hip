@@ -288,10 +288,24 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char
     }
 }
 
+// Line range of one edge along one axis (rasterize.py:567-569), packed lo | hi << 16; RNG_EMPTY (lo > hi) when the edge
+// crosses no integer line or is parallel to the sweeps (p0x == p1x: both contributions are skipped, :648, :653).
+constexpr unsigned RNG_EMPTY = 1u;
+
+__device__ __forceinline__ unsigned edge_range(float p0x, float p1x, int S)
+{
+    const int d0_from = (int)fmax((double)ceilf(fminf(p0x, p1x)), 0.0);   // :568
+    const int d0_to = (int)fmin((double)fmaxf(p0x, p1x), S - 1.0);        // :569
+    return (p0x != p1x && d0_to >= d0_from) ? (unsigned)d0_from | ((unsigned)d0_to << 16) : RNG_EMPTY;
+}
+
+// Besides the ordered list, every visible face gets its six edge line ranges, rng[b][axis][slot][edge], so that the
+// 2 * n_bands band workgroups of an image scan 12 coalesced bytes per face instead of chasing list -> vertices each.
 __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned char *__restrict__ flags,
                                                                const int *__restrict__ chunk_count,
                                                                int *__restrict__ vis_list, int *__restrict__ vis_count,
-                                                               int F, int n_chunks)
+                                                               int F, int n_chunks, const float *__restrict__ faces,
+                                                               unsigned *__restrict__ rng, int S)
 {
     __shared__ int s_wcnt[VIS_CHUNK / 64];
     __shared__ int s_part[VIS_CHUNK / 64];
@@ -312,7 +326,21 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
         if (w < wave) off += s_wcnt[w];
         own += s_wcnt[w];
     }
-    if (v) vis_list[(size_t)b * F + off + __popcll(m & ((1ull << lane) - 1ull))] = fn;
+    if (v) {
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        vis_list[(size_t)b * F + pos] = fn;
+        const float *f = faces + ((size_t)b * F + fn) * 9;
+        const float fs = (float)S;
+        float px[3], py[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { px[k] = to_pixel(f[3 * k], fs); py[k] = to_pixel(f[3 * k + 1], fs); }
+        unsigned *r0 = rng + (((size_t)b * 2 + 0) * F + pos) * 3, *r1 = rng + (((size_t)b * 2 + 1) * F + pos) * 3;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            r0[e] = edge_range(px[e], px[(e + 1) % 3], S);
+            r1[e] = edge_range(py[e], py[(e + 1) % 3], S);
+        }
+    }
     if (chunk == n_chunks - 1 && tid == 0) {
         int base = 0;
         for (int w = 0; w < VIS_CHUNK / 64; ++w) base += s_part[w];
@@ -349,8 +377,8 @@ template <bool RGB, bool ALPHA, bool EXACT, bool POW2>
 __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void k_bpm_band(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
-    const int *__restrict__ vis_list, const int *__restrict__ vis_count, double *__restrict__ scratch, int F, int S,
-    int W, int SP, double eps, int B)
+    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
+    double *__restrict__ scratch, int F, int S, int W, int SP, double eps, int B)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -473,19 +501,12 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
         int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
         if (chunk + tid < n_vis) {
             fn = vis_list[(size_t)b * F + chunk + tid];
-            const float *f = faces + ((size_t)b * F + fn) * 9;
-            float px[3], py[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { px[k] = to_pixel(f[3 * k], fs); py[k] = to_pixel(f[3 * k + 1], fs); }
+            const unsigned *r = rng + (((size_t)b * 2 + axis) * F + chunk + tid) * 3;
 #pragma unroll
             for (int e = 0; e < 3; e++) {
-                const int i0 = e, i1 = (e + 1) % 3;
-                const float p0x = axis ? py[i0] : px[i0], p1x = axis ? py[i1] : px[i1];
-                const int d0_from = (int)fmax((double)ceilf(fminf(p0x, p1x)), 0.0);   // :568
-                const int d0_to = (int)fmin((double)fmaxf(p0x, p1x), S - 1.0);        // :569
-                const int lo = max(d0_from, band_lo), hi = min(d0_to, band_hi);
-                // p0x == p1x: the only possible d0 equals both, so both contributions are skipped (:648, :653)
-                if (p0x != p1x && hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
+                const unsigned pr = r[e];
+                const int lo = max((int)(pr & 0xffffu), band_lo), hi = min((int)(pr >> 16), band_hi);
+                if (hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
             }
         }
         // one scan for two prefixes: lines in the low 20 bits (<= 512 * 3 * W), faces-with-lines above
@@ -727,7 +748,7 @@ __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__
 // ====================================================================================================
 
 struct BpmLayout {
-    size_t flags_off, scratch_off, count_off, chunk_off, list_off, total, zero_bytes;
+    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, total, zero_bytes;
     int n_chunks;
 };
 
@@ -742,7 +763,8 @@ BpmLayout bpm_layout(int B, int F)
     L.n_chunks = (F + VIS_CHUNK - 1) / VIS_CHUNK;
     L.chunk_off = L.count_off + align_up((size_t)B * sizeof(int), 256);
     L.list_off = L.chunk_off + align_up((size_t)B * L.n_chunks * sizeof(int), 256);
-    L.total = L.list_off + n * sizeof(int);
+    L.rng_off = L.list_off + align_up(n * sizeof(int), 256);
+    L.total = L.rng_off + n * 6 * sizeof(unsigned);  // [B][axis][slot][edge]
     return L;
 }
 
@@ -770,8 +792,8 @@ int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes)
 
 template <bool RGB, bool ALPHA, bool EXACT, bool POW2>
 int launch_band(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
-                const float *g_alpha, const int *vis_list, const int *vis_count, double *scratch, int B, int F, int S,
-                int W, size_t lds, double eps, hipStream_t st)
+                const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch, int B,
+                int F, int S, int W, size_t lds, double eps, hipStream_t st)
 {
     auto kern = k_bpm_band<RGB, ALPHA, EXACT, POW2>;
     if (lds > 48 * 1024) {
@@ -781,7 +803,7 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     const dim3 grid(xcd_grid(total_wg));  // 1-D: the kernel maps ids to (image, axis, band) per XCD
     hipLaunchKernelGGL(kern, grid, dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha, vis_list,
-                       vis_count, scratch, F, S, W, S + 4, eps, B);
+                       vis_count, rng, scratch, F, S, W, S + 4, eps, B);
     return 0;
 }
 
@@ -845,19 +867,20 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, face_index_map, flags, F,
                        S * S, P);
     int *chunk_count = (int *)(ws + L.chunk_off);
+    unsigned *rng = (unsigned *)(ws + L.rng_off);
     hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, flags,
                        chunk_count, F, L.n_chunks);
     hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, flags,
-                       chunk_count, vis_list, vis_count, F, L.n_chunks);
+                       chunk_count, vis_list, vis_count, F, L.n_chunks, faces, rng, S);
     const char *fa = getenv("NR_K6_FAST");  // 1: hardware reciprocal + per-segment float sums (-7 % time)
     const bool exact = !(fa && atoi(fa));
     int rc;
     const bool pow2 = (S & (S - 1)) == 0;
 #define NR_BAND(R, A, E)                                                                                          \
     (pow2 ? launch_band<R, A, E, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,   \
-                                       vis_list, vis_count, scratch, B, F, S, W, lds, eps, st)                     \
+                                       vis_list, vis_count, rng, scratch, B, F, S, W, lds, eps, st)                \
           : launch_band<R, A, E, false>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,  \
-                                        vis_list, vis_count, scratch, B, F, S, W, lds, eps, st))
+                                        vis_list, vis_count, rng, scratch, B, F, S, W, lds, eps, st))
     if (rgb && alpha) rc = exact ? NR_BAND(true, true, true) : NR_BAND(true, true, false);
     else if (rgb) rc = exact ? NR_BAND(true, false, true) : NR_BAND(true, false, false);
     else rc = exact ? NR_BAND(false, true, true) : NR_BAND(false, true, false);
