@@ -64,6 +64,13 @@ def build_scene(device, batch, first_view, total_views, image_size, texture_size
     return faces.contiguous(), textures.contiguous()
 
 
+# dominant kernel of each stage call (the rest of a stage are small helper launches, see profiles/README.md)
+STAGE_KERNEL = {
+    'forward_face_index_map': 'k_face_raster', 'forward_texture_sampling': 'k_shade', 'backward_pixel_map': 'k_bpm_band',
+    'backward_textures': 'k_backward_textures_face', 'backward_depth_map': 'k_backward_depth_face',
+}
+
+
 def algorithmic_bytes(B, F, S, ts):
     """Compulsory HBM traffic per launch of each stage (every input read once, every output written once;
     recomputable intermediates count zero) -- DESIGN.md 'Kernels'."""
@@ -345,9 +352,11 @@ def main():
             except Exception:
                 traffic = None
         roofline = {
-            'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'bound': 'hbm', 'kernel': STAGE_KERNEL.get(dominant, dominant), 'stage': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
             'algorithmic_bytes_per_launch': stage_bytes[dominant], 'avg_launch_us': stages[dominant],
+            'timing': 'HIP events on the launch stream around the stage call nr_%s (the dominant kernel plus its '
+                      'helper launches; profiles/README.md lists the per-kernel rocprofv3 durations they add up from)' % dominant,
             'whole_step': {
                 'algorithmic_bytes': sum(stage_bytes.values()),
                 'achieved': sum(stage_bytes.values()) / (ms_per_step * 1e-3) / 1e9,
