@@ -662,7 +662,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
                 auto fetch = [&](int d1) {
                     Px p;
                     const int l = ld * SP + d1;
-                    p.fi = s_fi[l];
+                    p.fi = mode_in ? s_fi[l] : fnr;  // only the in-sweep tests ownership (:707): out-sweeps skip this LDS read
                     p.al = p.ga = p.r = p.g = p.b = p.gr = p.gg = p.gb = 0.0f;
                     if (ALPHA) { p.al = s_al[l]; p.ga = s_ga[l]; }
                     if (RGB) {
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
                     return p;
                 };
                 auto visit = [&](const Px &p, int d1) {  // one pixel visit: :630-657 (out) / :697-728 (in)
-                    if (mode_in && p.fi != fnr) return;  // :707
+                    if (p.fi != fnr) return;  // :707
                     float diff = 0.0f;
                     if (ALPHA) diff += (p.al - ref_a) * p.ga;
                     if (RGB) {
