@@ -665,6 +665,32 @@ class Renderer(object):
                          self.rasterizer_eps, self.background_color)
 
 
+def project_backward(vertices, faces_idx, eye, grad_faces, angle=30., fill_back=True):
+    """Backward of Renderer.project (fill_back + look_at + perspective + vertices_to_faces) w.r.t. the vertices, in float64:
+    grad_faces [B, F', 3, 3] -> grad_vertices [B, Nv, 3].  The chain rule of look_at.py:42-44 (v' = R (v - eye)),
+    perspective.py:15-17 (x / z / w, y / z / w, z) and the get_item backward (scatter-add) of vertices_to_faces.py:19-21."""
+    vertices = np.asarray(vertices, np.float64)
+    bs, nv = vertices.shape[:2]
+    eye = np.broadcast_to(np.asarray(eye, np.float64).reshape(-1, 3), (bs, 3))
+    z_axis = np.float64(1) * (0 - eye)
+    z_axis = z_axis / (np.linalg.norm(z_axis, axis=1, keepdims=True) + 1e-5)
+    x_axis = np.cross(np.broadcast_to([0., 1., 0.], (bs, 3)), z_axis)
+    x_axis = x_axis / (np.linalg.norm(x_axis, axis=1, keepdims=True) + 1e-5)
+    y_axis = np.cross(z_axis, x_axis)
+    y_axis = y_axis / (np.linalg.norm(y_axis, axis=1, keepdims=True) + 1e-5)
+    r = np.stack((x_axis, y_axis, z_axis), axis=1)                              # [B,3,3], rows = axes
+    cam = np.matmul(vertices - eye[:, None, :], r.transpose(0, 2, 1))           # camera-space points
+    width = math.tan(float(np.float32(angle) / np.float32(180.) * np.float32(3.1416)))
+    idx = np.concatenate((faces_idx, faces_idx[:, :, ::-1]), axis=1) if fill_back else faces_idx
+    g_proj = np.zeros((bs, nv, 3))
+    for b in range(bs):                                                         # scatter-add of the gather
+        np.add.at(g_proj[b], idx[b].reshape(-1), np.asarray(grad_faces[b], np.float64).reshape(-1, 3))
+    zw = cam[..., 2] * width
+    g_cam = np.stack((g_proj[..., 0] / zw, g_proj[..., 1] / zw,
+                      g_proj[..., 2] - (g_proj[..., 0] * cam[..., 0] + g_proj[..., 1] * cam[..., 1]) / (cam[..., 2] * zw)), axis=2)
+    return np.matmul(g_cam, r)                                                  # g_world = R^T g_cam
+
+
 # ----------------------------------------------------------------------------------------------------
 # optimizer                                                                  (optimizers.py:9-39)
 def adam_update(param, grad, m, v, lr, one_minus_beta1, one_minus_beta2, eps):

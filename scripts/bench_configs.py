@@ -75,6 +75,27 @@ def main():
     # config 2: 16 azimuth views, RGB + depth + silhouette
     faces, textures = bench.build_scene(dev, 16, 0, 16, 256, 2)
     run('C2 teapot 16 views', faces, textures, 256, (True, True, True), 1e-3)
+    # config 3: example2, teapot -> rectangle silhouette loss through the public Renderer (256x256, anti-aliasing on), 300 Adam steps
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    import make_data
+    import example2
+    make_data.main()
+    data = os.path.join(ROOT, 'examples', 'data')
+    model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        opt.zero_grad()
+        loss = model()
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 300 * 1e3
+    print(json.dumps({'config': 'C3 example2 vertex optimisation, 300 Adam steps', 'B': 1, 'S': 512, 'ms_per_step': round(ms, 4),
+                      'loss_first': round(float(losses[0]), 2), 'loss_last': round(float(losses[-1]), 2)}), flush=True)
     # config 4 (per-GPU share): 64 distinct ~5k-face meshes (10 240 with fill_back), ts 4 random textures, 256x256 RGB
     from test_hip_parity import icosphere, project_mesh
     rng = np.random.default_rng(1234)

@@ -61,6 +61,48 @@ def test_example2_vertex_optimisation(data_dir):
     assert losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])  # silhouette moves towards the rectangle
 
 
+def test_example2_first_steps_match_the_oracle(data_dir):
+    """BASELINE.json config 3 (example2: teapot -> rectangle silhouette loss, 256x256 with anti-aliasing, Adam): the loss
+    curve and the vertices of the first optimisation steps against the same loop driven by the CPU oracle (its renderer,
+    its backward through the epilogue / rasterizer / projection, a NumPy Adam).  Tolerances: loss 1e-5 relative,
+    vertices 2e-6 absolute after 4 steps of size 1e-3."""
+    import example2
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    model = example2.Model(os.path.join(data_dir, 'teapot.obj'), os.path.join(data_dir, 'example2_ref.png')).cuda()
+    v = model.vertices.detach().cpu().numpy().copy()
+    f = model.faces.cpu().numpy()
+    ref = model.image_ref.cpu().numpy()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    steps, losses = 4, []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = model()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+
+    eye = O.get_points_from_angles(2.732, 0, 90)
+    renderer = O.Renderer()
+    renderer.eye = eye
+    m, s2 = np.zeros_like(v, dtype=np.float64), np.zeros_like(v, dtype=np.float64)
+    ref_losses = []
+    for t in range(1, steps + 1):
+        faces = renderer.project(v, f)
+        out = O.rasterize_rgbad(faces, None, 256, True, return_rgb=False, return_alpha=True, return_depth=False,
+                                return_function=True)
+        image = out['alpha']
+        ref_losses.append(float(np.sum(np.square(image.astype(np.float64) - ref[None]))))
+        g_faces, = O.rgbad_backward(out['function'], True, None, (2 * (image - ref[None])).astype(np.float32), None)
+        g = O.project_backward(v, f, eye, g_faces)
+        m = 0.9 * m + 0.1 * g                                    # torch.optim.Adam defaults
+        s2 = 0.999 * s2 + 0.001 * g * g
+        v = (v - 1e-3 * (m / (1 - 0.9 ** t)) / (np.sqrt(s2 / (1 - 0.999 ** t)) + 1e-8)).astype(np.float32)
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+    assert losses[-1] < losses[0]
+    np.testing.assert_allclose(model.vertices.detach().cpu().numpy(), v, atol=2e-6)
+
+
 def test_example3_texture_optimisation(data_dir):
     import example3
     np.random.seed(0)
