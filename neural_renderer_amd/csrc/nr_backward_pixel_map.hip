@@ -7,7 +7,8 @@ using namespace nr;
 namespace {
 
 // --------------------------------------------------------------------------------------------------
-// B1: backward_pixel_map (rasterize.py:517-748).
+// B1: backward_pixel_map (rasterize.py:517-748), global-memory form.  This kernel is the FALLBACK (raster sizes whose
+// bands do not fit in LDS, or NR_K6_GLOBAL=1); the default path is the band pipeline further down.
 //
 // Work decomposition.  The reference runs ONE thread per face through 3 edges x 2 axes x every integer
 // column/row d0 crossed by the edge x two pixel sweeps along d1 (an "in" sweep from the edge to the
@@ -222,21 +223,23 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 // kernel above to be bound by memory latency and, for the vertical sweeps (axis 0, stride S), by 3x
 // cache-line amplification.  The band pipeline makes every sweep an LDS access:
 //
-//   k_mark_visible / k_compact_visible   per image, the sorted list of faces that own at least one pixel.
-//          A face that owns no pixel contributes nothing to K6 (the out sweep needs face_index[in] == fn,
-//          :604, the in sweep only counts pixels owned by fn, :707), so ~2/3 of the front faces drop out.
-//   k_bpm_band   one workgroup per (image, axis, band of W consecutive lines d0).  It
+//   k_mark_visible / k_count_visible / k_compact_visible   per image, the sorted list of faces that own at least one
+//          pixel.  A face that owns no pixel contributes nothing to K6 (the out sweep needs face_index[in] == fn,
+//          :604, the in sweep only counts pixels owned by fn, :707), so ~2/3 of the front faces drop out.  The
+//          compaction also stores, per listed face, the line range of each of its 3 edges along both axes.
+//   k_bpm_band   one workgroup per (image, axis, band of W consecutive lines d0); workgroup ids are mapped so that all
+//          bands of an image run on one XCD (xcd_block).  It
 //          1. stages the band's W x S pixels of face_index / alpha / rgb / their gradients in LDS, laid out
 //             [line][d1] so that a sweep is a contiguous LDS run whatever the axis;
-//          2. scans the image's visible faces (one per thread): for each of the 3 edges the d0 range clipped
-//             to the band gives the face's lines; an exclusive scan assigns line slots;
+//          2. scans the image's visible faces (one per thread, 12 coalesced bytes each): for each of the 3 edges the
+//             precomputed d0 range clipped to the band gives the face's lines; an exclusive scan assigns line slots;
 //          3. sets lines up one per thread (crossing point, in/out pixels, sweep ranges, the two distance
 //             coefficients, rasterize.py:573-579, :606-609, :665-672) into 32-byte LDS records;
-//          4. sweeps: the in / out sweeps of all lines are cut into segments of <= 16 pixels; segment ids are dense
-//             (exclusive scan of the per-line segment counts), one thread walks one segment (binary search
-//             id -> line), so the work is balanced whatever the mix of short in-sweeps and border-long
-//             out-sweeps; the two partial sums of a segment are kept in double and added to per-face LDS
-//             accumulators (ds_add_f64);
+//          4. sweeps: the in / out sweeps of all lines are cut into segments of <= SEG = 15 pixels; segment ids are
+//             dense (one packed scan of the per-line counts) and ordered by class -- all full-length segments first,
+//             the remainders after -- and one thread walks one segment (binary search id -> line), so the lanes of a
+//             wave have equal trip counts whatever the mix of short in-sweeps and border-long out-sweeps; the two
+//             partial sums of a segment are kept in double and added to per-face LDS accumulators (ds_add_f64);
 //          5. adds the per-face sums to a double scratch array [B*F][3 vertices][x|y] (global_atomic_add_f64).
 //   k_bpm_finalize   rounds the scratch sums to float and STORES grad_faces (z = 0).
 // Every per-pixel term uses the reference's arithmetic; sums are carried in double, so the result is the
