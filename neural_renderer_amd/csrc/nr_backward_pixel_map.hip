@@ -374,6 +374,13 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int *total)
     return woff + inc - v;
 }
 
+// rasterize.py:651 / :656 / :722 / :727: `dist += eps` when 0 < dist, `dist -= eps` otherwise (eps is a double literal there).
+// Returns +-eps; only the high dword depends on the comparison (one v_cndmask instead of two selects on 64-bit values).
+__device__ __forceinline__ double signed_eps(float dist, unsigned eps_hi, unsigned eps_lo)
+{
+    return __hiloint2double((int)((0.0f < dist) ? eps_hi : (eps_hi ^ 0x80000000u)), (int)eps_lo);
+}
+
 // POW2: S is a power of two (x * 2. / S is then one exact float multiply; the generic instantiation carries a
 // double-precision division whose register footprint would otherwise cap the occupancy of the common case).
 template <bool RGB, bool ALPHA, bool EXACT, bool POW2>
@@ -658,6 +665,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
                 float f0 = 0.0f, f1 = 0.0f;
                 double d0acc = 0.0, d1acc = 0.0;
                 const float two_over_s_f = (float)two_over_s;  // exact when S is a power of two
+                const unsigned eps_hi = (unsigned)__double2hiint(eps), eps_lo = (unsigned)__double2loint(eps);
                 const bool has0 = (flags & 2) != 0, has1 = (flags & 4) != 0;
                 // pixel data of the NEXT visit is fetched before the current one is evaluated, so that the LDS
                 // latency hides behind the VALU work of a visit (occupancy here is only 2-4 waves/SIMD)
@@ -688,13 +696,13 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
                     if (has0) {  // :648-652 (x * 2. / S: an exact scaling when S is a power of two)
                         const float ct = c0 * t;
                         float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
-                        dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
+                        dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
                         if (EXACT) d0acc -= (double)(diff / dist); else f0 -= diff * __builtin_amdgcn_rcpf(dist);
                     }
                     if (has1) {  // :653-657
                         const float ct = c1 * t;
                         float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
-                        dist = (0.0f < dist) ? (float)((double)dist + eps) : (float)((double)dist - eps);
+                        dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
                         if (EXACT) d1acc -= (double)(diff / dist); else f1 -= diff * __builtin_amdgcn_rcpf(dist);
                     }
                 };
