@@ -215,7 +215,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='views per GPU')
     ap.add_argument('--image-size', type=int, default=256, help='raster size S (anti-aliasing off)')
     ap.add_argument('--texture-size', type=int, default=2)
-    ap.add_argument('--cpu-sample-views', type=int, default=16, help='views timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-sample-views', type=int, default=32,
+                    help='views timed on the CPU oracle, rank 0 of a 1-GPU run only (0 = skip); 32 views ~ 13 s')
     ap.add_argument('--stage-iters', type=int, default=20)
     ap.add_argument('--gather', action='store_true', help='also all_gather the rendered images each step (RCCL)')
     ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph (measured: no gain, the stream is GPU-bound)')
@@ -365,7 +366,7 @@ def main():
         }
         e2e = renderer_end_to_end(dev, B, rank * B, world * B, S, ts)
         cpu = None
-        if args.cpu_sample_views > 0:
+        if args.cpu_sample_views > 0 and world == 1:
             cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
                                min(args.cpu_sample_views, B))
         line = {
