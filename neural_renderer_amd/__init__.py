@@ -1,18 +1,25 @@
-"""neural_renderer_amd -- MI355X-native differentiable mesh rasterizer behind the API of
-hiroharu-kato/neural_renderer (reference neural_renderer/__init__.py:1-16)."""
+"""neural_renderer_amd -- MI355X-native differentiable mesh rasterizer behind the API of hiroharu-kato/neural_renderer.
+
+The public names are the reference's (neural_renderer/__init__.py:1-16); `import neural_renderer` is an alias package."""
+# the operator and its wrappers (HIP kernels behind include/nr_hip.h)
+from .rasterize import (Rasterize, rasterize, rasterize_depth, rasterize_rgbad, rasterize_silhouettes,
+                        use_unsafe_rasterizer)
+from .renderer import Renderer
+# geometry / lighting glue in front of the rasterizer
 from .cross import cross
 from .get_points_from_angles import get_points_from_angles
 from .lighting import lighting
-from .load_obj import load_obj
 from .look import look
 from .look_at import look_at
+from .perspective import perspective
+from .vertices_to_faces import vertices_to_faces
+# meshes, files, optimiser
+from .load_obj import load_obj
 from .mesh import Mesh
 from .optimizers import Adam
-from .perspective import perspective
-from .rasterize import (
-    rasterize_rgbad, rasterize, rasterize_silhouettes, rasterize_depth, use_unsafe_rasterizer, Rasterize)
-from .renderer import Renderer
 from .save_obj import save_obj
-from .vertices_to_faces import vertices_to_faces
 
-__version__ = '0.1.0'
+__version__ = '0.1.1'
+__all__ = ['Rasterize', 'rasterize', 'rasterize_depth', 'rasterize_rgbad', 'rasterize_silhouettes', 'use_unsafe_rasterizer',
+           'Renderer', 'cross', 'get_points_from_angles', 'lighting', 'look', 'look_at', 'perspective', 'vertices_to_faces',
+           'load_obj', 'Mesh', 'Adam', 'save_obj']
