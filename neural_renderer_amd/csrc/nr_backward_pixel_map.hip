@@ -706,12 +706,9 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
                         if (EXACT) d1acc -= (double)(diff / dist); else f1 -= diff * __builtin_amdgcn_rcpf(dist);
                     }
                 };
-                Px cur = fetch(s_from);
                 for (int d1 = s_from; d1 <= s_to; ++d1) {
-                    Px nxt = cur;
-                    if (d1 < s_to) nxt = fetch(d1 + 1);
+                    const Px cur = fetch(d1);
                     visit(cur, d1);
-                    cur = nxt;
                 }
                 const double a0 = (double)f0 + d0acc, a1 = (double)f1 + d1acc;
                 const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
