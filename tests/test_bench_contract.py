@@ -1,0 +1,42 @@
+"""`bench.py` prints ONE JSON line with the contract's fields (small sizes; the numbers themselves are not asserted)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_json_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                          '--batch', '4', '--cpu-sample-views', '1', '--stage-iters', '2'],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and d['value'] > 0 and d['ms_per_step'] > 0
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['achieved'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c and c['unit'] == d['unit']
+    g = d['grad_check']
+    assert g['grad_faces_max_abs_err'] <= 1e-4 * g['grad_faces_max_abs']
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')], cwd=ROOT, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode != 0 and 'needs a GPU' in (out.stderr + out.stdout)
