@@ -352,7 +352,8 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     if (he != hipSuccess) return (int)he;
     hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
                        large_list, n_large, (int)n, F, S, near, far);
-    hipLaunchKernelGGL(k_large_raster, dim3(256), dim3(256), 0, st, faces, ws_inv, zbuf, large_list, n_large, F, S,
+    // 8 workgroups per CU loop over the queue (one per CU left the kernel latency-bound: config 4, 189 -> ~85 us)
+    hipLaunchKernelGGL(k_large_raster, dim3(2048), dim3(256), 0, st, faces, ws_inv, zbuf, large_list, n_large, F, S,
                        near, far);
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
                        face_index_map, weight_map, depth_map, face_inv_map, F, S, near, far, P, textures, rgb_map,
