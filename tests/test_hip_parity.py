@@ -406,6 +406,54 @@ def test_fused_backward_equals_stage_calls(modes):
         np.testing.assert_array_equal(abi.host(gt_a), abi.host(gt_b))
 
 
+@pytest.mark.parametrize('ts,eps', [(2, 0.0), (5, 1e-3), (6, 1e-3), (9, 1e-3), (13, 1e-4), (14, 1e-3), (16, 1e-3)])
+def test_texture_size_paths(ts, eps):
+    """K4 / K7 over every dispatch class of the texture gradient: texture_size 2 with eps = 0 (the static-tap fast path
+    needs eps > 0, so this takes the general one), 3-5 (16 lanes per face), 6-8 (64), 9-13 (256), >= 14 (per-pixel scatter
+    with hardware float atomics, the reference's own formulation) -- staged and fused backward against the oracle."""
+    rng = np.random.default_rng(100 + ts)
+    B, F, S = 2, 48, 64
+    faces = H.random_scene(rng, B, F, spread=0.5, size=0.35)
+    textures = rng.uniform(0, 1, (B, F, ts, ts, ts, 3)).astype(np.float32)
+    fn = oracle_forward(faces, textures, S, 0.1, 100, eps, (0.3, 0.1, 0.2), True, True, True)
+    fw = abi.forward(faces, textures, S, 0.1, 100.0, eps, (0.3, 0.1, 0.2), 0, True, True, True)
+    check_forward(fw, fn)
+    g_rgb, g_alpha, g_depth = grads_for(fn, rng)
+    ref_gf, ref_gt = fn.backward(g_rgb, g_alpha, g_depth, accumulate_double=True)
+    for run in (abi.backward, abi.backward_fused):
+        gf, gt = run(fw, g_rgb, g_alpha, g_depth)
+        gf, gt = abi.host(gf), abi.host(gt)
+        assert not np.isnan(gt).any() and not np.isnan(gf).any()
+        assert H.rel_err(gt, ref_gt) <= RTOL, (run.__name__, H.rel_err(gt, ref_gt))
+        assert H.rel_err(gf, ref_gf) <= 1e-5, (run.__name__, H.rel_err(gf, ref_gf))
+
+
+def test_culled_images_and_per_batch_background():
+    """One image whose faces are all back-facing, one whose faces all lie beyond `far` / before `near`, one ordinary; a
+    different background colour per image (rasterize.py:464-465), which K6 sees through the post-background rgb_map."""
+    rng = np.random.default_rng(77)
+    B, F, S, eps = 3, 60, 48, 1e-3
+    faces = H.random_scene(rng, B, F, spread=0.5, size=0.3)
+    front = ((faces[0, :, 2, 1] - faces[0, :, 0, 1]) * (faces[0, :, 1, 0] - faces[0, :, 0, 0])
+             >= (faces[0, :, 1, 1] - faces[0, :, 0, 1]) * (faces[0, :, 2, 0] - faces[0, :, 0, 0]))
+    faces[0, front] = faces[0, front][:, ::-1]          # image 0: every face turned away from the camera
+    faces[1, : F // 2, :, 2] = 150.0                    # image 1: beyond far = 100 ...
+    faces[1, F // 2:, :, 2] = 0.05                      # ... or closer than near = 0.1
+    textures = rng.uniform(0, 1, (B, F, 2, 2, 2, 3)).astype(np.float32)
+    bg = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    fn = oracle_forward(faces, textures, S, 0.1, 100, eps, bg, True, True, True)
+    assert (fn.face_index_map[0] == -1).all() and (fn.face_index_map[1] == -1).all() and (fn.face_index_map[2] >= 0).any()
+    fw = abi.forward(faces, textures, S, 0.1, 100.0, eps, bg, 0, True, True, True)
+    check_forward(fw, fn)
+    g_rgb, g_alpha, g_depth = grads_for(fn, rng)
+    ref_gf, ref_gt = fn.backward(g_rgb, g_alpha, g_depth, accumulate_double=True)
+    for run in (abi.backward, abi.backward_fused):
+        gf, gt = run(fw, g_rgb, g_alpha, g_depth)
+        gf, gt = abi.host(gf), abi.host(gt)
+        assert np.all(gf[:2] == 0) and np.all(gt[:2] == 0)      # nothing visible: exact zeros, no NaN
+        assert H.rel_err(gf, ref_gf) <= 1e-5 and H.rel_err(gt, ref_gt) <= RTOL
+
+
 def test_fused_forward_equals_stage_calls():
     """nr_forward_rasterize == nr_forward_face_index_map + nr_forward_texture_sampling, bit for bit."""
     faces, _ = H.teapot_views(3, 100)
