@@ -62,7 +62,9 @@ __device__ __forceinline__ bool eval_pixel(const FaceGeo &q, float xp, float yp,
     // :330 -- double reciprocal of a float rounded to float == correctly rounded float division
     zp = 1.0f / (w0 / q.z0 + w1 / q.z1 + w2 / q.z2);
     if ((double)zp <= near_d || far_d <= (double)zp) return false;  // :331
-    return true;
+    // :334 `zp < depth_min` with depth_min starting at (float)far: implied by :331 for ordinary numbers, but a NaN zp (NaN /
+    // Inf vertices, zero depth) passes :331 and must never win a pixel
+    return zp < (float)far_d;
 }
 
 // pixel centre (2. * i + 1 - is) / is (rasterize.py:291-292, evaluated in double there).  Both operands are

@@ -454,6 +454,37 @@ def test_culled_images_and_per_batch_background():
         assert H.rel_err(gf, ref_gf) <= 1e-5 and H.rel_err(gt, ref_gt) <= RTOL
 
 
+def test_nan_inf_and_zero_depth_vertices_like_the_reference():
+    """NaN / Inf coordinates, astronomically large ones and a zero depth: a face whose depth comes out NaN passes the
+    near / far test (rasterize.py:331) but can never win a pixel (`zp < depth_min`, :334); maps must agree bit for bit with the
+    oracle (NaN == NaN) and the gradients must be NaN in exactly the same places.  No hang, no fault."""
+    rng = np.random.default_rng(5)
+    B, F, S, eps = 2, 40, 48, 1e-3
+    faces = H.random_scene(rng, B, F, spread=0.5, size=0.3)
+    faces[0, 3, 1, 0] = np.nan
+    faces[0, 7, 2, 1] = np.inf
+    faces[0, 9, 0, 2] = np.nan
+    faces[1, 2, :, :2] *= 1e20
+    faces[1, 5, 0, 0] = -np.inf
+    faces[1, 11, 1, 2] = 0.0
+    textures = rng.uniform(0, 1, (B, F, 2, 2, 2, 3)).astype(np.float32)
+    fn = oracle_forward(faces, textures, S, 0.1, 100, eps, (0.1, 0.2, 0.3), True, True, True)
+    fw = abi.forward(faces, textures, S, 0.1, 100.0, eps, (0.1, 0.2, 0.3), 0, True, True, True)
+    assert int((abi.host(fw['face_index_map']) != fn.face_index_map).sum()) == 0
+    for k in ('weight_map', 'depth_map', 'rgb_map', 'alpha_map'):
+        assert np.array_equal(abi.host(fw[k]), getattr(fn, k), equal_nan=True), k
+    g_rgb, g_alpha, g_depth = grads_for(fn, rng)
+    ref_gf, ref_gt = fn.backward(g_rgb, g_alpha, g_depth, accumulate_double=True)
+    for run in (abi.backward, abi.backward_fused):
+        gf, gt = run(fw, g_rgb, g_alpha, g_depth)
+        gf, gt = abi.host(gf), abi.host(gt)
+        assert np.array_equal(np.isnan(gf), np.isnan(ref_gf)) and np.array_equal(np.isnan(gt), np.isnan(ref_gt))
+        ok = np.isfinite(ref_gf)
+        assert H.rel_err(gf[ok], ref_gf[ok]) <= 1e-5
+        ok = np.isfinite(ref_gt)
+        assert H.rel_err(gt[ok], ref_gt[ok]) <= RTOL
+
+
 def test_fused_forward_equals_stage_calls():
     """nr_forward_rasterize == nr_forward_face_index_map + nr_forward_texture_sampling, bit for bit."""
     faces, _ = H.teapot_views(3, 100)
