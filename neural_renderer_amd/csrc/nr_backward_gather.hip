@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                         acc[3 * pn + 1] += t.w[pn] * g[1];
                         acc[3 * pn + 2] += t.w[pn] * g[2];
                     } else {
+                        if (t.isc[pn] * 3 >= n_tex) continue;  // outside the cube: weight 0 (compute_taps)
                         double *q = acc_l + t.isc[pn] * 3;
                         atomicAdd(q + 0, (double)(t.w[pn] * g[0]));
                         atomicAdd(q + 1, (double)(t.w[pn] * g[1]));
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_atomic(
     float *gt = grad_textures + ((size_t)b * F + fi) * ts * ts * ts * 3;
 #pragma unroll
     for (int pn = 0; pn < 8; pn++) {
+        if (t.isc[pn] >= ts * ts * ts) continue;  // outside the cube: weight 0 (compute_taps)
         float *p = gt + t.isc[pn] * 3;
         atomicAdd(p + 0, t.w[pn] * g[0]);  // :780
         atomicAdd(p + 1, t.w[pn] * g[1]);
@@ -323,14 +325,17 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     const size_t n_tex = (size_t)ts * ts * ts * 3;
     if (ts > 13) vis_list = nullptr;  // the atomic fallback walks pixels, not faces
     if (ts > 8 || sampling_weight_map || !grad_faces) g_depth = nullptr;  // K8 is fused only into the one-wave-per-group gathers
-    if (ts == 2 && !(eps > 0.0)) g_depth = nullptr;
+    // static taps (TS2 path): valid when the clamp of rasterize.py:402 keeps every index float below 1, i.e. when
+    // (ts - 1) - eps still rounds below ts - 1 in float32 (eps > 2^-25); otherwise a coordinate can be exactly 1.0
+    const bool ts2_static = ts == 2 && (float)(1.0 - eps) < 1.0f;
+    if (ts == 2 && !ts2_static) g_depth = nullptr;
     if (g_depth && depth_done) *depth_done = 1;
     if (vis_list) {
         // only visible faces are visited: everything else is zero
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    if (ts == 2 && eps > 0.0 && !sampling_weight_map) {
+    if (ts2_static && !sampling_weight_map) {
         const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
         if (g_depth)
             hipLaunchKernelGGL((k_backward_textures_face<true, true>), grid, dim3(256), 0, st, face_index_map,

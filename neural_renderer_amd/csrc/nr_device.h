@@ -113,6 +113,10 @@ struct Taps {
     float w[8];
 };
 
+// The eight trilinear taps of a pixel (rasterize.py:398-421).  When an index float reaches ts - 1 exactly (eps too small to
+// survive the float32 rounding of :402, or eps = 0) the "upper" corner of that dimension has index ts and weight exactly 0;
+// its flattened index can then leave the face's cube (isc >= ts^3).  The reference multiplies whatever lies there by 0 /
+// adds 0 to it; consumers here skip such taps instead of touching memory outside the cube.
 __device__ __forceinline__ void compute_taps(const float *__restrict__ face, const float *__restrict__ weight,
                                              float depth, int ts, double eps, Taps &t)
 {

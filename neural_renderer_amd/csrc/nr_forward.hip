@@ -188,6 +188,7 @@ __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, f
         rgb[0] = rgb[1] = rgb[2] = 0.0f;
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {
+            if (t.isc[pn] >= ts * ts * ts) continue;  // outside the cube: weight 0 (see compute_taps), never dereferenced
             const float *tx = texture + t.isc[pn] * 3;
             rgb[0] += t.w[pn] * tx[0];
             rgb[1] += t.w[pn] * tx[1];

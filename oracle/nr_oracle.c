@@ -213,7 +213,10 @@ API void oracle_forward_texture_sampling(const float *faces, const float *textur
                     }
                 }
                 int isc = texture_index_int[0] * ts * ts + texture_index_int[1] * ts + texture_index_int[2];
-                for (int k = 0; k < 3; k++) new_pixel[k] += w * texture[isc * 3 + k];
+                /* isc >= ts^3: an index float hit ts - 1 exactly (eps lost in the float rounding of :402); the reference then
+                 * reads past the cube with weight 0 -- not dereferenced here */
+                if (isc < ts * ts * ts)
+                    for (int k = 0; k < 3; k++) new_pixel[k] += w * texture[isc * 3 + k];
                 if (sampling_index_map) sampling_index_map[i * 8 + pn] = isc;
                 if (sampling_weight_map) sampling_weight_map[i * 8 + pn] = w;
             }
@@ -438,6 +441,7 @@ API void oracle_backward_textures(const int32_t *face_index_map, const float *sa
             for (int pn = 0; pn < 8; pn++) {
                 const float w = sampling_weight_map[i * 8 + pn];
                 const int isc = sampling_index_map[i * 8 + pn];
+                if (isc >= ts * ts * ts) continue; /* a zero-weight tap outside the cube (see K4): the reference adds 0 there */
                 for (int k = 0; k < 3; k++) {
                     const float term = w * grad_rgb_map[i * 3 + k]; /* :780 */
                     if (acc_d) acc_d[toff + isc * 3 + k] += (double)term; else grad_texture[isc * 3 + k] += term;

@@ -1,0 +1,65 @@
+"""Fuzz parity (GPU): random small scenes with unusual parameters -- raster sizes 1..64 (odd, tiny), near / far / eps values
+far from the defaults (eps = 0 and eps below float32 resolution included), faces behind the camera, vertices snapped onto
+pixel centres (ties, edges through centres), duplicated faces, per-image backgrounds, the batch-z flag -- through the C ABI
+against the oracle: forward maps bit for bit (NaN == NaN), gradients NaN in the same places and within tolerance elsewhere,
+staged and fused backward."""
+import numpy as np
+import pytest
+
+import abi
+import helpers as H
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_fuzz_unusual_parameters(seed):
+    rng = np.random.default_rng(seed)
+    failures = []
+    for it in range(60):
+        B = int(rng.integers(1, 4))
+        F = int(rng.integers(1, 50))
+        S = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 32, 47, 64]))
+        ts = int(rng.choice([2, 2, 3, 4]))
+        eps = float(rng.choice([0.0, 1e-10, 1e-4, 1e-3, 0.1, 1.0]))
+        near = float(rng.choice([1e-6, 0.1, 0.5, 1.7]))
+        far = float(rng.choice([2.0, 10.1, 100, 1e10]))
+        faces = H.random_scene(rng, B, F, spread=float(rng.choice([0.3, 0.8, 1.5])), size=float(rng.choice([0.05, 0.3, 1.2])),
+                               zmin=float(rng.choice([-1.0, 0.05, 1.0])), zmax=3.0)
+        if rng.uniform() < 0.5:   # snap some vertices onto pixel centres
+            q = (np.round((faces[..., :2] * S + S - 1) / 2) * 2 + 1 - S) / S
+            m = rng.uniform(size=faces[..., :2].shape) < 0.5
+            faces[..., :2] = np.where(m, q, faces[..., :2]).astype(np.float32)
+        if rng.uniform() < 0.3 and F > 1:   # reversed duplicates of the first half
+            faces[:, F // 2:] = faces[:, : F - F // 2][:, :, ::-1]
+        textures = rng.uniform(0, 1, (B, F, ts, ts, ts, 3)).astype(np.float32)
+        bg = rng.uniform(0, 1, (B, 3)).astype(np.float32) if rng.uniform() < 0.5 else (0.2, 0.4, 0.6)
+        flags = int(rng.integers(0, 2))
+        fn = O.Rasterize(S, near, far, eps, bg, True, True, True, bool(flags))
+        fn(faces, textures)
+        fw = abi.forward(faces, textures, S, near, far, eps, bg, flags, True, True, True)
+        msg = []
+        if int((abi.host(fw['face_index_map']) != fn.face_index_map).sum()):
+            msg.append('face_index_map')
+        for k in ('weight_map', 'depth_map', 'rgb_map', 'alpha_map'):
+            if not np.array_equal(abi.host(fw[k]), getattr(fn, k), equal_nan=True):
+                msg.append(k)
+        g = [rng.normal(size=x.shape).astype(np.float32) for x in (fn.rgb_map, fn.alpha_map, fn.depth_map)]
+        if rng.uniform() < 0.3:
+            g[0][rng.uniform(size=g[0].shape) < 0.5] = 0
+        ref_gf, ref_gt = fn.backward(*g, accumulate_double=True)
+        for run in (abi.backward, abi.backward_fused):
+            gf, gt = run(fw, *g)
+            gf, gt = abi.host(gf), abi.host(gt)
+            if not np.array_equal(np.isnan(gf), np.isnan(ref_gf)) or not np.array_equal(np.isnan(gt), np.isnan(ref_gt)):
+                msg.append(run.__name__ + ': NaN pattern')
+            ok = np.isfinite(ref_gf) & np.isfinite(gf)
+            if ok.any() and H.rel_err(gf[ok], ref_gf[ok]) > 2e-5:
+                msg.append('%s: grad_faces %.2e' % (run.__name__, H.rel_err(gf[ok], ref_gf[ok])))
+            ok = np.isfinite(ref_gt) & np.isfinite(gt)
+            if ok.any() and H.rel_err(gt[ok], ref_gt[ok]) > 1e-4:
+                msg.append('%s: grad_textures %.2e' % (run.__name__, H.rel_err(gt[ok], ref_gt[ok])))
+        if msg:
+            failures.append((it, dict(B=B, F=F, S=S, ts=ts, eps=eps, near=near, far=far, flags=flags), msg))
+    assert not failures, failures

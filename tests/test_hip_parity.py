@@ -406,10 +406,10 @@ def test_fused_backward_equals_stage_calls(modes):
         np.testing.assert_array_equal(abi.host(gt_a), abi.host(gt_b))
 
 
-@pytest.mark.parametrize('ts,eps', [(2, 0.0), (5, 1e-3), (6, 1e-3), (9, 1e-3), (13, 1e-4), (14, 1e-3), (16, 1e-3)])
+@pytest.mark.parametrize('ts,eps', [(2, 0.0), (2, 1e-10), (5, 1e-3), (6, 1e-3), (9, 1e-3), (13, 1e-4), (14, 1e-3), (16, 1e-3)])
 def test_texture_size_paths(ts, eps):
-    """K4 / K7 over every dispatch class of the texture gradient: texture_size 2 with eps = 0 (the static-tap fast path
-    needs eps > 0, so this takes the general one), 3-5 (16 lanes per face), 6-8 (64), 9-13 (256), >= 14 (per-pixel scatter
+    """K4 / K7 over every dispatch class of the texture gradient: texture_size 2 with eps = 0 or below float32 resolution (an index float can then reach 1.0 exactly, so the static-tap fast
+    path must not be taken and the zero-weight taps outside the cube must not be touched), 3-5 (16 lanes per face), 6-8 (64), 9-13 (256), >= 14 (per-pixel scatter
     with hardware float atomics, the reference's own formulation) -- staged and fused backward against the oracle."""
     rng = np.random.default_rng(100 + ts)
     B, F, S = 2, 48, 64
