@@ -63,3 +63,43 @@ def test_fuzz_unusual_parameters(seed):
         if msg:
             failures.append((it, dict(B=B, F=F, S=S, ts=ts, eps=eps, near=near, far=far, flags=flags), msg))
     assert not failures, failures
+
+
+@pytest.mark.parametrize('seed', [11, 12])
+def test_fuzz_dense_scenes(seed):
+    """Larger random scenes (up to 3000 faces, raster sizes up to 256 incl. non-powers of two, random output modes): several
+    scan passes and line windows per band, accumulator-slot overflow, the large-face queue of the forward."""
+    rng = np.random.default_rng(seed)
+    failures = []
+    for it in range(8):
+        B = int(rng.integers(1, 3))
+        F = int(rng.choice([200, 700, 1500, 3000]))
+        S = int(rng.choice([64, 100, 128, 200, 256]))
+        ts = int(rng.choice([2, 3]))
+        eps = float(rng.choice([1e-4, 1e-3]))
+        modes = [(True, True, True), (True, False, False), (False, True, False), (True, True, False)][int(rng.integers(0, 4))]
+        faces = H.random_scene(rng, B, F, spread=float(rng.choice([0.4, 0.9])), size=float(rng.choice([0.03, 0.1, 0.4])))
+        textures = rng.uniform(0, 1, (B, F, ts, ts, ts, 3)).astype(np.float32)
+        rgb, alpha, depth = modes
+        fn = O.Rasterize(S, 0.1, 100, eps, (0.2, 0.4, 0.6), rgb, alpha, depth)
+        fn(faces, textures) if rgb else fn(faces)
+        fw = abi.forward(faces, textures if rgb else None, S, 0.1, 100.0, eps, (0.2, 0.4, 0.6), 0, rgb, alpha, depth)
+        msg = []
+        if int((abi.host(fw['face_index_map']) != fn.face_index_map).sum()):
+            msg.append('face_index_map')
+        g_rgb = rng.normal(size=(B, S, S, 3)).astype(np.float32) if rgb else None
+        g_alpha = rng.normal(size=(B, S, S)).astype(np.float32) if alpha else None
+        g_depth = rng.normal(size=(B, S, S)).astype(np.float32) if depth else None
+        ref = fn.backward(g_rgb, g_alpha, g_depth, accumulate_double=True)
+        for run in (abi.backward, abi.backward_fused):
+            gf, gt = run(fw, g_rgb, g_alpha, g_depth)
+            e = H.rel_err(abi.host(gf), ref[0])
+            if not e <= 1e-5:
+                msg.append('%s: grad_faces %.2e' % (run.__name__, e))
+            if rgb:
+                e = H.rel_err(abi.host(gt), ref[1])
+                if not e <= 1e-4:
+                    msg.append('%s: grad_textures %.2e' % (run.__name__, e))
+        if msg:
+            failures.append((it, dict(B=B, F=F, S=S, ts=ts, eps=eps, modes=modes), msg))
+    assert not failures, failures
