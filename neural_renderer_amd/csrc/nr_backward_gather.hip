@@ -21,6 +21,8 @@ using namespace nr;
 
 namespace {
 
+constexpr int BIG_PX = 256;  // candidate sets above this size (and all strips) are walked by k_backward_big
+
 __device__ __forceinline__ float group_sum(float v, int width)
 {
     for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -71,8 +73,8 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     if (face_ok) {
         const int b = gi / F, fn = gi - b * F;
         const float *f = faces + (size_t)gi * 9;
-        const BBox bb = face_bbox(f[0], f[1], f[3], f[4], f[6], f[7], S);
-        if (bb.x_lo <= bb.x_hi) {
+        const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+        if (cd.n > 0 && (L == 256 || (!cd.strip && cd.n <= BIG_PX))) {  // the rest is k_backward_big's
             any_box = true;
             float inv[9], fv[9];
             if (DEPTH) {
@@ -85,13 +87,12 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
             }
             // z of the three vertices as the forward sampled them: batch 0's geometry unless fixed (:389, Q1)
             const float *fz = faces + ((size_t)(fix_batch_z ? b : 0) * F + fn) * 9;
-            const float face_z[9] = {0, 0, fz[2], 0, 0, fz[5], 0, 0, fz[8]};
-            const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
-            const int n_px = bw * bh;
+            const float face_z[3] = {fz[2], fz[5], fz[8]};
             const size_t img = (size_t)b * S * S;
-            for (int i = sub; i < n_px; i += L) {
-                const int yy = i / bw;
-                const size_t p = img + (size_t)(bb.y_lo + yy) * S + (bb.x_lo + (i - yy * bw));
+            for (int i = sub; i < cd.n; i += L) {
+                int x, y;
+                if (!cand_pixel(cd, i, S, x, y)) continue;
+                const size_t p = img + (size_t)y * S + x;
                 // every operand of the pixel is requested before the ownership test: one memory round trip per
                 // box pixel instead of two dependent ones (the kernel is bound by that latency, not by bandwidth)
                 const int fi_p = face_index_map[p];
@@ -183,6 +184,160 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 }
 
 // --------------------------------------------------------------------------------------------------
+// Faces with many candidate pixels (a ground plane, a backdrop, the strip of a needle) would keep one 16-lane group of
+// the kernels above busy for thousands of iterations while the rest of the chip idles.  Those kernels therefore leave
+// every face whose candidate set is a strip or exceeds BIG_PX pixels untouched (zeros stored / nothing added), and this
+// kernel, launched right after them, gives each such face a whole workgroup: one thread per face finds the big ones of a
+// 256-face range, then all 256 lanes walk each of them in turn (coalesced rows), texel sums in LDS doubles, depth sums
+// through a wave + LDS reduction.  With no big face in the range the workgroup exits after ~150 instructions.
+// TEX: 0 no textures, 1 grad_textures through per-face LDS double accumulators (any texture_size <= 8), 2 texture_size 2 with
+// static taps (24 register sums per lane, as in the TS2 gather); DEPTH: the K8 terms.
+template <int TEX, bool DEPTH>
+__global__ __launch_bounds__(256) void k_backward_big(
+    const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
+    const int32_t *__restrict__ sampling_index_map, const float *__restrict__ face_inv_map, const float *__restrict__ faces,
+    const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
+    float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z,
+    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
+    float *__restrict__ grad_faces)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_tex[];  // [ts^3 * 3] texel sums of the face being walked
+    __shared__ int s_list[256];
+    __shared__ int s_n;
+    __shared__ float s_red[33];  // 9 depth sums + 24 texel sums (TEX == 2)
+    const int tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    {   // one face per thread: is its candidate set this kernel's business?
+        int gi = blockIdx.x * 256 + tid;
+        bool ok = gi < n_faces_total;
+        if (vis_list) {
+            ok = gi < vis_count[blockIdx.y];
+            gi = ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + gi] : 0;
+        }
+        if (ok) {
+            const float *f = faces + (size_t)gi * 9;
+            const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+            if (cd.n > 0 && (cd.strip || cd.n > BIG_PX)) s_list[atomicAdd(&s_n, 1)] = gi;
+        }
+    }
+    __syncthreads();
+    const int n_big = s_n;
+    const int n_tex = TEX ? ts * ts * ts * 3 : 0;
+    const int n_lds = TEX == 1 ? n_tex : 0;
+    for (int q = 0; q < n_big; ++q) {
+        const int gi = s_list[q];
+        const int b = gi / F, fn = gi - b * F;
+        const float *fp = faces + (size_t)gi * 9;
+        float f[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = fp[k];
+        const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+        float inv[9];
+        if (DEPTH) {
+            const float fs = (float)S;
+            const float px[3] = {to_pixel(f[0], fs), to_pixel(f[3], fs), to_pixel(f[6], fs)};
+            const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
+            compute_face_inv(px, py, inv);
+        }
+        const float *fz = faces + ((size_t)(fix_batch_z ? b : 0) * F + fn) * 9;  // :389, Q1
+        const float face_z[3] = {fz[2], fz[5], fz[8]};
+        for (int k = tid; k < n_lds; k += 256) s_tex[k] = 0.0;
+        if (tid < 33) s_red[tid] = 0.0f;
+        __syncthreads();
+        float dacc[9], tacc[24];
+#pragma unroll
+        for (int k = 0; k < 9; k++) dacc[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 24; k++) tacc[k] = 0.0f;
+        const size_t img = (size_t)b * S * S;
+        for (int i = tid; i < cd.n; i += 256) {
+            int x, y;
+            if (!cand_pixel(cd, i, S, x, y)) continue;
+            const size_t p = img + (size_t)y * S + x;
+            if (face_index_map[p] != fn) continue;
+            float wk[3] = {0.0f, 0.0f, 0.0f}, depth = 0.0f;
+            if (weight_map) { wk[0] = weight_map[3 * p]; wk[1] = weight_map[3 * p + 1]; wk[2] = weight_map[3 * p + 2]; }
+            if (depth_map) depth = depth_map[p];
+            if (TEX) {
+                Taps t;
+                if (sampling_weight_map) {
+#pragma unroll
+                    for (int pn = 0; pn < 8; pn++) {
+                        t.w[pn] = sampling_weight_map[8 * p + pn];
+                        t.isc[pn] = sampling_index_map[8 * p + pn];
+                    }
+                } else {
+                    compute_taps(face_z, wk, depth, ts, eps, t);
+                }
+                const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
+#pragma unroll
+                for (int pn = 0; pn < 8; pn++) {
+                    if (TEX == 2) {
+                        tacc[3 * pn + 0] += t.w[pn] * g[0];  // :780
+                        tacc[3 * pn + 1] += t.w[pn] * g[1];
+                        tacc[3 * pn + 2] += t.w[pn] * g[2];
+                    } else {
+                        if (t.isc[pn] * 3 >= n_tex) continue;  // outside the cube: weight 0 (compute_taps)
+                        double *a = s_tex + t.isc[pn] * 3;
+                        atomicAdd(a + 0, (double)(t.w[pn] * g[0]));
+                        atomicAdd(a + 1, (double)(t.w[pn] * g[1]));
+                        atomicAdd(a + 2, (double)(t.w[pn] * g[2]));
+                    }
+                }
+            }
+            if (DEPTH) {  // rasterize.py:824-837, as in k_backward_depth_face
+                const float gd = g_depth[p];
+                float iv[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) iv[k] = face_inv_map ? face_inv_map[9 * p + k] : inv[k];
+                const float depth2 = depth * depth;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float z_k = f[3 * k + 2];
+                    dacc[3 * k + 2] += gd * wk[k] * depth2 / (z_k * z_k);
+                }
+                float tmp[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int l = 0; l < 3; l++) tmp[k] += -iv[3 * l + k] / f[3 * l + 2];
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+#pragma unroll
+                    for (int l = 0; l < 2; l++) dacc[3 * k + l] += -gd * tmp[l] * wk[k] * depth2 * (float)S / 2.0f;
+            }
+        }
+        if (DEPTH) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const float v = group_sum(dacc[k], 64);
+                if ((tid & 63) == 0 && v != 0.0f) atomicAdd(&s_red[k], v);
+            }
+        }
+        if (TEX == 2) {
+#pragma unroll
+            for (int k = 0; k < 24; k++) {
+                const float v = group_sum(tacc[k], 64);
+                if ((tid & 63) == 0 && v != 0.0f) atomicAdd(&s_red[9 + k], v);
+            }
+        }
+        __syncthreads();
+        if (TEX == 1) {
+            float *dst = grad_textures + (size_t)gi * n_tex;
+            for (int k = tid; k < n_tex; k += 256) dst[k] = (float)s_tex[k];
+        }
+        if (TEX == 2 && tid < 24) {  // corner pn = tid / 3 -> texel (pn & 1) * 4 + ((pn >> 1) & 1) * 2 + ((pn >> 2) & 1)
+            const int pn = tid / 3, c = tid - 3 * pn;
+            const int isc = (pn & 1) * 4 + ((pn >> 1) & 1) * 2 + ((pn >> 2) & 1);
+            grad_textures[(size_t)gi * 24 + 3 * isc + c] = s_red[9 + tid];
+        }
+        if (DEPTH && tid < 9) grad_faces[(size_t)gi * 9 + tid] += s_red[tid];
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // B2 (fallback, texture_size > 13): per-pixel scatter with hardware f32 atomics (-munsafe-fp-atomics =>
 // global_atomic_add_f32), the reference's own formulation (rasterize.py:750-792).  The caller's
 // zero fill is replaced by a hipMemsetAsync in the entry point.
@@ -207,7 +362,8 @@ __global__ __launch_bounds__(256) void k_backward_textures_atomic(
     } else {
         const float *face = faces + ((size_t)(fix_batch_z ? b : 0) * F + fi) * 9;
         const float w[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
-        compute_taps(face, w, depth_map[i], ts, eps, t);
+        const float fz[3] = {face[2], face[5], face[8]};
+        compute_taps(fz, w, depth_map[i], ts, eps, t);
     }
     const float g[3] = {g_rgb[3 * i], g_rgb[3 * i + 1], g_rgb[3 * i + 2]};
     float *gt = grad_textures + ((size_t)b * F + fi) * ts * ts * ts * 3;
@@ -252,20 +408,19 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
         float f[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = fp[k];
-        const BBox bb = face_bbox(f[0], f[1], f[3], f[4], f[6], f[7], S);
-        if (bb.x_lo <= bb.x_hi) {
+        const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+        if (cd.n > 0 && !cd.strip && cd.n <= BIG_PX) {  // the rest is k_backward_big's
             any_box = true;
             float inv[9];
             const float fs = (float)S;
             const float px[3] = {to_pixel(f[0], fs), to_pixel(f[3], fs), to_pixel(f[6], fs)};
             const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
             compute_face_inv(px, py, inv);
-            const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
-            const int n_px = bw * bh;
             const size_t img = (size_t)b * S * S;
-            for (int i = sub; i < n_px; i += L) {
-                const int yy = i / bw;
-                const size_t p = img + (size_t)(bb.y_lo + yy) * S + (bb.x_lo + (i - yy * bw));
+            for (int i = sub; i < cd.n; i += L) {
+                int x, y;
+                if (!cand_pixel(cd, i, S, x, y)) continue;
+                const size_t p = img + (size_t)y * S + x;
                 const int fi_p = face_index_map[p];  // operands requested before the ownership test (see K7)
                 const float depth = depth_map[p];
                 const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
@@ -358,7 +513,22 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
             hipLaunchKernelGGL((k_backward_textures_face<false, false>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, nullptr, nullptr);
-    } else {
+    }
+    if (ts <= 8) {
+        // faces the gathers above left out (strips, more than BIG_PX candidates): a workgroup each
+        const dim3 grid = vis_list ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
+        const bool st2 = ts2_static && !sampling_weight_map;
+        const size_t lds = st2 ? 0 : n_tex * sizeof(double);
+#define NR_BIG(T, D)                                                                                                    \
+    hipLaunchKernelGGL((k_backward_big<T, D>), grid, dim3(256), lds, st, face_index_map, sampling_weight_map,          \
+                       sampling_index_map, (const float *)nullptr, faces, weight_map, depth_map, grad_rgb_map,        \
+                       grad_textures, n, F, S, ts, eps, fix, vis_list, vis_count, D ? g_depth : (const float *)nullptr, \
+                       D ? grad_faces : (float *)nullptr)
+        if (st2) { if (g_depth) NR_BIG(2, true); else NR_BIG(2, false); }
+        else { if (g_depth) NR_BIG(1, true); else NR_BIG(1, false); }
+#undef NR_BIG
+    }
+    if (ts > 13) {
         // huge cubes: the reference's per-pixel scatter with hardware atomics
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
@@ -381,6 +551,10 @@ int nr::run_backward_depth_map(const float *faces, const float *depth_map, const
     const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
     hipLaunchKernelGGL(k_backward_depth_face, grid, dim3(256), 0, st, faces, depth_map, face_index_map, face_inv_map,
                        weight_map, grad_depth_map, grad_faces, n, F, S, vis_list, vis_count);
+    const dim3 grid_big = vis_list ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL((k_backward_big<0, true>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
+                       (const int32_t *)nullptr, face_inv_map, faces, weight_map, depth_map, (const float *)nullptr,
+                       (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces);
     return launch_status();
 }
 

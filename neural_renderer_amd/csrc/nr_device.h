@@ -64,46 +64,91 @@ __device__ __forceinline__ float bcast_f(float v, int src)
 
 
 // --------------------------------------------------------------------------------------------------
-// Screen-space bounding box of a face in pixel units (4 x int16: x_lo, x_hi, y_lo, y_hi), shared by the
-// forward tile rasterizer and the face-centric backward kernels (they MUST agree: a pixel the forward
-// could give to a face has to be inside the box the backward scans).
-// An empty box (x_lo > x_hi) marks faces that can never own a pixel: back faces (rasterize.py:306),
-// off-screen faces, faces whose three vertices coincide (their barycentric weights are NaN for every
-// pixel, so `zp < depth_min` never holds, :322-334).  Degenerate faces (zero / non-finite determinant but
-// distinct vertices) keep the full image: the reference's inside test can accept pixels anywhere on their
-// supporting line.  Regular faces get the exact pixel range of the triangle plus a guard band of
-// BBOX_GUARD pixels: the inside test runs on rounded NDC floats, whose rounding moves an edge by
-// ~1e-6 pixel, so 0.25 pixel is conservative for anything but needles thinner than ~1e-5 pixel.
-struct __attribute__((aligned(8))) BBox {
-    short x_lo, x_hi, y_lo, y_hi;
+// Candidate pixels of a face: the only pixels the forward needs to test and the backward gathers need to scan (they MUST
+// agree: a pixel the forward could give to a face has to be among the candidates the backward visits).
+//   * none: back faces (rasterize.py:306), off-screen faces, faces whose three vertices coincide (their barycentric weights
+//     are NaN for every pixel, so `zp < depth_min` never holds, :322-334);
+//   * a BOX: the exact pixel range of the triangle plus a guard band of BBOX_GUARD pixels -- the inside test (:310-312) runs
+//     on rounded NDC floats, whose rounding moves an edge by ~1e-6 pixel, so 0.25 pixel is conservative;
+//   * a STRIP along the longest edge for needles and degenerate (collinear) faces.  The inside test compares rounded
+//     products of NDC differences; its rounding error is a relative 2^-22 or so of |p - a| * |b - a|, i.e. every edge line is
+//     accepted within an ANGLE of ~5e-7 rad at any distance.  Beyond a vertex whose interior angle is below twice that, the
+//     wedges of the two adjacent edges overlap and the reference accepts pixels far outside the triangle, along its axis
+//     (found by fuzzing: micro-triangles of a few ulps through pixel centres).  Faces that thin -- 2 * area <= 2^-18 *
+//     (longest edge)^2 in NDC, the coordinates the test works with -- lie within 4e-6 of their longest edge's line, and so does
+//     everything the test can accept: the candidates are the STRIP_W pixels around that line in every row (or column);
+//   * the whole image when nothing better can be said (non-finite or astronomically large coordinates).
+struct Cand {
+    int x_lo, y_lo, bw;  // box: origin and width
+    int n;               // number of candidates, 0 = none
+    int strip;           // 0 box, 1 strip stepping through rows (x = a * y + b), 2 strip stepping through columns
+    float a, b;
 };
 constexpr float BBOX_GUARD = 0.25f;
+constexpr int STRIP_W = 4;  // floor(line) - 1 .. floor(line) + 2
 
-__device__ __forceinline__ BBox face_bbox(float x0, float y0, float x1, float y1, float x2, float y2, int S)
+__device__ __forceinline__ Cand face_candidates(float x0, float y0, float x1, float y1, float x2, float y2, int S)
 {
-    BBox bb;
-    bb.x_lo = 1; bb.x_hi = 0; bb.y_lo = 1; bb.y_hi = 0;
-    if (is_backside(x0, y0, x1, y1, x2, y2)) return bb;
-    if ((x0 == x1) && (x1 == x2) && (y0 == y1) && (y1 == y2)) return bb;
+    Cand c;
+    c.x_lo = c.y_lo = 0; c.bw = 1; c.n = 0; c.strip = 0; c.a = c.b = 0.0f;
+    if (is_backside(x0, y0, x1, y1, x2, y2)) return c;
+    if ((x0 == x1) && (x1 == x2) && (y0 == y1) && (y1 == y2)) return c;
     const float fs = (float)S;
     const float px[3] = {to_pixel(x0, fs), to_pixel(x1, fs), to_pixel(x2, fs)};
     const float py[3] = {to_pixel(y0, fs), to_pixel(y1, fs), to_pixel(y2, fs)};
     const float den = px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]);
-    if (!(fabsf(den) > 0.0f) || !(fabsf(den) < __builtin_inff())) {
-        bb.x_lo = 0; bb.x_hi = (short)(S - 1); bb.y_lo = 0; bb.y_hi = (short)(S - 1);
-        return bb;
+    const float e0x = x1 - x0, e0y = y1 - y0, e1x = x2 - x1, e1y = y2 - y1, e2x = x0 - x2, e2y = y0 - y2;
+    const float area2 = fabsf(e0x * e1y - e0y * e1x);
+    const float l0 = e0x * e0x + e0y * e0y, l1 = e1x * e1x + e1y * e1y, l2 = e2x * e2x + e2y * e2y;
+    const float len2 = fmaxf(fmaxf(l0, l1), l2);
+    const bool thin = !(area2 > 0x1p-18f * len2) || !(fabsf(den) > 0.0f);
+    const float big = 1.0e6f;  // pixel coordinates beyond this make the strip arithmetic meaningless
+    const bool wild = !(len2 < __builtin_inff()) || !(fabsf(den) < __builtin_inff()) ||
+                      !(fmaxf(fmaxf(fabsf(px[0]), fabsf(px[1])), fabsf(px[2])) < big) ||
+                      !(fmaxf(fmaxf(fabsf(py[0]), fabsf(py[1])), fabsf(py[2])) < big);
+    if (thin && !wild) {
+        // the longest edge: its direction from the NDC differences (exact for close vertices -- in pixel units a
+        // micro-triangle's edge would be a few ulps of noise), its position from one endpoint in pixel units
+        const int k = (l0 >= l1 && l0 >= l2) ? 0 : (l1 >= l2 ? 1 : 2);
+        const float ax = px[k], ay = py[k];
+        const float dx = k == 0 ? e0x : (k == 1 ? e1x : e2x), dy = k == 0 ? e0y : (k == 1 ? e1y : e2y);
+        if (fabsf(dy) >= fabsf(dx) && dy != 0.0f) {
+            c.strip = 1; c.a = dx / dy; c.b = ax - c.a * ay;
+        } else if (dx != 0.0f) {
+            c.strip = 2; c.a = dy / dx; c.b = ay - c.a * ax;
+        }
+        if (c.strip) { c.n = S * STRIP_W; return c; }
+    }
+    if (thin || wild) {  // the whole image
+        c.bw = S; c.n = S * S;
+        return c;
     }
     const float xmin = fminf(fminf(px[0], px[1]), px[2]), xmax = fmaxf(fmaxf(px[0], px[1]), px[2]);
     const float ymin = fminf(fminf(py[0], py[1]), py[2]), ymax = fmaxf(fmaxf(py[0], py[1]), py[2]);
-    const float lo_c = -2.0f, hi_c = (float)S + 1.0f;  // clamp before the int conversion (huge / NaN coordinates)
+    const float lo_c = -2.0f, hi_c = (float)S + 1.0f;  // clamp before the int conversion
     const int xl = max((int)ceilf(fminf(fmaxf(xmin - BBOX_GUARD, lo_c), hi_c)), 0);
     const int xh = min((int)floorf(fminf(fmaxf(xmax + BBOX_GUARD, lo_c), hi_c)), S - 1);
     const int yl = max((int)ceilf(fminf(fmaxf(ymin - BBOX_GUARD, lo_c), hi_c)), 0);
     const int yh = min((int)floorf(fminf(fmaxf(ymax + BBOX_GUARD, lo_c), hi_c)), S - 1);
     if (xl <= xh && yl <= yh) {
-        bb.x_lo = (short)xl; bb.x_hi = (short)xh; bb.y_lo = (short)yl; bb.y_hi = (short)yh;
+        c.x_lo = xl; c.y_lo = yl; c.bw = xh - xl + 1; c.n = c.bw * (yh - yl + 1);
     }
-    return bb;
+    return c;
+}
+
+// i-th candidate -> pixel (x, y); false when it falls outside the image (strips only)
+__device__ __forceinline__ bool cand_pixel(const Cand &c, int i, int S, int &x, int &y)
+{
+    if (c.strip == 0) {
+        const int yy = i / c.bw;
+        x = c.x_lo + (i - yy * c.bw);
+        y = c.y_lo + yy;
+        return true;
+    }
+    const int m = i / STRIP_W, j = i - m * STRIP_W;
+    const int o = (int)floorf(c.a * (float)m + c.b) - 1 + j;
+    if (c.strip == 1) { y = m; x = o; } else { x = m; y = o; }
+    return o >= 0 && o < S;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -117,7 +162,8 @@ struct Taps {
 // survive the float32 rounding of :402, or eps = 0) the "upper" corner of that dimension has index ts and weight exactly 0;
 // its flattened index can then leave the face's cube (isc >= ts^3).  The reference multiplies whatever lies there by 0 /
 // adds 0 to it; consumers here skip such taps instead of touching memory outside the cube.
-__device__ __forceinline__ void compute_taps(const float *__restrict__ face, const float *__restrict__ weight,
+// z: the face's three vertex depths
+__device__ __forceinline__ void compute_taps(const float *__restrict__ z, const float *__restrict__ weight,
                                              float depth, int ts, double eps, Taps &t)
 {
     float tif[3];
@@ -125,7 +171,7 @@ __device__ __forceinline__ void compute_taps(const float *__restrict__ face, con
     float fr[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float v = weight[k] * (float)(ts - 1) * (depth / face[3 * k + 2]);  // :400
+        float v = weight[k] * (float)(ts - 1) * (depth / z[k]);  // :400
         v = fmaxf(v, 0.0f);                                                 // :401
         v = (float)fmin((double)v, (double)(ts - 1) - eps);                 // :402 (double min, then rounded)
         tif[k] = v;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     const float *f = faces + (size_t)i * 9;
     FaceGeo g;
     g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
-    const BBox bb = face_bbox(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
+    const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
     float inv[9];
     if (is_backside(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2)) {
 #pragma unroll
@@ -118,9 +118,8 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = inv[k];
     }
-    if (bb.x_lo > bb.x_hi) return;
-    const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
-    if (bw * bh > SMALL_AREA) {
+    if (cd.n == 0) return;
+    if (cd.strip || cd.n > SMALL_AREA) {  // strips (needles) and large boxes: a whole workgroup each, k_large_raster
         if (sub == 0) large_list[atomicAdd(n_large, 1)] = i;
         return;
     }
@@ -131,10 +130,11 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     unsigned long long *zimg = zbuf + (size_t)b * S * S;
     const bool pow2 = (S & (S - 1)) == 0;
     const float inv_s = 1.0f / (float)S;
-    for (int py = bb.y_lo + sub; py <= bb.y_hi; py += LPF) {
+    const int x_hi = cd.x_lo + cd.bw - 1, y_hi = cd.y_lo + cd.n / cd.bw - 1;
+    for (int py = cd.y_lo + sub; py <= y_hi; py += LPF) {
         const float yp = pixel_center_p(py, S, inv_s, pow2);
         unsigned long long *zrow = zimg + (size_t)py * S;
-        for (int px = bb.x_lo; px <= bb.x_hi; ++px)
+        for (int px = cd.x_lo; px <= x_hi; ++px)
             raster_pixel(g, fnu, px, py, pixel_center_p(px, S, inv_s, pow2), yp, near_d, far_d, zrow);
     }
 }
@@ -153,15 +153,14 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
         FaceGeo g;
         g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
         g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5]; g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
-        const BBox bb = face_bbox(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
-        const int bw = bb.x_hi - bb.x_lo + 1, bh = bb.y_hi - bb.y_lo + 1;
+        const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
         const int b = i / F;
         const unsigned fnu = (unsigned)(i - b * F);
         unsigned long long *zimg = zbuf + (size_t)b * S * S;
-        for (int k = threadIdx.x; k < bw * bh; k += blockDim.x) {
-            const int yy = k / bw, xx = k - yy * bw;
-            raster_pixel(g, fnu, bb.x_lo + xx, bb.y_lo + yy, pixel_center_f(bb.x_lo + xx, S), pixel_center_f(bb.y_lo + yy, S),
-                         near_d, far_d, zimg + (size_t)(bb.y_lo + yy) * S);
+        for (int k = threadIdx.x; k < cd.n; k += blockDim.x) {
+            int x, y;
+            if (!cand_pixel(cd, k, S, x, y)) continue;
+            raster_pixel(g, fnu, x, y, pixel_center_f(x, S), pixel_center_f(y, S), near_d, far_d, zimg + (size_t)y * S);
         }
     }
 }
@@ -184,7 +183,8 @@ __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, f
         const float *face = faces + ((size_t)(fix_batch_z ? b : 0) * F + fi) * 9;  // :389 (Q1)
         const float *texture = textures + ((size_t)b * F + fi) * ts * ts * ts * 3;   // :390
         const float w[3] = {w0, w1, w2};
-        compute_taps(face, w, depth, ts, eps, t);
+        const float fz[3] = {face[2], face[5], face[8]};
+        compute_taps(fz, w, depth, ts, eps, t);
         rgb[0] = rgb[1] = rgb[2] = 0.0f;
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {

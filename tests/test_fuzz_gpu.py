@@ -103,3 +103,52 @@ def test_fuzz_dense_scenes(seed):
         if msg:
             failures.append((it, dict(B=B, F=F, S=S, ts=ts, eps=eps, modes=modes), msg))
     assert not failures, failures
+
+
+def _coverage_mismatches(faces, S):
+    fn = O.Rasterize(S, 0.1, 100, 1e-3, (0, 0, 0), False, True, True)
+    fn(faces)
+    fw = abi.forward(faces, None, S, 0.1, 100.0, 1e-3, (0, 0, 0), 0, False, True, True)
+    same_depth = np.array_equal(abi.host(fw['depth_map']), fn.depth_map, equal_nan=True)
+    return int((abi.host(fw['face_index_map']) != fn.face_index_map).sum()) + (0 if same_depth else 1)
+
+
+@pytest.mark.parametrize('seed', [21, 22])
+def test_fuzz_micro_triangles_and_needles(seed):
+    """Coverage parity where the reference's rounded inside test (rasterize.py:310-312) is least intuitive: triangles of a
+    few ulps to 0.1 NDC around pixel centres, a vertex exactly on a centre, edges through a centre, collinear triples, and
+    needles whose apex angle is 3e-9 .. 1e-3 rad aimed exactly at another pixel centre (the test accepts pixels far along a
+    needle's axis; faces that thin are exempt from screen-box culling, face_bbox)."""
+    rng = np.random.default_rng(seed)
+    bad = []
+    for it in range(40):
+        S = int(rng.choice([8, 16, 32, 33, 64]))
+        F = 256
+        kind = rng.integers(0, 4, F)
+        c = (2 * rng.integers(0, S, (F, 1, 2)) + 1 - S) / S
+        base = rng.normal(size=(F, 3, 2)) * 10.0 ** rng.uniform(-9, -1, (F, 1, 1))
+        base[kind == 1, 2] = (rng.normal(size=(F, 2)) * 10.0 ** rng.uniform(-3, 0.5, (F, 1)))[kind == 1]   # long third vertex
+        base[kind == 2, 0] = 0                                   # a vertex exactly on the pixel centre
+        base[kind == 3, 1] = -base[kind == 3, 0]                 # an edge through the centre
+        faces = np.zeros((1, F, 3, 3), np.float32)
+        faces[0, :, :, :2] = (c + base).astype(np.float32)
+        faces[..., 2] = rng.uniform(1, 3, (1, F, 3)).astype(np.float32)
+        if _coverage_mismatches(faces, S):
+            bad.append(('micro', it, S))
+        # needles: apex A near a pixel centre, axis through another centre, apex angle theta
+        i0, i1 = rng.integers(0, S, (F, 2)), rng.integers(0, S, (F, 2))
+        c0, c1 = (2 * i0 + 1 - S) / S, (2 * i1 + 1 - S) / S
+        u = c1 - c0
+        n = np.linalg.norm(u, axis=1, keepdims=True)
+        u = u / np.where(n == 0, 1, n)
+        th = 10.0 ** rng.uniform(-8.5, -3, F) * rng.choice([-1, 1], F)
+        t1, t2 = 10.0 ** rng.uniform(-7, -0.5, (F, 1)), 10.0 ** rng.uniform(-7, -0.5, (F, 1))
+        rot = np.stack((u[:, 0] * np.cos(th) - u[:, 1] * np.sin(th), u[:, 0] * np.sin(th) + u[:, 1] * np.cos(th)), axis=1)
+        A = c0 + rng.normal(size=(F, 2)) * 10.0 ** rng.uniform(-9, -6, (F, 1)) * (rng.uniform(size=(F, 1)) < 0.5)
+        faces[0, :, 0, :2], faces[0, :, 1, :2], faces[0, :, 2, :2] = A, A - u * t1, A - rot * t2
+        f = faces[0]
+        back = ((f[:, 2, 1] - f[:, 0, 1]) * (f[:, 1, 0] - f[:, 0, 0]) < (f[:, 1, 1] - f[:, 0, 1]) * (f[:, 2, 0] - f[:, 0, 0]))
+        f[back] = f[back][:, ::-1]
+        if _coverage_mismatches(faces, S):
+            bad.append(('needle', it, S))
+    assert not bad, bad

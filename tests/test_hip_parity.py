@@ -225,6 +225,28 @@ def test_big_triangles_long_sweeps():
     check_backward(faces, textures, 256, 1e-3, (True, True, False), seed=12)
 
 
+@pytest.mark.parametrize('ts,eps', [(2, 1e-3), (2, 1e-10), (3, 1e-3), (6, 1e-3), (9, 1e-3)])
+def test_big_faces_every_gather_path(ts, eps):
+    """Screen-filling faces mixed with small ones: their texture / depth gradients come from k_backward_big (a workgroup per
+    face) in its three texture modes (static taps, LDS accumulators, none) and from the one-face-per-workgroup gather for
+    texture_size >= 9; staged and fused backward, all three outputs."""
+    rng = np.random.default_rng(200 + ts)
+    big = H.random_scene(rng, 2, 6, spread=0.3, size=0.9)
+    small = H.random_scene(rng, 2, 60, spread=0.6, size=0.08)
+    faces = np.concatenate((small[:, :30], big, small[:, 30:]), axis=1)
+    textures = rng.uniform(0, 1, (2, faces.shape[1], ts, ts, ts, 3)).astype(np.float32)
+    S = 128
+    fn = oracle_forward(faces, textures, S, 0.1, 100, eps, (0.3, 0.1, 0.2), True, True, True)
+    fw = abi.forward(faces, textures, S, 0.1, 100.0, eps, (0.3, 0.1, 0.2), 0, True, True, True)
+    check_forward(fw, fn)
+    g_rgb, g_alpha, g_depth = grads_for(fn, rng)
+    ref_gf, ref_gt = fn.backward(g_rgb, g_alpha, g_depth, accumulate_double=True)
+    for run in (abi.backward, abi.backward_fused):
+        gf, gt = run(fw, g_rgb, g_alpha, g_depth)
+        assert H.rel_err(abi.host(gt), ref_gt) <= RTOL, run.__name__
+        assert H.rel_err(abi.host(gf), ref_gf) <= 1e-5, run.__name__
+
+
 def test_known_answer_gradients_through_renderer():
     """The reference's grad_ref constants (tests/test_rasterize_silhouettes.py:37-99) through the full
     PyTorch-facing API: Renderer -> look_at -> vertices_to_faces -> HIP rasterizer -> autograd."""
