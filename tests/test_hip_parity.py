@@ -247,6 +247,16 @@ def test_big_faces_every_gather_path(ts, eps):
         assert H.rel_err(abi.host(gf), ref_gf) <= 1e-5, run.__name__
 
 
+@pytest.mark.parametrize('S', [384, 512, 768, 1024])
+def test_band_width_classes(S):
+    """Raster sizes whose K6 bands are 2 lines (512, 384: the anti-aliased default of Renderer) or 1 line (768, 1024) wide,
+    powers of two and not: every staging / band-width path of k_bpm_band against the oracle."""
+    rng = np.random.default_rng(300 + S)
+    faces = H.random_scene(rng, 1, 400, spread=0.7, size=0.15)
+    textures = rng.uniform(0, 1, (1, 400, 2, 2, 2, 3)).astype(np.float32)
+    check_backward(faces, textures, S, 1e-3, (True, True, True), seed=301 + S)
+
+
 def test_known_answer_gradients_through_renderer():
     """The reference's grad_ref constants (tests/test_rasterize_silhouettes.py:37-99) through the full
     PyTorch-facing API: Renderer -> look_at -> vertices_to_faces -> HIP rasterizer -> autograd."""
