@@ -21,7 +21,7 @@ using namespace nr;
 
 namespace {
 
-constexpr int BIG_PX = 256;  // candidate sets above this size (and all strips) are walked by k_backward_big
+constexpr int BIG_PX = 2048;  // candidate sets above this size are walked by k_backward_big (A/B on config 4: 256 cost 0.25 ms)
 
 __device__ __forceinline__ float group_sum(float v, int width)
 {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         const int b = gi / F, fn = gi - b * F;
         const float *f = faces + (size_t)gi * 9;
         const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-        if (cd.n > 0 && (L == 256 || (!cd.strip && cd.n <= BIG_PX))) {  // the rest is k_backward_big's
+        if (cd.n > 0 && (L == 256 || (cd.n <= BIG_PX))) {  // the rest is k_backward_big's
             any_box = true;
             float inv[9], fv[9];
             if (DEPTH) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 // --------------------------------------------------------------------------------------------------
 // Faces with many candidate pixels (a ground plane, a backdrop, the strip of a needle) would keep one 16-lane group of
 // the kernels above busy for thousands of iterations while the rest of the chip idles.  Those kernels therefore leave
-// every face whose candidate set is a strip or exceeds BIG_PX pixels untouched (zeros stored / nothing added), and this
+// every face whose candidate set exceeds BIG_PX pixels untouched (zeros stored / nothing added), and this
 // kernel, launched right after them, gives each such face a whole workgroup: one thread per face finds the big ones of a
 // 256-face range, then all 256 lanes walk each of them in turn (coalesced rows), texel sums in LDS doubles, depth sums
 // through a wave + LDS reduction.  With no big face in the range the workgroup exits after ~150 instructions.
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
         if (ok) {
             const float *f = faces + (size_t)gi * 9;
             const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-            if (cd.n > 0 && (cd.strip || cd.n > BIG_PX)) s_list[atomicAdd(&s_n, 1)] = gi;
+            if (cd.n > BIG_PX) s_list[atomicAdd(&s_n, 1)] = gi;
         }
     }
     __syncthreads();
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = fp[k];
         const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-        if (cd.n > 0 && !cd.strip && cd.n <= BIG_PX) {  // the rest is k_backward_big's
+        if (cd.n > 0 && cd.n <= BIG_PX) {  // the rest is k_backward_big's
             any_box = true;
             float inv[9];
             const float fs = (float)S;
@@ -515,7 +515,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, nullptr, nullptr);
     }
     if (ts <= 8) {
-        // faces the gathers above left out (strips, more than BIG_PX candidates): a workgroup each
+        // faces the gathers above left out (more than BIG_PX candidates): a workgroup each
         const dim3 grid = vis_list ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
         const bool st2 = ts2_static && !sampling_weight_map;
         const size_t lds = st2 ? 0 : n_tex * sizeof(double);
