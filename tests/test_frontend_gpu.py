@@ -174,3 +174,63 @@ def test_image_epilogue_bit_exact(aa, S):
     up = np.repeat(np.repeat(g, 2, axis=-2), 2, axis=-1) * np.float32(0.25) if aa else g
     np.testing.assert_array_equal(tr.grad.cpu().numpy(), np.ascontiguousarray(up[:, :, ::-1, :].transpose((0, 2, 3, 1))))
     assert td.grad is None
+
+
+@pytest.mark.parametrize('seed', [1, 2])
+def test_fuzz_frontend_against_torch_chain(seed):
+    """Random cameras, lights and meshes: the fused front-end against the module-by-module torch path, outputs and gradients."""
+    from neural_renderer_amd import frontend
+    import neural_renderer_amd as nr
+    rng = np.random.default_rng(seed)
+    for it in range(12):
+        B, Nv, Nf = int(rng.integers(1, 4)), int(rng.integers(3, 40)), int(rng.integers(1, 60))
+        ts = int(rng.choice([2, 3, 4]))
+        vb = rng.normal(scale=0.5, size=(B, Nv, 3)).astype(np.float32)
+        # three distinct vertices per face: with a repeated vertex the normal is cross(v, v), exactly 0 here and in NumPy but
+        # a rounding residual in torch.cross (fused multiply-add), which chainer-style normalisation (|n| + 1e-5) then turns
+        # into a 1e-4 difference of the light colour -- of a face that has no area and is never drawn
+        fb = np.stack([rng.permutation(Nv)[:3] for _ in range(B * Nf)]).reshape(B, Nf, 3).astype(np.int32)
+        tex = rng.uniform(0, 1, (B, Nf, ts, ts, ts, 3)).astype(np.float32)
+        per_batch_eye = bool(rng.integers(0, 2))
+        eye_np = (rng.normal(size=(B, 3)) * 0.5 + np.array([0, 0, -2.5])).astype(np.float32)
+        if not per_batch_eye:
+            eye_np = eye_np[0]
+
+        def make(requires=True):
+            r = nr.Renderer()
+            r.camera_mode = ['look_at', 'look'][int(rng.integers(0, 2))]
+            r.perspective = bool(rng.integers(0, 2))
+            r.fill_back = bool(rng.integers(0, 2))
+            r.viewing_angle = float(rng.choice([10, 30, 45.5]))
+            r.camera_direction = (rng.normal(size=3) + np.array([0, 0, 2.0])).tolist()
+            r.light_direction = rng.normal(size=3).tolist()
+            r.light_color_ambient = rng.uniform(0, 1, 3).tolist()
+            r.light_color_directional = rng.uniform(0, 1, 3).tolist()
+            r.light_intensity_ambient = float(rng.choice([0.0, 0.3, 1.0]))
+            r.light_intensity_directional = float(rng.choice([0.0, 0.5]))
+            return r
+        state = rng.bit_generator.state
+        results = []
+        for fused in (True, False):
+            rng.bit_generator.state = state          # identical renderer settings for both paths
+            r = make()
+            v = torch.tensor(vb, device='cuda', requires_grad=True)
+            t = torch.tensor(tex, device='cuda', requires_grad=True)
+            e = torch.tensor(eye_np, device='cuda', requires_grad=True)
+            r.eye = e
+            f = torch.tensor(fb, device='cuda')
+            assert frontend.fusable(r, v, f, t)
+            faces, lit = frontend.project_and_light(r, v, f, t) if fused else r._frontend_torch(v, f, t)
+            gen = torch.Generator('cuda').manual_seed(100 + it)
+            gf = torch.randn(faces.shape, device='cuda', generator=gen)
+            gl = torch.randn(lit.shape, device='cuda', generator=gen)
+            torch.autograd.backward([faces, lit], [gf, gl])
+            results.append([x.detach().cpu().numpy() for x in (faces, lit, v.grad, t.grad, e.grad)])
+        a, b = results
+        ok = np.isfinite(b[0])
+        np.testing.assert_allclose(a[0][ok], b[0][ok], rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-6, atol=1e-7)
+        for k in (2, 3, 4):
+            fin = np.isfinite(b[k]) & np.isfinite(a[k])
+            assert fin.mean() > 0.9
+            assert H.rel_err(a[k][fin], b[k][fin]) <= 2e-4, (it, k, H.rel_err(a[k][fin], b[k][fin]))
