@@ -184,3 +184,51 @@ def test_hip_texture_atlas_bit_exact(tmp_path, nf, ts):
         # and back in through the loader
         v2, f2, t2 = nr.load_obj(str(tmp_path / 'a.obj'), normalization=False, texture_size=ts, load_texture=True)
         assert np.array_equal(f2, f) and t2.shape == tex.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [1, 2])
+def test_fuzz_texture_baking_and_atlas(seed, tmp_path):
+    """Random OBJ / MTL / PNG sets (uv inside, on the border of, and outside [0,1]; polygons; materials with and without
+    images; image sizes down to 1 pixel) through the loader, and random texture cubes through the atlas writer: HIP == oracle."""
+    from PIL import Image
+    import neural_renderer_amd as nr
+    from neural_renderer_amd.save_obj import create_texture_image
+    rng = np.random.default_rng(seed)
+    for it in range(6):
+        d = tmp_path / ('m%d' % it)
+        d.mkdir()
+        n_mat = int(rng.integers(1, 4))
+        with open(str(d / 'm.mtl'), 'w') as fh:
+            for m in range(n_mat):
+                fh.write('newmtl mat%d\nKd %.4f %.4f %.4f\n' % ((m,) + tuple(rng.uniform(0, 1, 3))))
+                if rng.uniform() < 0.7:
+                    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+                    Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(str(d / ('t%d.png' % m)))
+                    fh.write('map_Kd t%d.png\n' % m)
+        nv, nt = int(rng.integers(4, 12)), int(rng.integers(3, 12))
+        with open(str(d / 'm.obj'), 'w') as fh:
+            fh.write('mtllib m.mtl\n')
+            for p in rng.normal(size=(nv, 3)):
+                fh.write('v %.6f %.6f %.6f\n' % tuple(p))
+            for _ in range(nt):
+                uv = rng.choice([0.0, 1.0, rng.uniform(0, 1), rng.uniform(-0.5, 2.5)], 2)
+                fh.write('vt %.6f %.6f\n' % tuple(uv))
+            for _ in range(int(rng.integers(3, 15))):
+                if rng.uniform() < 0.4:
+                    fh.write('usemtl mat%d\n' % rng.integers(0, n_mat))
+                k = int(rng.integers(3, 6))
+                with_uv = rng.uniform() < 0.8
+                fh.write('f ' + ' '.join(('%d/%d' % (rng.integers(1, nv + 1), rng.integers(1, nt + 1))) if with_uv
+                                          else str(rng.integers(1, nv + 1)) for _ in range(k)) + '\n')
+        ts = int(rng.choice([2, 3, 4, 7]))
+        v, f, t = nr.load_obj(str(d / 'm.obj'), load_texture=True, texture_size=ts)
+        v0, f0, t0 = O.load_obj(str(d / 'm.obj'), load_texture=True, texture_size=ts)
+        assert np.array_equal(v, v0) and np.array_equal(f, f0)
+        np.testing.assert_array_equal(t, t0)
+        tex = rng.uniform(0, 1, (int(rng.integers(1, 70)), ts, ts, ts, 3)).astype(np.float32)
+        tso = int(rng.choice([4, 16]))
+        image, uv = create_texture_image(tex, tso)
+        image0, uv0 = O.create_texture_image(tex, tso)
+        np.testing.assert_array_equal(np.ascontiguousarray(image), np.ascontiguousarray(image0))
+        np.testing.assert_array_equal(uv, uv0)
