@@ -27,7 +27,8 @@
  *   - plain device pointers (hipMalloc / torch caching allocator memory), C-contiguous, float32 / int32;
  *     sizes are int32; near / far / eps are doubles because the reference pastes their Python repr into
  *     the kernel source as double literals (rasterize.py:226-234, 428-433, 737-743).
- *   - the library owns no memory and keeps no global mutable state: outputs, residuals and scratch
+ *   - the library owns no memory and keeps no state between calls (it reads no environment variable; the one thing it
+ *     remembers is which dynamic-LDS limit the driver already granted to a kernel): outputs, residuals and scratch
  *     ("workspace", size from nr_*_workspace_bytes) all belong to the caller.
  *   - every launch goes to `stream` (a hipStream_t passed as void*; NULL = the null stream), is
  *     asynchronous, and never synchronises the device.  Functions are re-entrant and thread-safe.
@@ -51,26 +52,48 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 110 /* 0.1.1 */
+#define NR_VERSION 200 /* 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
 
 /* argument errors */
 #define NR_E_NULL (-1)      /* a required pointer is NULL */
 #define NR_E_SIZE (-2)      /* a size is out of range (B,F,S < 1, S > 16384, ts < 2, index overflow) */
 #define NR_E_WORKSPACE (-3) /* workspace missing or too small */
 #define NR_E_MODE (-4)      /* nothing to do / inconsistent optional arguments */
+#define NR_E_NEAR (-5)      /* near <= 0: the z-buffer packs positive depths (reference default 0.1; the reference itself accepts
+                               any near, rasterize.py:331 -- rescale the scene or pass a small positive near) */
+#define NR_E_INDEX (-6)     /* a vertex index outside [0, num_vertices) */
 
-/* flags for nr_forward_texture_sampling / nr_backward_textures */
-#define NR_FLAG_FIX_TEXTURE_BATCH_Z 1 /* read the face's z from the pixel's own batch element instead of
-                                         batch 0 (the reference reads batch 0: rasterize.py:389) */
+/* flags */
+#define NR_FLAG_FIX_TEXTURE_BATCH_Z 1 /* texture sampling (K4 / K7): read the face's z from the pixel's own batch element
+                                         instead of batch 0 (the reference reads batch 0: rasterize.py:389) */
+#define NR_FLAG_EXACT_GRADIENT 2      /* K6: every per-pixel term with the reference's arithmetic (IEEE division, the double
+                                         `dist +- eps`), <= 2e-6 against the exactly summed reference terms, ~1.7x the time.
+                                         Default (flag clear): float terms through v_rcp_f32, <= 1e-5 (tolerance 1e-4). */
+#define NR_FLAG_K6_GLOBAL 4           /* K6: force the global-memory kernel that otherwise only serves rasters whose band
+                                         does not fit in LDS (a testing aid) */
+
+/*
+ * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):
+ * the reference samples textures with the vertex depths of BATCH ELEMENT 0 (`&faces[face_index * 9]`, rasterize.py:389,
+ * SURVEY Q1).  NULL = batch element 0 of `faces`, i.e. the reference's behaviour for a call that holds the whole
+ * batch.  A caller that holds only a SHARD of the batch (views [start, stop) on one GPU) passes the [F,3,3] faces of
+ * the GLOBAL batch element 0 here (device memory; neural_renderer_amd.distributed.broadcast_reference_faces), so that
+ * sharded and unsharded runs give identical bits.  Ignored when NR_FLAG_FIX_TEXTURE_BATCH_Z is set.
+ *
+ * visible_faces (uint8 [B,F], optional everywhere): 1 for every face that owns at least one pixel of its image.  The
+ * forward writes every element when the pointer is given; the K6 pipeline starts from it (it otherwise rebuilds the flags
+ * with one more pass over face_index_map).  It is a residual like face_index_map: pass back what the forward produced.
+ */
 
 int nr_version(void);
 const char *nr_error_string(int code);
 
-/* Scratch needed by nr_forward_face_index_map: per-face inverse matrices (the reference's `faces_inv`,
- * rasterize.py:240) plus per-face screen-space bounding boxes. */
+/* Scratch needed by the forward: the packed 64-bit z-buffer (depth bits << 32 | face index, one word per pixel) and the
+ * queue of faces with large screen boxes.  The reference's `faces_inv` scratch (rasterize.py:240) is not materialised. */
 size_t nr_forward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_t image_size);
 
-/* Scratch needed by nr_backward_pixel_map (transposed copies of the maps for the vertical sweeps). */
+/* Scratch needed by nr_backward_pixel_map / nr_backward_rasterize: per image the sorted list of visible faces, their edge
+ * line ranges, face -> list position, and six double sums per listed face (+ the flags when visible_faces is not passed). */
 size_t nr_backward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_t image_size,
                                    int32_t return_rgb, int32_t return_alpha);
 
@@ -78,11 +101,13 @@ size_t nr_backward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_
  * Visibility (K1+K2, rasterize.py:240-359; tie rule "min depth, then lowest face index").
  * Writes EVERY element of face_index_map (-1 where empty), weight_map (0), depth_map (far) and, when
  * non-NULL, face_inv_map (0) -- the caller need not pre-fill them (the reference does, :478-496).
- * weight_map, depth_map and face_inv_map may each be NULL when the caller does not need them.
+ * weight_map, depth_map, face_inv_map and visible_faces may each be NULL when the caller does not need them.
+ * near must be > 0 (NR_E_NEAR): depths are packed as unsigned integers, which orders positive floats only.
  */
 int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map,
-                              float *face_inv_map, int32_t batch_size, int32_t num_faces, int32_t image_size,
-                              double near, double far, void *workspace, size_t workspace_bytes, void *stream);
+                              float *face_inv_map, uint8_t *visible_faces, int32_t batch_size, int32_t num_faces,
+                              int32_t image_size, double near, double far, void *workspace, size_t workspace_bytes,
+                              void *stream);
 
 /*
  * Shading (K4 + K5, rasterize.py:361-465): trilinear sampling of the winning face's texture cube,
@@ -91,23 +116,25 @@ int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float
  * background: 3 floats, or batch_size*3 floats when bg_per_batch != 0 (device memory).
  * sampling_index_map / sampling_weight_map: optional residuals of the reference (:394-395); zero where empty.
  */
-int nr_forward_texture_sampling(const float *faces, const float *textures, const int32_t *face_index_map,
-                                const float *weight_map, const float *depth_map, float *rgb_map,
-                                int32_t *sampling_index_map, float *sampling_weight_map, const float *background,
-                                int32_t bg_per_batch, float *alpha_map, int32_t batch_size, int32_t num_faces,
-                                int32_t image_size, int32_t texture_size, double eps, int32_t flags, void *stream);
+int nr_forward_texture_sampling(const float *faces, const float *faces_z_ref, const float *textures,
+                                const int32_t *face_index_map, const float *weight_map, const float *depth_map,
+                                float *rgb_map, int32_t *sampling_index_map, float *sampling_weight_map,
+                                const float *background, int32_t bg_per_batch, float *alpha_map, int32_t batch_size,
+                                int32_t num_faces, int32_t image_size, int32_t texture_size, double eps, int32_t flags,
+                                void *stream);
 
 /*
  * Approximate gradient of rgb / alpha w.r.t. vertex x, y (K6, rasterize.py:517-748).
  * STORES every element of grad_faces [B,F,3,3] (z components and back faces = 0), like the reference
  * (:736 after the zero fill of :851).  rgb_map must be the post-background map.
  * return_rgb / return_alpha select the terms; the matching map and gradient pointers must be non-NULL.
+ * flags: NR_FLAG_EXACT_GRADIENT, NR_FLAG_K6_GLOBAL; visible_faces: the forward's flags or NULL.
  */
 int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                           const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                           float *grad_faces, int32_t batch_size, int32_t num_faces, int32_t image_size, double eps,
-                          int32_t return_rgb, int32_t return_alpha, void *workspace, size_t workspace_bytes,
-                          void *stream);
+                          int32_t return_rgb, int32_t return_alpha, int32_t flags, const uint8_t *visible_faces,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Texture gradient (K7, rasterize.py:750-792): the sum of w * grad_rgb over the 8 taps of every pixel a
@@ -118,8 +145,8 @@ int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, con
  * residuals).
  */
 int nr_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
-                         const int32_t *sampling_index_map, const float *faces, const float *weight_map,
-                         const float *depth_map, const float *grad_rgb_map, float *grad_textures,
+                         const int32_t *sampling_index_map, const float *faces, const float *faces_z_ref,
+                         const float *weight_map, const float *depth_map, const float *grad_rgb_map, float *grad_textures,
                          int32_t batch_size, int32_t num_faces, int32_t image_size, int32_t texture_size, double eps,
                          int32_t flags, void *stream);
 
@@ -137,11 +164,11 @@ int nr_backward_depth_map(const float *faces, const float *depth_map, const int3
  * nr_forward_texture_sampling, identical results, one resolve pass (the winner is shaded while still in
  * registers).  rgb_map / alpha_map / weight_map / depth_map are each optional (NULL = not requested).
  */
-int nr_forward_rasterize(const float *faces, const float *textures, int32_t *face_index_map, float *weight_map,
-                         float *depth_map, float *rgb_map, float *alpha_map, const float *background,
-                         int32_t bg_per_batch, int32_t batch_size, int32_t num_faces, int32_t image_size,
-                         int32_t texture_size, double near, double far, double eps, int32_t flags, void *workspace,
-                         size_t workspace_bytes, void *stream);
+int nr_forward_rasterize(const float *faces, const float *faces_z_ref, const float *textures, int32_t *face_index_map,
+                         float *weight_map, float *depth_map, float *rgb_map, float *alpha_map, uint8_t *visible_faces,
+                         const float *background, int32_t bg_per_batch, int32_t batch_size, int32_t num_faces,
+                         int32_t image_size, int32_t texture_size, double near, double far, double eps, int32_t flags,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Fused backward = Rasterize.backward_gpu (rasterize.py:849-889): K6, then K7, then K8, identical results to the
@@ -152,18 +179,19 @@ int nr_forward_rasterize(const float *faces, const float *textures, int32_t *fac
  * when grad_rgb_map or grad_depth_map is given, rgb_map / alpha_map for their gradients; workspace as for
  * nr_backward_pixel_map.
  */
-int nr_backward_rasterize(const float *faces, const int32_t *face_index_map, const float *weight_map,
-                          const float *depth_map, const float *rgb_map, const float *alpha_map,
+int nr_backward_rasterize(const float *faces, const float *faces_z_ref, const int32_t *face_index_map,
+                          const float *weight_map, const float *depth_map, const float *rgb_map, const float *alpha_map,
                           const float *grad_rgb_map, const float *grad_alpha_map, const float *grad_depth_map,
                           float *grad_faces, float *grad_textures, int32_t batch_size, int32_t num_faces,
-                          int32_t image_size, int32_t texture_size, double eps, int32_t flags, void *workspace,
-                          size_t workspace_bytes, void *stream);
+                          int32_t image_size, int32_t texture_size, double eps, int32_t flags,
+                          const uint8_t *visible_faces, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * vertices_to_faces (reference neural_renderer/vertices_to_faces.py:4-21): faces_out[b,f,k,:] = vertices[b, faces_idx[.,f,k], :]
  * and its backward (Chainer's get_item backward = scatter-add): grad_vertices[b, faces_idx[.,f,k], :] += grad_faces[b,f,k,:]
  * with hardware float atomics; grad_vertices [B,Nv,3] is zero-filled by the call.  faces_idx is [B,Nf,3] int32 when
- * idx_per_batch != 0, else one [Nf,3] topology shared by the batch.  Indices must lie in [0, Nv).
+ * idx_per_batch != 0, else one [Nf,3] topology shared by the batch.  Indices must lie in [0, Nv): the Python binding checks
+ * that (IndexError, like the reference's get_item); the kernels clamp, so a bad index never leaves the buffers.
  */
 int nr_vertices_to_faces(const float *vertices, const int32_t *faces_idx, float *faces_out, int32_t batch_size,
                          int32_t num_vertices, int32_t num_faces, int32_t idx_per_batch, void *stream);

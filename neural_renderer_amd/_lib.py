@@ -30,18 +30,15 @@ SIGNATURES = {
     'nr_error_string': (_c.c_char_p, [_c.c_int]),
     'nr_forward_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'nr_backward_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
-    'nr_forward_face_index_map': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f64, _f64, _vp, _sz, _vp]),
-    'nr_forward_texture_sampling': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32,
-                                               _i32, _i32, _f64, _i32, _vp]),
-    'nr_backward_pixel_map': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f64, _i32, _i32, _vp,
-                                         _sz, _vp]),
-    'nr_backward_textures': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _i32,
-                                        _vp]),
+    'nr_forward_face_index_map': (_c.c_int, [_vp] * 6 + [_i32, _i32, _i32, _f64, _f64, _vp, _sz, _vp]),
+    'nr_forward_texture_sampling': (_c.c_int, [_vp] * 10 + [_i32, _vp, _i32, _i32, _i32, _i32, _f64, _i32, _vp]),
+    'nr_backward_pixel_map': (_c.c_int, [_vp] * 7 + [_i32, _i32, _i32, _f64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    'nr_backward_textures': (_c.c_int, [_vp] * 9 + [_i32, _i32, _i32, _i32, _f64, _i32, _vp]),
     'nr_backward_depth_map': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    'nr_forward_rasterize': (_c.c_int, [_vp] * 8 + [_i32] * 5 + [_f64] * 3 + [_i32, _vp, _sz, _vp]),
+    'nr_forward_rasterize': (_c.c_int, [_vp] * 10 + [_i32] * 5 + [_f64] * 3 + [_i32, _vp, _sz, _vp]),
     'nr_vertices_to_faces': (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'nr_vertices_to_faces_backward': (_c.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    'nr_backward_rasterize': (_c.c_int, [_vp] * 11 + [_i32] * 4 + [_f64, _i32, _vp, _sz, _vp]),
+    'nr_backward_rasterize': (_c.c_int, [_vp] * 12 + [_i32] * 4 + [_f64, _i32, _vp, _vp, _sz, _vp]),
     'nr_image_epilogue': (_c.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
     'nr_image_epilogue_backward': (_c.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
     'nr_load_textures': (_c.c_int, [_vp] * 4 + [_i32] * 4 + [_vp]),
@@ -53,6 +50,10 @@ SIGNATURES = {
 }
 
 NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
+NR_FLAG_EXACT_GRADIENT = 2
+NR_FLAG_K6_GLOBAL = 4
+NR_E_NEAR = -5
+NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1
 NR_CAMERA_LOOK = 2
 
@@ -84,7 +85,12 @@ def load():
 def check(code, what):
     if code != 0:
         msg = load().nr_error_string(code)
-        raise NRError('%s failed (%d): %s' % (what, code, msg.decode() if msg else '?'))
+        text = '%s failed (%d): %s' % (what, code, msg.decode() if msg else '?')
+        if code == NR_E_NEAR:
+            raise ValueError(text)
+        if code == NR_E_INDEX:
+            raise IndexError(text)
+        raise NRError(text)
 
 
 def ptr(t):

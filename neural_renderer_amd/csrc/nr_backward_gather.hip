@@ -39,8 +39,9 @@ template <bool TS2, bool DEPTH>
 __global__ __launch_bounds__(256) void k_backward_textures_face(
     const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
     const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
-    const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
-    float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z, int L,
+    const float *__restrict__ zbase, const float *__restrict__ weight_map, const float *__restrict__ depth_map,
+    const float *__restrict__ g_rgb, float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts,
+    double eps, int fix_batch_z, int L,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
     float *__restrict__ grad_faces)
 {
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                 const float py[3] = {to_pixel(fv[1], fs), to_pixel(fv[4], fs), to_pixel(fv[7], fs)};
                 compute_face_inv(px, py, inv);
             }
-            // z of the three vertices as the forward sampled them: batch 0's geometry unless fixed (:389, Q1)
-            const float *fz = faces + ((size_t)(fix_batch_z ? b : 0) * F + fn) * 9;
+            // z of the three vertices as the forward sampled them: batch 0's geometry (zbase) unless fixed (:389, Q1)
+            const float *fz = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fn * 9;
             const float face_z[3] = {fz[2], fz[5], fz[8]};
             const size_t img = (size_t)b * S * S;
             for (int i = sub; i < cd.n; i += L) {
@@ -196,7 +197,7 @@ template <int TEX, bool DEPTH>
 __global__ __launch_bounds__(256) void k_backward_big(
     const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
     const int32_t *__restrict__ sampling_index_map, const float *__restrict__ face_inv_map, const float *__restrict__ faces,
-    const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
+    const float *__restrict__ zbase, const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
     float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
     float *__restrict__ grad_faces)
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
             const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
             compute_face_inv(px, py, inv);
         }
-        const float *fz = faces + ((size_t)(fix_batch_z ? b : 0) * F + fn) * 9;  // :389, Q1
+        const float *fz = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fn * 9;  // :389, Q1
         const float face_z[3] = {fz[2], fz[5], fz[8]};
         for (int k = tid; k < n_lds; k += 256) s_tex[k] = 0.0;
         if (tid < 33) s_red[tid] = 0.0f;
@@ -344,8 +345,9 @@ __global__ __launch_bounds__(256) void k_backward_big(
 __global__ __launch_bounds__(256) void k_backward_textures_atomic(
     const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
     const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
-    const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
-    float *__restrict__ grad_textures, int F, int S, int ts, double eps, int fix_batch_z, size_t n_pixels)
+    const float *__restrict__ zbase, const float *__restrict__ weight_map, const float *__restrict__ depth_map,
+    const float *__restrict__ g_rgb, float *__restrict__ grad_textures, int F, int S, int ts, double eps,
+    int fix_batch_z, size_t n_pixels)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_atomic(
             t.isc[pn] = sampling_index_map[8 * i + pn];
         }
     } else {
-        const float *face = faces + ((size_t)(fix_batch_z ? b : 0) * F + fi) * 9;
+        const float *face = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fi * 9;
         const float w[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
         const float fz[3] = {face[2], face[5], face[8]};
         compute_taps(fz, w, depth_map[i], ts, eps, t);
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
 
 // ====================================================================================================
 int nr::run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
-                              const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                              const int32_t *sampling_index_map, const float *faces, const float *faces_z_ref,
+                              const float *weight_map,
                               const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F,
                               int S, int ts, double eps, int flags, const int *vis_list, const int *vis_count,
                               hipStream_t st, const float *g_depth, float *grad_faces, int *depth_done)
@@ -476,6 +479,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     if (int e = check_sizes(B, F, S)) return e;
     if (ts < 2 || ts > 1024) return NR_E_SIZE;
     const int fix = (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0;
+    const float *zbase = faces_z_ref ? faces_z_ref : faces;  // :389 reads batch 0 of the GLOBAL batch (see nr_hip.h)
     const int n = B * F;
     const size_t n_tex = (size_t)ts * ts * ts * 3;
     if (ts > 13) vis_list = nullptr;  // the atomic fallback walks pixels, not faces
@@ -494,11 +498,11 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
         if (g_depth)
             hipLaunchKernelGGL((k_backward_textures_face<true, true>), grid, dim3(256), 0, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces);
         else
             hipLaunchKernelGGL((k_backward_textures_face<true, false>), grid, dim3(256), 0, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, nullptr, nullptr);
     } else if (ts <= 13) {
         const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
@@ -507,11 +511,11 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         const dim3 grid = vis_list ? dim3((unsigned)((F + per - 1) / per), (unsigned)B) : dim3((unsigned)((n + per - 1) / per));
         if (g_depth && L <= 64)
             hipLaunchKernelGGL((k_backward_textures_face<false, true>), grid, dim3(256), lds, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces);
         else
             hipLaunchKernelGGL((k_backward_textures_face<false, false>), grid, dim3(256), lds, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, weight_map, depth_map, grad_rgb_map,
+                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, nullptr, nullptr);
     }
     if (ts <= 8) {
@@ -521,7 +525,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         const size_t lds = st2 ? 0 : n_tex * sizeof(double);
 #define NR_BIG(T, D)                                                                                                    \
     hipLaunchKernelGGL((k_backward_big<T, D>), grid, dim3(256), lds, st, face_index_map, sampling_weight_map,          \
-                       sampling_index_map, (const float *)nullptr, faces, weight_map, depth_map, grad_rgb_map,        \
+                       sampling_index_map, (const float *)nullptr, faces, zbase, weight_map, depth_map, grad_rgb_map, \
                        grad_textures, n, F, S, ts, eps, fix, vis_list, vis_count, D ? g_depth : (const float *)nullptr, \
                        D ? grad_faces : (float *)nullptr)
         if (st2) { if (g_depth) NR_BIG(2, true); else NR_BIG(2, false); }
@@ -534,7 +538,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         if (e != hipSuccess) return (int)e;
         const size_t np = (size_t)B * S * S;
         hipLaunchKernelGGL(k_backward_textures_atomic, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st,
-                           face_index_map, sampling_weight_map, sampling_index_map, faces, weight_map, depth_map,
+                           face_index_map, sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map,
                            grad_rgb_map, grad_textures, F, S, ts, eps, fix, np);
     }
     return launch_status();
@@ -553,18 +557,19 @@ int nr::run_backward_depth_map(const float *faces, const float *depth_map, const
                        weight_map, grad_depth_map, grad_faces, n, F, S, vis_list, vis_count);
     const dim3 grid_big = vis_list ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
     hipLaunchKernelGGL((k_backward_big<0, true>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
-                       (const int32_t *)nullptr, face_inv_map, faces, weight_map, depth_map, (const float *)nullptr,
+                       (const int32_t *)nullptr, face_inv_map, faces, faces, weight_map, depth_map, (const float *)nullptr,
                        (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces);
     return launch_status();
 }
 
 NR_API int nr_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
-                                const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                                const int32_t *sampling_index_map, const float *faces, const float *faces_z_ref,
+                                const float *weight_map,
                                 const float *depth_map, const float *grad_rgb_map, float *grad_textures, int32_t B,
                                 int32_t F, int32_t S, int32_t ts, double eps, int32_t flags, void *stream)
 {
-    return run_backward_textures(face_index_map, sampling_weight_map, sampling_index_map, faces, weight_map, depth_map,
-                                 grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, nullptr, nullptr,
+    return run_backward_textures(face_index_map, sampling_weight_map, sampling_index_map, faces, faces_z_ref, weight_map,
+                                 depth_map, grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, nullptr, nullptr,
                                  (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 

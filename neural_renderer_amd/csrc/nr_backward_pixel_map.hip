@@ -2,6 +2,8 @@
 // (reference Rasterize.backward_pixel_map_gpu, rasterize.py:517-748) + its C-ABI entry point.
 #include "nr_device.h"
 
+#include <atomic>
+
 using namespace nr;
 
 namespace {
@@ -223,28 +225,39 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 // kernel above to be bound by memory latency and, for the vertical sweeps (axis 0, stride S), by 3x
 // cache-line amplification.  The band pipeline makes every sweep an LDS access:
 //
-//   k_mark_visible / k_count_visible / k_compact_visible   per image, the sorted list of faces that own at least one
+//   [k_mark_visible]   only when the forward did not hand over its per-face "owns a pixel" flags (visible_faces)
+//   k_compact_small | k_count_visible + k_compact_visible   per image, the sorted list of faces that own at least one
 //          pixel.  A face that owns no pixel contributes nothing to K6 (the out sweep needs face_index[in] == fn,
 //          :604, the in sweep only counts pixels owned by fn, :707), so ~2/3 of the front faces drop out.  The
-//          compaction also stores, per listed face, the line range of each of its 3 edges along both axes.
-//   k_bpm_band   one workgroup per (image, axis, band of W consecutive lines d0); workgroup ids are mapped so that all
-//          bands of an image run on one XCD (xcd_block).  It
-//          1. stages the band's W x S pixels of face_index / alpha / rgb / their gradients in LDS, laid out
-//             [line][d1] so that a sweep is a contiguous LDS run whatever the axis;
+//          compaction also stores, per listed face, the line range of each of its 3 edges along both axes, zeroes the
+//          face's six double sums (indexed by list position: no fill launch) and records face -> list position.
+//   k_bpm_fast (default) / k_bpm_band (NR_FLAG_EXACT_GRADIENT)   one workgroup per (image, axis, band of W consecutive
+//          lines d0); workgroup ids are mapped so that all bands of an image run on one XCD (xcd_block).  It
+//          0. counts the lines the image's visible faces have in the band and leaves when there are none (more than half
+//             of the bands of a teapot view: the object covers 12 % of the image);
+//          1. stages the band's W x S pixels in LDS, laid out [line][d1] so that a sweep is a contiguous LDS run
+//             whatever the axis;
 //          2. scans the image's visible faces (one per thread, 12 coalesced bytes each): for each of the 3 edges the
 //             precomputed d0 range clipped to the band gives the face's lines; an exclusive scan assigns line slots;
 //          3. sets lines up one per thread (crossing point, in/out pixels, sweep ranges, the two distance
-//             coefficients, rasterize.py:573-579, :606-609, :665-672) into 32-byte LDS records;
+//             coefficients, rasterize.py:573-579, :606-609, :665-672) into LDS records;
 //          4. sweeps: the in / out sweeps of all lines are cut into segments of <= SEG = 15 pixels; segment ids are
 //             dense (one packed scan of the per-line counts) and ordered by class -- all full-length segments first,
 //             the remainders after -- and one thread walks one segment (binary search id -> line), so the lanes of a
 //             wave have equal trip counts whatever the mix of short in-sweeps and border-long out-sweeps; the two
-//             partial sums of a segment are kept in double and added to per-face LDS accumulators (ds_add_f64);
-//          5. adds the per-face sums to a double scratch array [B*F][3 vertices][x|y] (global_atomic_add_f64).
-//   k_bpm_finalize   rounds the scratch sums to float and STORES grad_faces (z = 0).
-// Every per-pixel term uses the reference's arithmetic; sums are carried in double, so the result is the
-// correctly rounded sum of the reference's terms up to double round-off (run-to-run differences of the
-// atomic order are ~1e-16 relative and do not survive the final rounding in practice).
+//             partial sums of a segment are added to per-face LDS accumulators (ds_add_f64);
+//          5. adds the per-face sums to a double scratch array [B][list position][3 vertices][x|y] (global_atomic_add_f64).
+//   k_bpm_finalize   rounds the scratch sums to float and STORES grad_faces (z = 0; zeros for unlisted faces).
+//
+// Two instantiations of step 1 / 4 (DESIGN.md "K6 numerics"):
+//   k_bpm_band  EXACT: every per-pixel term is computed with the reference's arithmetic (IEEE division, the double
+//          `dist +- eps`), sums in double: the result is the correctly rounded sum of the reference's terms up to double
+//          round-off (<= 2e-6 against the exactly summed oracle).
+//   k_bpm_fast  the north star's tolerance (1e-4) spent where it buys time: per pixel the band keeps
+//          q = sum_c I_c * g_c and the gradients g_c (24 B instead of 36 B), so a visit is diff = q - sum_c ref_c * g_c
+//          (4 fma), dist = fma(c * 2/S, t, +-eps) in float, diff * v_rcp_f32(dist), float sums over the <= 15 terms of a
+//          segment, double from there on.  Per-term deviation ~1e-7; measured <= 1e-5 on a face gradient across the
+//          test suite (tests assert it).  ~30 issue slots per visit instead of ~95.
 constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per pass
 constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
@@ -260,6 +273,15 @@ struct __attribute__((aligned(16))) BandLine {
     int fn;
 };
 
+// the fast kernel's record: the same 32 bytes (c0 / c1 pre-multiplied by 2 / S) + the colours of the in / out pixel
+struct __attribute__((aligned(16))) FastLine {
+    int in_rng, out_rng, geo, tgt;
+    float cross, c0k, c1k;
+    int fn;
+    float ref_in[4];   // alpha, r, g, b of the in pixel  (reference colour of the OUT sweep)
+    float ref_out[4];  // alpha, r, g, b of the out pixel (reference colour of the IN sweep)
+};
+
 __global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict__ fi_map,
                                                       unsigned char *__restrict__ flags, int F, int SS, size_t P)
 {
@@ -269,10 +291,78 @@ __global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict_
     if (fi >= 0) flags[(i / SS) * F + fi] = 1;
 }
 
-// Ordered compaction in two launches so that a single huge mesh (config 5: 655 360 faces, B = 1) is not
-// serialised in one workgroup: k_count_visible counts the flags of each 1024-face chunk, k_compact_visible
-// turns the counts of the preceding chunks into the chunk's offset and writes the face indices in order.
+// Line range of one edge along one axis (rasterize.py:567-569), packed lo | hi << 16; RNG_EMPTY (lo > hi) when the edge
+// crosses no integer line or is parallel to the sweeps (p0x == p1x: both contributions are skipped, :648, :653).
+constexpr unsigned RNG_EMPTY = 1u;
+
+__device__ __forceinline__ unsigned edge_range(float p0x, float p1x, int S)
+{
+    const int d0_from = (int)fmax((double)ceilf(fminf(p0x, p1x)), 0.0);   // :568
+    const int d0_to = (int)fmin((double)fmaxf(p0x, p1x), S - 1.0);        // :569
+    return (p0x != p1x && d0_to >= d0_from) ? (unsigned)d0_from | ((unsigned)d0_to << 16) : RNG_EMPTY;
+}
+
+// What the compaction records for the face at list position `pos` of image b: its index, the six edge line ranges
+// rng[b][axis][pos][edge] (so that the 2 * n_bands band workgroups of an image scan 12 coalesced bytes per face instead of
+// chasing list -> vertices each) and six zeroed double sums.
+__device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int S, const float *__restrict__ faces,
+                                             int *__restrict__ vis_list, unsigned *__restrict__ rng,
+                                             double *__restrict__ scratch)
+{
+    vis_list[(size_t)b * F + pos] = fn;
+    const float *f = faces + ((size_t)b * F + fn) * 9;
+    const float fs = (float)S;
+    float px[3], py[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { px[k] = to_pixel(f[3 * k], fs); py[k] = to_pixel(f[3 * k + 1], fs); }
+    unsigned *r0 = rng + (((size_t)b * 2 + 0) * F + pos) * 3, *r1 = rng + (((size_t)b * 2 + 1) * F + pos) * 3;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        r0[e] = edge_range(px[e], px[(e + 1) % 3], S);
+        r1[e] = edge_range(py[e], py[(e + 1) % 3], S);
+    }
+    double2 *z = reinterpret_cast<double2 *>(scratch + ((size_t)b * F + pos) * 6);
+    z[0] = z[1] = z[2] = make_double2(0.0, 0.0);
+}
+
+// Ordered compaction.  Meshes of up to SMALL_CHUNKS * 1024 faces: one workgroup per image walks the chunks in order
+// (one launch).  Larger meshes (config 5: 655 360 faces, B = 1) would be serialised in that one workgroup, so they take two
+// launches: k_count_visible counts the flags of each 1024-face chunk, k_compact_visible turns the counts of the preceding
+// chunks into the chunk's offset.  Either way every face gets slot_of = its list position or -1.
 constexpr int VIS_CHUNK = 1024;
+constexpr int SMALL_CHUNKS = 16;
+
+__global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char *__restrict__ flags,
+                                                             int *__restrict__ vis_list, int *__restrict__ vis_count,
+                                                             int *__restrict__ slot_of, int F, int n_chunks,
+                                                             const float *__restrict__ faces, unsigned *__restrict__ rng,
+                                                             double *__restrict__ scratch, int S)
+{
+    __shared__ int s_wcnt[VIS_CHUNK / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int fn = chunk * VIS_CHUNK + tid;
+        const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base, tot = 0;
+        for (int w = 0; w < VIS_CHUNK / 64; ++w) {
+            const int c = s_wcnt[w];
+            if (w < wave) off += c;
+            tot += c;
+        }
+        __syncthreads();
+        if (fn < F) {
+            const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+            slot_of[(size_t)b * F + fn] = pos;
+            if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch);
+        }
+        base += tot;
+    }
+    if (tid == 0) vis_count[b] = base;
+}
 
 __global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char *__restrict__ flags,
                                                              int *__restrict__ chunk_count, int F, int n_chunks)
@@ -291,24 +381,13 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char
     }
 }
 
-// Line range of one edge along one axis (rasterize.py:567-569), packed lo | hi << 16; RNG_EMPTY (lo > hi) when the edge
-// crosses no integer line or is parallel to the sweeps (p0x == p1x: both contributions are skipped, :648, :653).
-constexpr unsigned RNG_EMPTY = 1u;
-
-__device__ __forceinline__ unsigned edge_range(float p0x, float p1x, int S)
-{
-    const int d0_from = (int)fmax((double)ceilf(fminf(p0x, p1x)), 0.0);   // :568
-    const int d0_to = (int)fmin((double)fmaxf(p0x, p1x), S - 1.0);        // :569
-    return (p0x != p1x && d0_to >= d0_from) ? (unsigned)d0_from | ((unsigned)d0_to << 16) : RNG_EMPTY;
-}
-
-// Besides the ordered list, every visible face gets its six edge line ranges, rng[b][axis][slot][edge], so that the
-// 2 * n_bands band workgroups of an image scan 12 coalesced bytes per face instead of chasing list -> vertices each.
 __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned char *__restrict__ flags,
                                                                const int *__restrict__ chunk_count,
                                                                int *__restrict__ vis_list, int *__restrict__ vis_count,
-                                                               int F, int n_chunks, const float *__restrict__ faces,
-                                                               unsigned *__restrict__ rng, int S)
+                                                               int *__restrict__ slot_of, int F, int n_chunks,
+                                                               const float *__restrict__ faces,
+                                                               unsigned *__restrict__ rng, double *__restrict__ scratch,
+                                                               int S)
 {
     __shared__ int s_wcnt[VIS_CHUNK / 64];
     __shared__ int s_part[VIS_CHUNK / 64];
@@ -329,20 +408,10 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
         if (w < wave) off += s_wcnt[w];
         own += s_wcnt[w];
     }
-    if (v) {
-        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-        vis_list[(size_t)b * F + pos] = fn;
-        const float *f = faces + ((size_t)b * F + fn) * 9;
-        const float fs = (float)S;
-        float px[3], py[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { px[k] = to_pixel(f[3 * k], fs); py[k] = to_pixel(f[3 * k + 1], fs); }
-        unsigned *r0 = rng + (((size_t)b * 2 + 0) * F + pos) * 3, *r1 = rng + (((size_t)b * 2 + 1) * F + pos) * 3;
-#pragma unroll
-        for (int e = 0; e < 3; e++) {
-            r0[e] = edge_range(px[e], px[(e + 1) % 3], S);
-            r1[e] = edge_range(py[e], py[(e + 1) % 3], S);
-        }
+    if (fn < F) {
+        const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+        slot_of[(size_t)b * F + fn] = pos;
+        if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch);
     }
     if (chunk == n_chunks - 1 && tid == 0) {
         int base = 0;
@@ -381,14 +450,78 @@ __device__ __forceinline__ double signed_eps(float dist, unsigned eps_hi, unsign
     return __hiloint2double((int)((0.0f < dist) ? eps_hi : (eps_hi ^ 0x80000000u)), (int)eps_lo);
 }
 
+// list position of face fn in an image's (ascending) visible list; only the rare LDS-slot overflow path needs it
+__device__ __forceinline__ int vis_position(const int *__restrict__ list, int n, int fn)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (list[mid] < fn) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// lines of the image's visible faces inside [band_lo, band_hi] along `axis`: does the band have any work?
+__device__ __forceinline__ bool band_has_lines(const unsigned *__restrict__ rng_ba, int n_vis, int band_lo, int band_hi)
+{
+    bool any = false;
+    for (int i = threadIdx.x; i < 3 * n_vis; i += BAND_THREADS) {
+        const unsigned pr = rng_ba[i];
+        any |= min((int)(pr >> 16), band_hi) >= max((int)(pr & 0xffffu), band_lo);
+    }
+    return __syncthreads_or(any) != 0;
+}
+
+// Segment id -> (line, sweep, pixel range): shared by the two band kernels.  s_pref holds, per line of the window, the
+// exclusive prefix of full segments (low 16 bits) and partial segments (high 16 bits).
+struct SegRange {
+    int line, s_from, s_to;
+    bool mode_in;
+};
+__device__ __forceinline__ SegRange decode_segment(int sid, int total_full, int n_win, const int *s_pref,
+                                                   const int *line_words /* BandLine / FastLine array */, int stride_words)
+{
+    SegRange r;
+    const bool is_full = sid < total_full;
+    const int id = is_full ? sid : sid - total_full;
+    const int shift = is_full ? 0 : 16;
+    int lo = 0, hi = n_win - 1;  // last line whose prefix (of this class) is <= id
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (((s_pref[mid] >> shift) & 0xffff) <= id) lo = mid; else hi = mid - 1;
+    }
+    r.line = lo;
+    const int in_rng = line_words[lo * stride_words], out_rng = line_words[lo * stride_words + 1];
+    const int k = id - ((s_pref[lo] >> shift) & 0xffff);
+    const int in_from = in_rng & 0xffff, in_to = in_rng >> 16;
+    const int il = in_to - in_from + 1;
+    const int n_in_full = il > 0 ? il / SEG : 0;
+    if (is_full) {
+        r.mode_in = k < n_in_full;
+        r.s_from = r.mode_in ? in_from + k * SEG : (out_rng & 0xffff) + (k - n_in_full) * SEG;
+        r.s_to = r.s_from + SEG - 1;
+    } else {
+        r.mode_in = k == 0 && il > 0 && il % SEG != 0;
+        if (r.mode_in) {
+            r.s_from = in_from + n_in_full * SEG;
+            r.s_to = in_to;
+        } else {
+            const int out_from = out_rng & 0xffff, out_to = out_rng >> 16;
+            r.s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG;
+            r.s_to = out_to;
+        }
+    }
+    return r;
+}
+
 // POW2: S is a power of two (x * 2. / S is then one exact float multiply; the generic instantiation carries a
 // double-precision division whose register footprint would otherwise cap the occupancy of the common case).
-template <bool RGB, bool ALPHA, bool EXACT, bool POW2>
+template <bool RGB, bool ALPHA, bool POW2>
 __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void k_bpm_band(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
-    double *__restrict__ scratch, int F, int S, int W, int SP, double eps, int B)
+    double *__restrict__ scratch, int F, int S, int W, int SP, double eps, int B, int win_lines)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -403,6 +536,9 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
+    const int n_vis = vis_count[b];
+    const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
+    if (!band_has_lines(rng_ba, n_vis, band_lo, band_hi)) return;  // step 0
 
     // ---- LDS carve-out
     size_t off = 0;
@@ -417,7 +553,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
     int *s_pref = (int *)carve(4 * BAND_WIN);
     int *s_recfn = (int *)carve(4 * BAND_WIN);           // face index of each line record
     double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);  // per-face sums of the faces that have lines in this band
-    int *s_slotfn = (int *)carve(4 * ACC_SLOTS);
+    int *s_slotpos = (int *)carve(4 * ACC_SLOTS);        // list position of the face in each slot
     int *s_tmp = (int *)carve(4 * 16);
 
     // ---- 1. stage the band: LDS[(ld, d1)] = map[b][d0 = band_lo + ld][d1] (axis 1) or map[b][d1][d0] (axis 0)
@@ -503,7 +639,6 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
 
     const float fs = (float)S;
     const double s_d = (double)S, two_over_s = 2.0 / (double)S;
-    const int n_vis = vis_count[b];
 
     for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
         // ---- 2. one visible face per thread: lines of its 3 edges inside the band
@@ -511,7 +646,7 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
         int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
         if (chunk + tid < n_vis) {
             fn = vis_list[(size_t)b * F + chunk + tid];
-            const unsigned *r = rng + (((size_t)b * 2 + axis) * F + chunk + tid) * 3;
+            const unsigned *r = rng_ba + (size_t)(chunk + tid) * 3;
 #pragma unroll
             for (int e = 0; e < 3; e++) {
                 const unsigned pr = r[e];
@@ -524,22 +659,22 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
         const int packed_off = block_excl_scan(nl | ((nl > 0) << 20), s_tmp, &total_packed);
         const int line_off = packed_off & 0xfffff, slot = packed_off >> 20;
         const int total_lines = total_packed & 0xfffff;
-        if (nl > 0 && slot < ACC_SLOTS) s_slotfn[slot] = fn;
+        if (nl > 0 && slot < ACC_SLOTS) s_slotpos[slot] = chunk + tid;
 
-        for (int win = 0; win < total_lines; win += BAND_WIN) {
+        for (int win = 0; win < total_lines; win += win_lines) {
             // ---- compact records of the lines that fall into this window
-            if (nl > 0 && line_off < win + BAND_WIN && line_off + nl > win) {
+            if (nl > 0 && line_off < win + win_lines && line_off + nl > win) {
                 int k = line_off;
 #pragma unroll
                 for (int e = 0; e < 3; e++)
                     for (int j = 0; j < e_n[e]; j++, k++)
-                        if (k >= win && k < win + BAND_WIN) {
+                        if (k >= win && k < win + win_lines) {
                             s_rec[k - win] = slot | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
                             s_recfn[k - win] = fn;
                         }
             }
             __syncthreads();
-            const int n_win = min(total_lines - win, BAND_WIN);
+            const int n_win = min(total_lines - win, win_lines);
 
             // ---- 3. line setup, one line per thread: rasterize.py:543-579, :604-609, :665-672
             if (tid < n_win) {
@@ -598,7 +733,8 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
             //         class: first every FULL segment (exactly SEG pixels) of every line, then the partial ones (the
             //         remainders, i.e. all the short in-sweeps), so that the 64 lanes of a wave walk segments of (nearly)
             //         equal length instead of idling behind one long out-sweep piece.  One packed scan gives both
-            //         prefixes: full segments in the low 16 bits (<= BAND_WIN * 2 * S / SEG), partial ones above.
+            //         prefixes: full segments in the low 16 bits (win_lines is chosen so that win_lines * 2 * S / SEG fits),
+            //         partial ones above.
             int n_seg = 0;
             if (tid < n_win) {
                 const BandLine &L = s_line[tid];
@@ -613,39 +749,12 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
             __syncthreads();
             const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
             for (int sid = tid; sid < total_all; sid += BAND_THREADS) {
-                const bool is_full = sid < total_full;
-                const int id = is_full ? sid : sid - total_full;
-                const int shift = is_full ? 0 : 16;
-                // last line l whose prefix (of this class) is <= id
-                int lo = 0, hi = n_win - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (((s_pref[mid] >> shift) & 0xffff) <= id) lo = mid; else hi = mid - 1;
-                }
-                const BandLine *L = &s_line[lo];
+                const SegRange sr = decode_segment(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
+                                                   (int)(sizeof(BandLine) / 4));
+                const BandLine *L = &s_line[sr.line];
                 const int4 h = *reinterpret_cast<const int4 *>(L);
                 const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
-                const int k = id - ((s_pref[lo] >> shift) & 0xffff);
-                const int in_from = h.x & 0xffff, in_to = h.x >> 16;
-                const int il = in_to - in_from + 1;
-                const int n_in_full = il > 0 ? il / SEG : 0;
-                bool mode_in;
-                int s_from, s_to;
-                if (is_full) {
-                    mode_in = k < n_in_full;
-                    s_from = mode_in ? in_from + k * SEG : (h.y & 0xffff) + (k - n_in_full) * SEG;
-                    s_to = s_from + SEG - 1;
-                } else {
-                    mode_in = k == 0 && il > 0 && il % SEG != 0;
-                    if (mode_in) {
-                        s_from = in_from + n_in_full * SEG;
-                        s_to = in_to;
-                    } else {
-                        const int out_from = h.y & 0xffff, out_to = h.y >> 16;
-                        s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG;
-                        s_to = out_to;
-                    }
-                }
+                const bool mode_in = sr.mode_in;
                 const int flags = (h.z >> 24) & 0xff;
                 const int ld = (h.z >> 16) & 0xff;
                 const int d1_in = h.z & 0xffff;
@@ -656,81 +765,57 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
                 if (RGB) { ref_r = s_rgb[3 * lref]; ref_g = s_rgb[3 * lref + 1]; ref_b = s_rgb[3 * lref + 2]; }
                 const float cross = c.x, c0 = c.y, c1 = c.z;
                 const int fnr = __float_as_int(c.w);
-                // EXACT = true (default): IEEE division and double accumulation of every term -- each term is
-                // bit-identical to the reference's and the sum is exact up to double round-off.
-                // EXACT = false (NR_K6_FAST=1): the two quotients diff / dist use the hardware reciprocal (v_rcp_f32,
-                // 1 ulp) and the <= 15 same-signed terms of a segment are summed in float before they enter the
-                // double accumulators: a per-term relative deviation of ~1e-7 (measured <= 1.4e-5 on a face
-                // gradient after cancellation, against the 1e-4 tolerance) for -7 % kernel time.
-                float f0 = 0.0f, f1 = 0.0f;
+                // every term bit-identical to the reference's (IEEE division, double `dist +- eps`), summed in double
                 double d0acc = 0.0, d1acc = 0.0;
                 const float two_over_s_f = (float)two_over_s;  // exact when S is a power of two
                 const unsigned eps_hi = (unsigned)__double2hiint(eps), eps_lo = (unsigned)__double2loint(eps);
                 const bool has0 = (flags & 2) != 0, has1 = (flags & 4) != 0;
-                // pixel data of the NEXT visit is fetched before the current one is evaluated, so that the LDS
-                // latency hides behind the VALU work of a visit (occupancy here is only 2-4 waves/SIMD)
-                struct Px { int fi; float al, ga, r, g, b, gr, gg, gb; };
-                auto fetch = [&](int d1) {
-                    Px p;
+                for (int d1 = sr.s_from; d1 <= sr.s_to; ++d1) {  // one pixel visit: :630-657 (out) / :697-728 (in)
                     const int l = ld * SP + d1;
-                    p.fi = mode_in ? s_fi[l] : fnr;  // only the in-sweep tests ownership (:707): out-sweeps skip this LDS read
-                    p.al = p.ga = p.r = p.g = p.b = p.gr = p.gg = p.gb = 0.0f;
-                    if (ALPHA) { p.al = s_al[l]; p.ga = s_ga[l]; }
-                    if (RGB) {
-                        p.r = s_rgb[3 * l]; p.g = s_rgb[3 * l + 1]; p.b = s_rgb[3 * l + 2];
-                        p.gr = s_grgb[3 * l]; p.gg = s_grgb[3 * l + 1]; p.gb = s_grgb[3 * l + 2];
-                    }
-                    return p;
-                };
-                auto visit = [&](const Px &p, int d1) {  // one pixel visit: :630-657 (out) / :697-728 (in)
-                    if (p.fi != fnr) return;  // :707
+                    if (mode_in && s_fi[l] != fnr) continue;  // :707 (the out sweep does not test ownership)
                     float diff = 0.0f;
-                    if (ALPHA) diff += (p.al - ref_a) * p.ga;
+                    if (ALPHA) diff += (s_al[l] - ref_a) * s_ga[l];
                     if (RGB) {
-                        diff += (p.r - ref_r) * p.gr;
-                        diff += (p.g - ref_g) * p.gg;
-                        diff += (p.b - ref_b) * p.gb;
+                        diff += (s_rgb[3 * l] - ref_r) * s_grgb[3 * l];
+                        diff += (s_rgb[3 * l + 1] - ref_g) * s_grgb[3 * l + 1];
+                        diff += (s_rgb[3 * l + 2] - ref_b) * s_grgb[3 * l + 2];
                     }
-                    if (diff <= 0.0f) return;  // :647 / :717
+                    if (diff <= 0.0f) continue;  // :647 / :717
                     const float t = (float)d1 - cross;
                     if (has0) {  // :648-652 (x * 2. / S: an exact scaling when S is a power of two)
                         const float ct = c0 * t;
                         float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
                         dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
-                        if (EXACT) d0acc -= (double)(diff / dist); else f0 -= diff * __builtin_amdgcn_rcpf(dist);
+                        d0acc -= (double)(diff / dist);
                     }
                     if (has1) {  // :653-657
                         const float ct = c1 * t;
                         float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
-                        dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
-                        if (EXACT) d1acc -= (double)(diff / dist); else f1 -= diff * __builtin_amdgcn_rcpf(dist);
+                        dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));
+                        d1acc -= (double)(diff / dist);
                     }
-                };
-                for (int d1 = s_from; d1 <= s_to; ++d1) {
-                    const Px cur = fetch(d1);
-                    visit(cur, d1);
                 }
-                const double a0 = (double)f0 + d0acc, a1 = (double)f1 + d1acc;
                 const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
                 if (slot < ACC_SLOTS) {
-                    if (a0 != 0.0) atomicAdd(&s_acc[3 * slot + v0], a0);
-                    if (a1 != 0.0) atomicAdd(&s_acc[3 * slot + v1], a1);
-                } else {  // more faces with lines in this pass than LDS slots: straight to the global sums
-                    double *dst = scratch + ((size_t)b * F + fnr) * 6 + (1 - axis);
-                    if (a0 != 0.0) atomicAdd(dst + 2 * v0, a0);
-                    if (a1 != 0.0) atomicAdd(dst + 2 * v1, a1);
+                    if (d0acc != 0.0) atomicAdd(&s_acc[3 * slot + v0], d0acc);
+                    if (d1acc != 0.0) atomicAdd(&s_acc[3 * slot + v1], d1acc);
+                } else if (d0acc != 0.0 || d1acc != 0.0) {  // more faces with lines in this pass than LDS slots
+                    const int pos = vis_position(vis_list + (size_t)b * F, n_vis, fnr);
+                    double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
+                    if (d0acc != 0.0) atomicAdd(dst + 2 * v0, d0acc);
+                    if (d1acc != 0.0) atomicAdd(dst + 2 * v1, d1acc);
                 }
             }
             __syncthreads();
         }
 
-        // ---- 5. per-face sums of this chunk -> global double scratch [face][vertex][x|y]
+        // ---- 5. per-face sums of this chunk -> global double scratch [list position][vertex][x|y]
         {
             const int n_slots = min(total_packed >> 20, ACC_SLOTS);
             if (tid < 3 * n_slots) {
                 const int sl = tid / 3, v = tid - 3 * sl;
                 const double a = s_acc[tid];
-                if (a != 0.0) atomicAdd(scratch + ((size_t)b * F + s_slotfn[sl]) * 6 + 2 * v + (1 - axis), a);
+                if (a != 0.0) atomicAdd(scratch + ((size_t)b * F + s_slotpos[sl]) * 6 + 2 * v + (1 - axis), a);
                 s_acc[tid] = 0.0;
             }
         }
@@ -738,13 +823,316 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
     }
 }
 
-__global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__ scratch, float *__restrict__ grad_faces,
-                                                      int n_faces_total)
+// --------------------------------------------------------------------------------------------------
+// The tolerance-mode band kernel (default).  Same pipeline as k_bpm_band; differences:
+//   * LDS pixel data: face index, q = sum_c I_c * g_c, and the gradients g_c (SoA, [line][d1]);
+//   * line records carry the colours of the in / out pixel (read from the maps in global memory, L2 hits);
+//   * a visit is 4 fma + compare + (fma, rcp, fma) x 2 in float.
+// Why `0 < dist` can be decided on t = d1 - d1_cross alone: c0 = (p1x - p0x) / (p1x - d0) and c1 = (p1x - p0x) / (d0 - p0x)
+// are quotients of equally signed numbers whenever the contribution is taken (d0 lies between p0x and p1x and differs from
+// the vertex in the denominator, :648 / :653), i.e. c >= 1 > 0, and 2 / S > 0: sign(dist) = sign(t), and dist = +-0 exactly
+// when t = 0 (then `0 < dist` is false: - eps, as here).  When the contribution is NOT taken the coefficient is +-Inf / NaN;
+// the lane then accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
+template <bool RGB, bool ALPHA>
+__global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
+    const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
+    const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
+    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
+    double *__restrict__ scratch, int F, int S, int W, int SP, float eps_f, int B, int win_lines)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
+    const unsigned total_wg = n_bands * 2u * (unsigned)B;
+    const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_band)
+    if (logical >= total_wg) return;
+    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
+    const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
+    const int nld = band_hi - band_lo + 1;
+    const int n_vis = vis_count[b];
+    const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
+    if (!band_has_lines(rng_ba, n_vis, band_lo, band_hi)) return;  // step 0
+
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
+    // pixel records, [line][d1], NP 8-byte pairs each: (face index, q) (g_alpha | g_r, g_r | g_g) (g_g, g_b).  One record =
+    // NP ds_read_b64 with immediate offsets (a single wait); consecutive segments of a sweep are SEG * NP * 2 dwords apart,
+    // which spreads the 8-byte reads of a wave over all banks for NP = 3 (90 dwords: every even bank once per 32 lanes).
+    constexpr int NP = RGB ? 3 : 2;
+    float2 *s_px = (float2 *)carve((size_t)W * SP * NP * 8);
+    FastLine *s_line = (FastLine *)carve(sizeof(FastLine) * BAND_WIN);
+    int *s_rec = (int *)carve(4 * BAND_WIN);
+    int *s_pref = (int *)carve(4 * BAND_WIN);
+    int *s_recfn = (int *)carve(4 * BAND_WIN);
+    double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);
+    int *s_slotpos = (int *)carve(4 * ACC_SLOTS);
+    int *s_tmp = (int *)carve(4 * 16);
+
+    // ---- 1. stage the band.  One thread owns one pixel: it needs all of the pixel's colours and gradients for q.
+    const size_t img = (size_t)b * S * S;
+    auto put = [&](int l, int fi, float al, float ga, float r, float g, float bl, float gr, float gg, float gb) {
+        float q = 0.0f;
+        if (ALPHA) q = al * ga;
+        if (RGB) { q = __builtin_fmaf(r, gr, q); q = __builtin_fmaf(g, gg, q); q = __builtin_fmaf(bl, gb, q); }
+        float2 *rec = s_px + (size_t)l * NP;
+        rec[0] = make_float2(__int_as_float(fi), q);
+        if (RGB && ALPHA) { rec[1] = make_float2(ga, gr); rec[2] = make_float2(gg, gb); }
+        else if (RGB) { rec[1] = make_float2(gr, gg); rec[2] = make_float2(gb, 0.0f); }
+        else rec[1] = make_float2(ga, 0.0f);
+    };
+    if (axis) {  // a band line is an image row: thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
+        for (int i = tid; i < nld * S; i += BAND_THREADS) {
+            const int ld = i / S, x = i - ld * S;
+            const size_t g = img + (size_t)(band_lo + ld) * S + x;
+            float al = 0, ga = 0, r = 0, gn = 0, bl = 0, gr = 0, gg = 0, gb = 0;
+            if (ALPHA) { al = alpha_map[g]; ga = g_alpha[g]; }
+            if (RGB) {
+                r = rgb_map[3 * g]; gn = rgb_map[3 * g + 1]; bl = rgb_map[3 * g + 2];
+                gr = g_rgb[3 * g]; gg = g_rgb[3 * g + 1]; gb = g_rgb[3 * g + 2];
+            }
+            put(ld * SP + x, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
+        }
+    } else if (nld == 4 && (S & 3) == 0) {  // 4 adjacent columns: one 16-byte load per (row, field)
+        for (int y = tid; y < S; y += BAND_THREADS) {
+            const size_t g = img + (size_t)y * S + band_lo;
+            const int4 vf = *reinterpret_cast<const int4 *>(fi_map + g);
+            float4 va = make_float4(0, 0, 0, 0), vg = va;
+            if (ALPHA) {
+                va = *reinterpret_cast<const float4 *>(alpha_map + g);
+                vg = *reinterpret_cast<const float4 *>(g_alpha + g);
+            }
+            float rr[12], qq[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) rr[k] = qq[k] = 0.0f;
+            if (RGB) {
+                const float4 *pr = reinterpret_cast<const float4 *>(rgb_map + 3 * g);
+                const float4 *pg = reinterpret_cast<const float4 *>(g_rgb + 3 * g);
+                const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], q0 = pg[0], q1 = pg[1], q2 = pg[2];
+                rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+                rr[8] = r2.x; rr[9] = r2.y; rr[10] = r2.z; rr[11] = r2.w;
+                qq[0] = q0.x; qq[1] = q0.y; qq[2] = q0.z; qq[3] = q0.w; qq[4] = q1.x; qq[5] = q1.y; qq[6] = q1.z; qq[7] = q1.w;
+                qq[8] = q2.x; qq[9] = q2.y; qq[10] = q2.z; qq[11] = q2.w;
+            }
+            const int fis[4] = {vf.x, vf.y, vf.z, vf.w};
+            const float als[4] = {va.x, va.y, va.z, va.w}, gas[4] = {vg.x, vg.y, vg.z, vg.w};
+#pragma unroll
+            for (int ld = 0; ld < 4; ++ld)
+                put(ld * SP + y, fis[ld], als[ld], gas[ld], rr[3 * ld], rr[3 * ld + 1], rr[3 * ld + 2], qq[3 * ld],
+                    qq[3 * ld + 1], qq[3 * ld + 2]);
+        }
+    } else {  // generic columns: thread -> (row d1, line ld) with ld fastest
+        for (int i = tid; i < nld * S; i += BAND_THREADS) {
+            const int d1 = i / nld, ld = i - d1 * nld;
+            const size_t g = img + (size_t)d1 * S + band_lo + ld;
+            float al = 0, ga = 0, r = 0, gn = 0, bl = 0, gr = 0, gg = 0, gb = 0;
+            if (ALPHA) { al = alpha_map[g]; ga = g_alpha[g]; }
+            if (RGB) {
+                r = rgb_map[3 * g]; gn = rgb_map[3 * g + 1]; bl = rgb_map[3 * g + 2];
+                gr = g_rgb[3 * g]; gg = g_rgb[3 * g + 1]; gb = g_rgb[3 * g + 2];
+            }
+            put(ld * SP + d1, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
+        }
+    }
+    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
+    __syncthreads();
+
+    const float fs = (float)S;
+    const float k2s = 2.0f / fs;
+
+    for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
+        // ---- 2. one visible face per thread: lines of its 3 edges inside the band
+        int fn = -1, nl = 0;
+        int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
+        if (chunk + tid < n_vis) {
+            fn = vis_list[(size_t)b * F + chunk + tid];
+            const unsigned *r = rng_ba + (size_t)(chunk + tid) * 3;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const unsigned pr = r[e];
+                const int lo = max((int)(pr & 0xffffu), band_lo), hi = min((int)(pr >> 16), band_hi);
+                if (hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
+            }
+        }
+        int total_packed = 0;
+        const int packed_off = block_excl_scan(nl | ((nl > 0) << 20), s_tmp, &total_packed);
+        const int line_off = packed_off & 0xfffff, slot = packed_off >> 20;
+        const int total_lines = total_packed & 0xfffff;
+        if (nl > 0 && slot < ACC_SLOTS) s_slotpos[slot] = chunk + tid;
+
+        for (int win = 0; win < total_lines; win += win_lines) {
+            if (nl > 0 && line_off < win + win_lines && line_off + nl > win) {
+                int k = line_off;
+#pragma unroll
+                for (int e = 0; e < 3; e++)
+                    for (int j = 0; j < e_n[e]; j++, k++)
+                        if (k >= win && k < win + win_lines) {
+                            s_rec[k - win] = slot | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
+                            s_recfn[k - win] = fn;
+                        }
+            }
+            __syncthreads();
+            const int n_win = min(total_lines - win, win_lines);
+
+            // ---- 3. line setup, one line per thread: rasterize.py:543-579, :594-609, :665-672 (reference arithmetic: the
+            //         crossing points decide WHICH pixels are visited, which must not depend on the mode)
+            if (tid < n_win) {
+                const int rec = s_rec[tid];
+                const int slot = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
+                const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+                const int rfn = s_recfn[tid];
+                const float *fv = faces + ((size_t)b * F + rfn) * 9;
+                float fp[6];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { fp[k] = to_pixel(fv[3 * k], fs); fp[3 + k] = to_pixel(fv[3 * k + 1], fs); }
+                const int ox = axis ? 3 : 0, oy = axis ? 0 : 3;  // p[num][dim] = pp[num][(dim + axis) % 2] (:556)
+                const float p0x = fp[ox + i0], p0y = fp[oy + i0], p1x = fp[ox + i1], p1y = fp[oy + i1];
+                const float p2x = fp[ox + i2], p2y = fp[oy + i2];
+                int direction;
+                if (axis == 0) direction = (p0x < p1x) ? -1 : 1; else direction = (p0x < p1x) ? 1 : -1;  // :559-564
+                const int d0 = band_lo + ld;
+                const float d0f = (float)d0;
+                FastLine r;
+                r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = slot | (i0 << 16) | (i1 << 18);
+                r.cross = r.c0k = r.c1k = 0.0f;
+                r.fn = rfn;
+#pragma unroll
+                for (int k = 0; k < 4; k++) r.ref_in[k] = r.ref_out[k] = 0.0f;
+                const float d1_cross = (p1y - p0y) / (p1x - p0x) * (d0f - p0x) + p0y;                  // :573
+                const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);     // :574
+                const int d1_out = d1_in + direction;                                                 // :575
+                if (!(d1_in < 0 || S <= d1_in) && !(d1_out < 0 || S <= d1_out)) {                     // :578-579
+                    int flags = (0 < direction) ? 8 : 0;
+                    if (p1x != d0f) flags |= 2;
+                    if (p0x != d0f) flags |= 4;
+                    r.c0k = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor x 2 / S
+                    r.c1k = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
+                    if (__float_as_int(s_px[(size_t)(ld * SP + d1_in) * NP].x) == rfn) {  // :604-609
+                        const int lim = (0 < direction) ? S - 1 : 0;
+                        const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
+                        r.out_rng = o_from | (o_to << 16);
+                        flags |= 1;
+                    }
+                    float d0_cross2;                          // :665-672
+                    if ((d0f - p0x) * (d0f - p2x) < 0)
+                        d0_cross2 = (p2y - p0y) / (p2x - p0x) * (d0f - p0x) + p0y;
+                    else
+                        d0_cross2 = (p1y - p2y) / (p1x - p2x) * (d0f - p2x) + p2y;
+                    const int lim2 = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
+                    const int i_from = max(min(d1_in, lim2), 0), i_to = min(max(d1_in, lim2), S - 1);
+                    r.in_rng = i_from | (i_to << 16);
+                    r.geo = d1_in | (ld << 16) | (flags << 24);
+                    r.cross = d1_cross;
+                    // colours of the in / out pixel (:594-601) from the maps themselves
+                    const size_t g_in = axis ? img + (size_t)d0 * S + d1_in : img + (size_t)d1_in * S + d0;
+                    const size_t g_out = axis ? img + (size_t)d0 * S + d1_out : img + (size_t)d1_out * S + d0;
+                    if (ALPHA) { r.ref_in[0] = alpha_map[g_in]; r.ref_out[0] = alpha_map[g_out]; }
+                    if (RGB) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { r.ref_in[1 + k] = rgb_map[3 * g_in + k]; r.ref_out[1 + k] = rgb_map[3 * g_out + k]; }
+                    }
+                }
+                s_line[tid] = r;
+            }
+            __syncthreads();
+
+            // ---- 4. sweeps, one segment per thread (see k_bpm_band)
+            int n_seg = 0;
+            if (tid < n_win) {
+                const FastLine &L = s_line[tid];
+                const int il = (L.in_rng >> 16) - (L.in_rng & 0xffff) + 1, ol = (L.out_rng >> 16) - (L.out_rng & 0xffff) + 1;
+                const int full = (il > 0 ? il / SEG : 0) + (ol > 0 ? ol / SEG : 0);
+                const int part = (il > 0 && il % SEG != 0) + (ol > 0 && ol % SEG != 0);
+                n_seg = full | (part << 16);
+            }
+            int total_seg = 0;
+            const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
+            if (tid < n_win) s_pref[tid] = seg_off;
+            __syncthreads();
+            const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
+            for (int sid = tid; sid < total_all; sid += BAND_THREADS) {
+                const SegRange sr = decode_segment(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
+                                                   (int)(sizeof(FastLine) / 4));
+                const FastLine *L = &s_line[sr.line];
+                const int4 h = *reinterpret_cast<const int4 *>(L);
+                const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
+                const bool mode_in = sr.mode_in;
+                // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
+                const float4 ref = *reinterpret_cast<const float4 *>(mode_in ? L->ref_out : L->ref_in);
+                const int flags = (h.z >> 24) & 0xff;
+                const int base = ((h.z >> 16) & 0xff) * SP;
+                const float cross = c.x, c0k = c.y, c1k = c.z;
+                const int fnr = __float_as_int(c.w);
+                float f0 = 0.0f, f1 = 0.0f;
+                float d1f = (float)sr.s_from;
+                const int own = mode_in ? fnr : -2;  // only the in sweep tests ownership (:707); -2 is no face index
+                const float2 *px = s_px + (size_t)(base + sr.s_from) * NP;
+                for (int d1 = sr.s_from; d1 <= sr.s_to; ++d1, d1f += 1.0f, px += NP) {
+                    const float2 r0 = px[0], r1 = px[1];
+                    float diff = r0.y;  // sum_c I_c g_c - sum_c ref_c g_c  (:631-638, :709-716)
+                    if (RGB && ALPHA) {
+                        const float2 r2 = px[2];
+                        diff = __builtin_fmaf(-ref.x, r1.x, diff);
+                        diff = __builtin_fmaf(-ref.y, r1.y, diff);
+                        diff = __builtin_fmaf(-ref.z, r2.x, diff);
+                        diff = __builtin_fmaf(-ref.w, r2.y, diff);
+                    } else if (RGB) {
+                        const float2 r2 = px[2];
+                        diff = __builtin_fmaf(-ref.y, r1.x, diff);
+                        diff = __builtin_fmaf(-ref.z, r1.y, diff);
+                        diff = __builtin_fmaf(-ref.w, r2.x, diff);
+                    } else {
+                        diff = __builtin_fmaf(-ref.x, r1.x, diff);
+                    }
+                    const int fi = __float_as_int(r0.x);
+                    const bool owned = (mode_in ? fi : -2) == own;                   // :707
+                    if (!owned || diff <= 0.0f) continue;                            // :647 / :717
+                    const float t = d1f - cross;
+                    const float e = (0.0f < t) ? eps_f : -eps_f;  // sign(dist) = sign(t), see above
+                    f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(__builtin_fmaf(c0k, t, e)), f0);  // :649-652
+                    f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(__builtin_fmaf(c1k, t, e)), f1);  // :654-657
+                }
+                const double a0 = (flags & 2) ? (double)f0 : 0.0, a1 = (flags & 4) ? (double)f1 : 0.0;  // :648 / :653
+                const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
+                if (slot < ACC_SLOTS) {
+                    if (a0 != 0.0) atomicAdd(&s_acc[3 * slot + v0], a0);
+                    if (a1 != 0.0) atomicAdd(&s_acc[3 * slot + v1], a1);
+                } else if (a0 != 0.0 || a1 != 0.0) {
+                    const int pos = vis_position(vis_list + (size_t)b * F, n_vis, fnr);
+                    double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
+                    if (a0 != 0.0) atomicAdd(dst + 2 * v0, a0);
+                    if (a1 != 0.0) atomicAdd(dst + 2 * v1, a1);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- 5. per-face sums of this chunk -> global double scratch
+        {
+            const int n_slots = min(total_packed >> 20, ACC_SLOTS);
+            if (tid < 3 * n_slots) {
+                const int sl = tid / 3, v = tid - 3 * sl;
+                const double a = s_acc[tid];
+                if (a != 0.0) atomicAdd(scratch + ((size_t)b * F + s_slotpos[sl]) * 6 + 2 * v + (1 - axis), a);
+                s_acc[tid] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__ scratch, const int *__restrict__ slot_of,
+                                                      float *__restrict__ grad_faces, int F, int n_faces_total)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_faces_total) return;
-    const double *a = scratch + (size_t)i * 6;
+    const int pos = slot_of[i];
     float *o = grad_faces + (size_t)i * 9;
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (pos >= 0) {
+        const double *src = scratch + ((size_t)(i / F) * F + pos) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) a[k] = src[k];
+    }
 #pragma unroll
     for (int v = 0; v < 3; v++) {
         o[3 * v + 0] = (float)a[2 * v + 0];
@@ -756,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__
 // ====================================================================================================
 
 struct BpmLayout {
-    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, total, zero_bytes;
+    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, total;
     int n_chunks;
 };
 
@@ -764,33 +1152,32 @@ BpmLayout bpm_layout(int B, int F)
 {
     BpmLayout L;
     const size_t n = (size_t)B * F;
-    L.flags_off = 0;
-    L.scratch_off = align_up(n, 256);                       // flags: n bytes
-    L.zero_bytes = L.scratch_off + n * 6 * sizeof(double);  // flags + scratch are zeroed by one memset
-    L.count_off = align_up(L.zero_bytes, 256);
+    L.flags_off = 0;                                  // n bytes (only used when the caller has no visible_faces)
+    L.scratch_off = align_up(n, 256);                 // n * 6 doubles, indexed by list position
+    L.count_off = align_up(L.scratch_off + n * 6 * sizeof(double), 256);
     L.n_chunks = (F + VIS_CHUNK - 1) / VIS_CHUNK;
     L.chunk_off = L.count_off + align_up((size_t)B * sizeof(int), 256);
     L.list_off = L.chunk_off + align_up((size_t)B * L.n_chunks * sizeof(int), 256);
     L.rng_off = L.list_off + align_up(n * sizeof(int), 256);
-    L.total = L.rng_off + n * 6 * sizeof(unsigned);  // [B][axis][slot][edge]
+    L.slot_off = L.rng_off + align_up(n * 6 * sizeof(unsigned), 256);  // rng: [B][axis][position][edge]
+    L.total = L.slot_off + n * sizeof(int);
     return L;
 }
 
-constexpr size_t BAND_FIXED_LDS = sizeof(BandLine) * BAND_WIN + 12 * BAND_WIN + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 +
-                                  8 * 16;
+constexpr size_t BAND_COMMON_LDS = 12 * BAND_WIN + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16;
+constexpr size_t LDS_BUDGET = 53 * 1024 + 512;  // three workgroups per 160 KB CU
 
 // band width (lines per workgroup) for the given raster size and modes; 0 = does not fit (global fallback)
-int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes)
+int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes)
 {
-    const size_t per_px = 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0);
-    const char *env = getenv("NR_K6_LDS_KB");  // tuning knob: LDS budget per workgroup (default: two per CU)
-    const size_t budget = env ? (size_t)atoi(env) * 1024 : 53 * 1024 + 512;  // three workgroups per 160 KB CU
+    const size_t per_px = exact ? 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0) : (rgb ? 24 : 16);
+    const size_t fixed = BAND_COMMON_LDS + (exact ? sizeof(BandLine) : sizeof(FastLine)) * BAND_WIN;
     const size_t SP = (size_t)S + 4;
     // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
     // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
     for (int W = 4; W >= 1; W >>= 1) {
-        const size_t need = (size_t)W * SP * per_px + BAND_FIXED_LDS;
-        if (need <= budget || (W == 1 && need <= 160 * 1024)) {
+        const size_t need = (size_t)W * SP * per_px + fixed;
+        if (need <= LDS_BUDGET || (W == 1 && need <= 160 * 1024)) {
             *lds_bytes = need;
             return W;
         }
@@ -798,20 +1185,51 @@ int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes)
     return 0;
 }
 
-template <bool RGB, bool ALPHA, bool EXACT, bool POW2>
+// A kernel that asks for more than 48 KB of dynamic LDS has to be told so (hipFuncSetAttribute).  The attribute is sticky,
+// so the largest size granted so far is remembered per kernel instantiation and device and the launch path only makes the
+// runtime call when a launch needs more than that -- in a steady loop, never.  (A cache of an idempotent driver setting,
+// not library state: losing it would only repeat the call.)
+struct LdsLimit {
+    std::atomic<size_t> granted[32];
+    LdsLimit() { for (auto &g : granted) g.store(48 * 1024); }
+    int ensure(const void *kern, size_t lds)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 31;
+        if (lds <= granted[dev].load(std::memory_order_relaxed) && dev != 31) return 0;
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        granted[dev].store(lds, std::memory_order_relaxed);
+        return 0;
+    }
+};
+
+template <bool RGB, bool ALPHA, bool POW2>
 int launch_band(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch, int B,
-                int F, int S, int W, size_t lds, double eps, hipStream_t st)
+                int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
 {
-    auto kern = k_bpm_band<RGB, ALPHA, EXACT, POW2>;
-    if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
+    static LdsLimit limit;  // one per instantiation
+    auto kern = k_bpm_band<RGB, ALPHA, POW2>;
+    if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     const dim3 grid(xcd_grid(total_wg));  // 1-D: the kernel maps ids to (image, axis, band) per XCD
     hipLaunchKernelGGL(kern, grid, dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha, vis_list,
-                       vis_count, rng, scratch, F, S, W, S + 4, eps, B);
+                       vis_count, rng, scratch, F, S, W, S + 4, eps, B, win_lines);
+    return 0;
+}
+
+template <bool RGB, bool ALPHA>
+int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
+                const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch, int B,
+                int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
+{
+    static LdsLimit limit;
+    auto kern = k_bpm_fast<RGB, ALPHA>;
+    if (int rc = limit.ensure((const void *)kern, lds)) return rc;
+    const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
+                       vis_list, vis_count, rng, scratch, F, S, W, S + 4, (float)eps, B, win_lines);
     return 0;
 }
 
@@ -827,8 +1245,8 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
 int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                                const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                                float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
-                               void *workspace, size_t workspace_bytes, hipStream_t st, const int **vis_list_out,
-                               const int **vis_count_out)
+                               int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
+                               hipStream_t st, const int **vis_list_out, const int **vis_count_out)
 {
     if (vis_list_out) *vis_list_out = nullptr;
     if (vis_count_out) *vis_count_out = nullptr;
@@ -840,82 +1258,99 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     if ((size_t)B * S * S > 0x7fffffffull / 3) return NR_E_SIZE;  // int32 pixel indexing inside the kernels
     const int n = B * F;
     const bool rgb = return_rgb != 0, alpha = return_alpha != 0;
+    const bool exact = (flags & NR_FLAG_EXACT_GRADIENT) != 0;
 
     size_t lds = 0;
-    const int W = band_width(S, rgb, alpha, &lds);
-    const char *force = getenv("NR_K6_GLOBAL");  // experiment knob: force the global-memory kernel
-    {
-        if (W == 0 || (force && atoi(force))) {
-            const dim3 grid((unsigned)n), block(WAVE);
-            if (rgb && alpha)
-                hipLaunchKernelGGL((k_bpm_global<true, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
-            else if (rgb)
-                hipLaunchKernelGGL((k_bpm_global<true, false>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
-            else
-                hipLaunchKernelGGL((k_bpm_global<false, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
-                                   alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
-            return launch_status();
-        }
+    const int W = band_width(S, rgb, alpha, exact, &lds);
+    if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
+        const dim3 grid((unsigned)n), block(WAVE);
+        if (rgb && alpha)
+            hipLaunchKernelGGL((k_bpm_global<true, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
+                               alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
+        else if (rgb)
+            hipLaunchKernelGGL((k_bpm_global<true, false>), grid, block, 0, st, faces, face_index_map, rgb_map,
+                               alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
+        else
+            hipLaunchKernelGGL((k_bpm_global<false, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
+                               alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, F, S, eps);
+        return launch_status();
     }
 
     const BpmLayout L = bpm_layout(B, F);
     if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
     unsigned char *ws = (unsigned char *)workspace;
-    unsigned char *flags = ws + L.flags_off;
     double *scratch = (double *)(ws + L.scratch_off);
     int *vis_count = (int *)(ws + L.count_off);
     int *vis_list = (int *)(ws + L.list_off);
+    int *slot_of = (int *)(ws + L.slot_off);
+    unsigned *rng = (unsigned *)(ws + L.rng_off);
     if (vis_list_out) *vis_list_out = vis_list;
     if (vis_count_out) *vis_count_out = vis_count;
-    hipError_t he = hipMemsetAsync(ws, 0, L.zero_bytes, st);
-    if (he != hipSuccess) return (int)he;
-    const size_t P = (size_t)B * S * S;
-    hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, face_index_map, flags, F,
-                       S * S, P);
-    int *chunk_count = (int *)(ws + L.chunk_off);
-    unsigned *rng = (unsigned *)(ws + L.rng_off);
-    hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, flags,
-                       chunk_count, F, L.n_chunks);
-    hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, flags,
-                       chunk_count, vis_list, vis_count, F, L.n_chunks, faces, rng, S);
-    const char *fa = getenv("NR_K6_FAST");  // 1: hardware reciprocal + per-segment float sums (-7 % time)
-    const bool exact = !(fa && atoi(fa));
+    const unsigned char *vflags = visible_faces;
+    if (!vflags) {  // the forward's flags were not kept: one pass over face_index_map rebuilds them
+        unsigned char *f = ws + L.flags_off;
+        const hipError_t he = hipMemsetAsync(f, 0, (size_t)n, st);
+        if (he != hipSuccess) return (int)he;
+        const size_t P = (size_t)B * S * S;
+        hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, face_index_map, f, F,
+                           S * S, P);
+        vflags = f;
+    }
+    if (L.n_chunks <= SMALL_CHUNKS) {
+        hipLaunchKernelGGL(k_compact_small, dim3((unsigned)B), dim3(VIS_CHUNK), 0, st, vflags, vis_list, vis_count, slot_of,
+                           F, L.n_chunks, faces, rng, scratch, S);
+    } else {
+        int *chunk_count = (int *)(ws + L.chunk_off);
+        hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
+                           chunk_count, F, L.n_chunks);
+        hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
+                           chunk_count, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S);
+    }
+    // lines per window: the packed segment scan keeps the count of full segments in 16 bits (<= win * 2 * S / SEG)
+    const int win_lines = max(1, min(BAND_WIN, (int)(65535ll * SEG / (2ll * S))));
     int rc;
-    const bool pow2 = (S & (S - 1)) == 0;
-#define NR_BAND(R, A, E)                                                                                          \
-    (pow2 ? launch_band<R, A, E, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,   \
-                                       vis_list, vis_count, rng, scratch, B, F, S, W, lds, eps, st)                \
-          : launch_band<R, A, E, false>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,  \
-                                        vis_list, vis_count, rng, scratch, B, F, S, W, lds, eps, st))
-    if (rgb && alpha) rc = exact ? NR_BAND(true, true, true) : NR_BAND(true, true, false);
-    else if (rgb) rc = exact ? NR_BAND(true, false, true) : NR_BAND(true, false, false);
-    else rc = exact ? NR_BAND(false, true, true) : NR_BAND(false, true, false);
+    if (exact) {
+        const bool pow2 = (S & (S - 1)) == 0;
+#define NR_BAND(R, A)                                                                                                  \
+    (pow2 ? launch_band<R, A, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list,  \
+                                    vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st)                       \
+          : launch_band<R, A, false>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
+                                     vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st))
+        rc = (rgb && alpha) ? NR_BAND(true, true) : (rgb ? NR_BAND(true, false) : NR_BAND(false, true));
 #undef NR_BAND
+    } else {
+#define NR_FAST(R, A)                                                                                                   \
+    launch_fast<R, A>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, \
+                      scratch, B, F, S, W, lds, eps, win_lines, st)
+        rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
+#undef NR_FAST
+    }
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, grad_faces, n);
+    hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, slot_of, grad_faces,
+                       F, n);
     return launch_status();
 }
 
 NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                                  const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                                  float *grad_faces, int32_t B, int32_t F, int32_t S, double eps, int32_t return_rgb,
-                                 int32_t return_alpha, void *workspace, size_t workspace_bytes, void *stream)
+                                 int32_t return_alpha, int32_t flags, const uint8_t *visible_faces, void *workspace,
+                                 size_t workspace_bytes, void *stream)
 {
     return run_backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, B,
-                                  F, S, eps, return_rgb, return_alpha, workspace, workspace_bytes, (hipStream_t)stream,
-                                  nullptr, nullptr);
+                                  F, S, eps, return_rgb, return_alpha, flags, visible_faces, workspace, workspace_bytes,
+                                  (hipStream_t)stream, nullptr, nullptr);
 }
 
 // Fused backward: K6, K7 and K8 of one Rasterize.backward_gpu call (rasterize.py:849-889) behind one entry point.
 // Same results as calling the three stage functions in the reference's order; the visible-face lists built for
 // K6 are reused by the K7 / K8 gathers, which then visit ~1/5 of the faces.
-NR_API int nr_backward_rasterize(const float *faces, const int32_t *face_index_map, const float *weight_map,
-                                 const float *depth_map, const float *rgb_map, const float *alpha_map,
-                                 const float *grad_rgb_map, const float *grad_alpha_map, const float *grad_depth_map,
-                                 float *grad_faces, float *grad_textures, int32_t B, int32_t F, int32_t S, int32_t ts,
-                                 double eps, int32_t flags, void *workspace, size_t workspace_bytes, void *stream)
+NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, const int32_t *face_index_map,
+                                 const float *weight_map, const float *depth_map, const float *rgb_map,
+                                 const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
+                                 const float *grad_depth_map, float *grad_faces, float *grad_textures, int32_t B,
+                                 int32_t F, int32_t S, int32_t ts, double eps, int32_t flags,
+                                 const uint8_t *visible_faces, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!faces || !face_index_map || !grad_faces) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
@@ -925,8 +1360,8 @@ NR_API int nr_backward_rasterize(const float *faces, const int32_t *face_index_m
     if (use_rgb || use_alpha) {
         if (int rc = run_backward_pixel_map(faces, face_index_map, use_rgb ? rgb_map : nullptr,
                                             use_alpha ? alpha_map : nullptr, grad_rgb_map, grad_alpha_map, grad_faces,
-                                            B, F, S, eps, use_rgb, use_alpha, workspace, workspace_bytes, st, &vis_list,
-                                            &vis_count))
+                                            B, F, S, eps, use_rgb, use_alpha, flags, visible_faces, workspace,
+                                            workspace_bytes, st, &vis_list, &vis_count))
             return rc;
     } else {
         const hipError_t e = hipMemsetAsync(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
@@ -935,8 +1370,8 @@ NR_API int nr_backward_rasterize(const float *faces, const int32_t *face_index_m
     int depth_done = 0;
     if (use_rgb && grad_textures) {
         // when both gradients are wanted, K8 rides along in the K7 gather (one walk of each face's screen box)
-        if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, weight_map, depth_map, grad_rgb_map,
-                                           grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
+        if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, faces_z_ref, weight_map, depth_map,
+                                           grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
                                            use_depth ? grad_depth_map : nullptr, grad_faces, &depth_done))
             return rc;
     }

@@ -239,10 +239,11 @@ inline int launch_status()
 int run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                            const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                            float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
-                           void *workspace, size_t workspace_bytes, hipStream_t st, const int **vis_list_out,
-                           const int **vis_count_out);
+                           int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
+                           hipStream_t st, const int **vis_list_out, const int **vis_count_out);
 int run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
-                          const int32_t *sampling_index_map, const float *faces, const float *weight_map,
+                          const int32_t *sampling_index_map, const float *faces, const float *faces_z_ref,
+                          const float *weight_map,
                           const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F, int S,
                           int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st,
                           const float *g_depth_fused, float *grad_faces_fused, int *depth_done);

@@ -25,9 +25,11 @@ namespace {
 //                    (K2 body) and publishes (depth bits << 32 | face index) with a 64-bit atomicMin on the
 //                    pixel's z-buffer word; faces with a large box are queued;
 //   k_large_raster   queued faces are rasterized by a whole workgroup each (threads stride over the box);
-//   k_resolve        one thread per pixel decodes the winner, re-evaluates its weights (same function, same
-//                    inputs -> same bits) and writes face_index / weight / depth / face_inv maps (every
-//                    element, init values where no face was found, rasterize.py:478-496).
+//   k_resolve        one thread per pixel decodes the winner, re-evaluates its inverse matrix and weights (same
+//                    functions, same inputs -> same bits: the per-face inverses are never stored, which saves
+//                    36 B per face written + 36 B per covered pixel re-read) and writes face_index / weight / depth /
+//                    face_inv maps (every element, init values where no face was found, rasterize.py:478-496) and,
+//                    on request, the per-face "owns a pixel" flags that the backward's K6 pipeline starts from.
 // The packed minimum reproduces the reference's winner rule "smaller zp, ties -> lower face index" (it
 // scans faces in ascending order with a strict `<`, rasterize.py:300,334): zp > near > 0, so the float bit
 // pattern is order-preserving as an unsigned integer.  The result does not depend on the order of the
@@ -85,46 +87,49 @@ __device__ __forceinline__ void raster_pixel(const FaceGeo &g, unsigned fnu, int
         atomicMin(zrow + px, ((unsigned long long)__float_as_uint(zp) << 32) | fnu);
 }
 
-// LPF lanes share one face (they split the rows of its box): 4x more waves than a thread-per-face launch,
-// each with 4x shorter serial loops.  The kernel is bound by the dependent-instruction latency of the IEEE
-// divisions in the K2 body (measured: 13 cycles per VALU instruction at 1.2 waves/SIMD), which more resident
-// waves hide.
-constexpr int LPF = 4;
-
-__global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces, float *__restrict__ ws_inv,
-                                                     unsigned long long *__restrict__ zbuf,
-                                                     int *__restrict__ large_list, int *__restrict__ n_large,
-                                                     int n_faces_total, int F, int S, double near_d, double far_d)
+// vertices -> FaceGeo with the inverse barycentric matrix of K1 (rasterize.py:240-277); zeros for back faces (:240, :253)
+__device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S, FaceGeo &g, float inv[9])
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = t / LPF, sub = t - i * LPF;
-    if (i >= n_faces_total) return;
-    const float *f = faces + (size_t)i * 9;
-    FaceGeo g;
     g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
-    const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
-    float inv[9];
     if (is_backside(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2)) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) inv[k] = 0.0f;  // rasterize.py:240 zeros_like + :253 continue
+        for (int k = 0; k < 9; k++) inv[k] = 0.0f;
     } else {
         const float fs = (float)S;
         const float px[3] = {to_pixel(g.x0, fs), to_pixel(g.x1, fs), to_pixel(g.x2, fs)};
         const float py[3] = {to_pixel(g.y0, fs), to_pixel(g.y1, fs), to_pixel(g.y2, fs)};
         compute_face_inv(px, py, inv);
     }
-    if (sub == 0) {
-        float *o = ws_inv + (size_t)i * 9;
-#pragma unroll
-        for (int k = 0; k < 9; k++) o[k] = inv[k];
-    }
-    if (cd.n == 0) return;
-    if (cd.strip || cd.n > SMALL_AREA) {  // strips (needles) and large boxes: a whole workgroup each, k_large_raster
-        if (sub == 0) large_list[atomicAdd(n_large, 1)] = i;
-        return;
-    }
     g.i0 = inv[0]; g.i1 = inv[1]; g.i2 = inv[2]; g.i3 = inv[3]; g.i4 = inv[4]; g.i5 = inv[5];
     g.i6 = inv[6]; g.i7 = inv[7]; g.i8 = inv[8];
+}
+
+// LPF lanes share one face (they split the rows of its box): 4x more waves than a thread-per-face launch,
+// each with 4x shorter serial loops.  The kernel is bound by the dependent-instruction latency of the IEEE
+// divisions in the K2 body (measured: 13 cycles per VALU instruction at 1.2 waves/SIMD), which more resident
+// waves hide.
+constexpr int LPF = 4;
+
+__global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces,
+                                                     unsigned long long *__restrict__ zbuf,
+                                                     int *__restrict__ large_list, int *__restrict__ n_large,
+                                                     unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
+                                                     int S, double near_d, double far_d)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t / LPF, sub = t - i * LPF;
+    if (i >= n_faces_total) return;
+    if (visible_faces && sub == 0) visible_faces[i] = 0;  // k_resolve raises the flags of the faces that win a pixel
+    const float *f = faces + (size_t)i * 9;
+    const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+    if (cd.n == 0) return;  // back faces, off-screen faces, coincident vertices
+    if (cd.strip || cd.n > SMALL_AREA) {  // strips (needles) and large boxes: a whole workgroup each, k_large_raster
+        if (sub == 0) large_list[atomicAdd(n_large, 1) + 1] = i;  // the counter starts at -1 (one fill with the z-buffer)
+        return;
+    }
+    FaceGeo g;
+    float inv[9];
+    load_face_geo(f, S, g, inv);
     const int b = i / F;
     const unsigned fnu = (unsigned)(i - b * F);
     unsigned long long *zimg = zbuf + (size_t)b * S * S;
@@ -139,20 +144,19 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     }
 }
 
-__global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces, const float *__restrict__ ws_inv,
+__global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces,
                                                       unsigned long long *__restrict__ zbuf,
                                                       const int *__restrict__ large_list,
                                                       const int *__restrict__ n_large, int F, int S, double near_d,
                                                       double far_d)
 {
-    const int n = *n_large;
+    const int n = *n_large + 1;  // the counter starts at -1
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
         const int i = large_list[j];
         const float *f = faces + (size_t)i * 9;
-        const float *iv = ws_inv + (size_t)i * 9;
         FaceGeo g;
-        g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
-        g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5]; g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
+        float inv[9];
+        load_face_geo(f, S, g, inv);
         const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
         const int b = i / F;
         const unsigned fnu = (unsigned)(i - b * F);
@@ -169,8 +173,9 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
 // F3: shading, one pixel per thread (linear pixel index: fully coalesced map traffic).
 // Shading of one pixel (K4 + K5, rasterize.py:361-465): shared by k_shade and the fused k_resolve.
 __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, float w1, float w2, float depth,
-                                            const float *__restrict__ faces, const float *__restrict__ textures,
-                                            float *__restrict__ rgb_map, int32_t *__restrict__ sampling_index_map,
+                                            const float *__restrict__ faces, const float *__restrict__ zbase,
+                                            const float *__restrict__ textures, float *__restrict__ rgb_map,
+                                            int32_t *__restrict__ sampling_index_map,
                                             float *__restrict__ sampling_weight_map,
                                             const float *__restrict__ background, int bg_per_batch,
                                             float *__restrict__ alpha_map, int F, int ts, double eps, int fix_batch_z)
@@ -180,7 +185,8 @@ __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, f
     float rgb[3];
     Taps t;
     if (fi >= 0) {
-        const float *face = faces + ((size_t)(fix_batch_z ? b : 0) * F + fi) * 9;  // :389 (Q1)
+        // :389 (Q1): the reference reads batch element 0's geometry here; zbase = that element's faces (of the GLOBAL batch)
+        const float *face = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fi * 9;
         const float *texture = textures + ((size_t)b * F + fi) * ts * ts * ts * 3;   // :390
         const float w[3] = {w0, w1, w2};
         const float fz[3] = {face[2], face[5], face[8]};
@@ -221,7 +227,8 @@ __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, f
     }
 }
 
-__global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, const float *__restrict__ textures,
+__global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, const float *__restrict__ zbase,
+                                               const float *__restrict__ textures,
                                                const int32_t *__restrict__ face_index_map,
                                                const float *__restrict__ weight_map,
                                                const float *__restrict__ depth_map, float *__restrict__ rgb_map,
@@ -237,26 +244,28 @@ __global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, 
     const int b = (int)(i / ((size_t)S * S));
     float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, depth = 0.0f;
     if (rgb_map && fi >= 0) { w0 = weight_map[3 * i]; w1 = weight_map[3 * i + 1]; w2 = weight_map[3 * i + 2]; depth = depth_map[i]; }
-    shade_pixel(i, b, fi, w0, w1, w2, depth, faces, textures, rgb_map, sampling_index_map, sampling_weight_map, background,
-                bg_per_batch, alpha_map, F, ts, eps, fix_batch_z);
+    shade_pixel(i, b, fi, w0, w1, w2, depth, faces, zbase, textures, rgb_map, sampling_index_map, sampling_weight_map,
+                background, bg_per_batch, alpha_map, F, ts, eps, fix_batch_z);
 }
 
-__global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces, const float *__restrict__ ws_inv,
+__global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces,
                                                  const unsigned long long *__restrict__ zbuf,
                                                  int32_t *__restrict__ face_index_map, float *__restrict__ weight_map,
                                                  float *__restrict__ depth_map, float *__restrict__ face_inv_map,
-                                                 int F, int S, double near_d, double far_d, size_t n_pixels,
+                                                 unsigned char *__restrict__ visible_faces, int F, int S, double near_d,
+                                                 double far_d, size_t n_pixels,
                                                  // fused shading (all NULL / 0 when not requested)
-                                                 const float *__restrict__ textures, float *__restrict__ rgb_map,
-                                                 const float *__restrict__ background, int bg_per_batch,
-                                                 float *__restrict__ alpha_map, int ts, double eps, int fix_batch_z)
+                                                 const float *__restrict__ zbase, const float *__restrict__ textures,
+                                                 float *__restrict__ rgb_map, const float *__restrict__ background,
+                                                 int bg_per_batch, float *__restrict__ alpha_map, int ts, double eps,
+                                                 int fix_batch_z)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
     const unsigned long long pk = zbuf[i];
     int fn = -1;
     float zp = (float)far_d, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;  // rasterize.py:296, :478-480
-    const float *iv = nullptr;
+    float inv[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     int b = 0;
     if (rgb_map || alpha_map) b = (int)(i / ((size_t)S * S));
     if (pk != ZEMPTY) {
@@ -265,12 +274,10 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
         b = (int)(i / SS);
         const int pn = (int)(i - (size_t)b * SS);
         const int py = pn / S, px = pn - py * S;
-        const float *f = faces + ((size_t)b * F + fn) * 9;
-        iv = ws_inv + ((size_t)b * F + fn) * 9;
         FaceGeo g;
-        g.x0 = f[0]; g.y0 = f[1]; g.z0 = f[2]; g.x1 = f[3]; g.y1 = f[4]; g.z1 = f[5]; g.x2 = f[6]; g.y2 = f[7]; g.z2 = f[8];
-        g.i0 = iv[0]; g.i1 = iv[1]; g.i2 = iv[2]; g.i3 = iv[3]; g.i4 = iv[4]; g.i5 = iv[5]; g.i6 = iv[6]; g.i7 = iv[7]; g.i8 = iv[8];
+        load_face_geo(faces + ((size_t)b * F + fn) * 9, S, g, inv);
         eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, near_d, far_d, zp, w0, w1, w2);
+        if (visible_faces) visible_faces[(size_t)b * F + fn] = 1;  // same value from every pixel of the face: no atomic
     }
     face_index_map[i] = fn;
     if (depth_map) depth_map[i] = zp;
@@ -283,11 +290,11 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
     if (face_inv_map) {
         float *o = face_inv_map + 9 * i;
 #pragma unroll
-        for (int k = 0; k < 9; k++) o[k] = (fn >= 0) ? iv[k] : 0.0f;
+        for (int k = 0; k < 9; k++) o[k] = inv[k];
     }
     if (rgb_map || alpha_map)
-        shade_pixel(i, b, fn, w0, w1, w2, zp, faces, textures, rgb_map, nullptr, nullptr, background, bg_per_batch, alpha_map,
-                    F, ts, eps, fix_batch_z);
+        shade_pixel(i, b, fn, w0, w1, w2, zp, faces, zbase, textures, rgb_map, nullptr, nullptr, background, bg_per_batch,
+                    alpha_map, F, ts, eps, fix_batch_z);
 }
 
 }  // namespace
@@ -303,22 +310,23 @@ NR_API const char *nr_error_string(int code)
         case NR_E_SIZE: return "nr: size out of range";
         case NR_E_WORKSPACE: return "nr: workspace missing or too small";
         case NR_E_MODE: return "nr: nothing to do / inconsistent optional arguments";
+        case NR_E_NEAR: return "nr: near must be > 0 (the z-buffer packs positive depths; the reference default is 0.1)";
+        case NR_E_INDEX: return "nr: a vertex index lies outside [0, num_vertices)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "nr: unknown error";
     }
 }
 
 namespace {
 struct FwdLayout {
-    size_t inv_off, zbuf_off, list_off, count_off, total;
+    size_t zbuf_off, list_off, count_off, total;
 };
 FwdLayout fwd_layout(int B, int F, int S)
 {
     FwdLayout L;
     const size_t n = (size_t)B * F, P = (size_t)B * S * S;
-    L.inv_off = 0;
-    L.zbuf_off = align_up(n * 9 * sizeof(float), 256);
+    L.zbuf_off = 0;
     L.count_off = L.zbuf_off + P * sizeof(unsigned long long);  // the counter sits right behind the z-buffer
-    L.list_off = align_up(L.count_off + sizeof(int), 256);
+    L.list_off = align_up(L.count_off + sizeof(long long), 256);
     L.total = L.list_off + n * sizeof(int);
     return L;
 }
@@ -332,67 +340,66 @@ NR_API size_t nr_forward_workspace_bytes(int32_t B, int32_t F, int32_t S)
 
 namespace {
 int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map, float *face_inv_map,
-                int B, int F, int S, double near, double far, void *workspace, size_t workspace_bytes, hipStream_t st,
-                const float *textures, float *rgb_map, const float *background, int bg_per_batch, float *alpha_map,
-                int ts, double eps, int fix_batch_z)
+                unsigned char *visible_faces, int B, int F, int S, double near, double far, void *workspace,
+                size_t workspace_bytes, hipStream_t st, const float *faces_z_ref, const float *textures, float *rgb_map,
+                const float *background, int bg_per_batch, float *alpha_map, int ts, double eps, int fix_batch_z)
 {
     if (!faces || !face_index_map) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
-    if (!(near > 0.0)) return NR_E_SIZE;  // the packed z-buffer needs positive depths (reference default 0.1)
+    if (!(near > 0.0)) return NR_E_NEAR;  // the packed z-buffer needs positive depths (reference default 0.1)
     const FwdLayout L = fwd_layout(B, F, S);
     if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
     const size_t n = (size_t)B * F, P = (size_t)B * S * S;
     unsigned char *ws = (unsigned char *)workspace;
-    float *ws_inv = (float *)(ws + L.inv_off);
     unsigned long long *zbuf = (unsigned long long *)(ws + L.zbuf_off);
     int *n_large = (int *)(ws + L.count_off);
     int *large_list = (int *)(ws + L.list_off);
 
-    // ZEMPTY words and, right behind them, the large-face counter (0xffffffff + 1 == 0 would also do, but keep it plain)
-    hipError_t he = hipMemsetAsync(zbuf, 0xff, P * sizeof(unsigned long long), st);
+    // one fill: ZEMPTY words and, right behind them, the large-face counter at -1
+    const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
     if (he != hipSuccess) return (int)he;
-    he = hipMemsetAsync(n_large, 0, sizeof(int), st);
-    if (he != hipSuccess) return (int)he;
-    hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
-                       large_list, n_large, (int)n, F, S, near, far);
-    // 8 workgroups per CU loop over the queue (one per CU left the kernel latency-bound: config 4, 189 -> ~85 us)
-    hipLaunchKernelGGL(k_large_raster, dim3(2048), dim3(256), 0, st, faces, ws_inv, zbuf, large_list, n_large, F, S,
-                       near, far);
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, ws_inv, zbuf,
-                       face_index_map, weight_map, depth_map, face_inv_map, F, S, near, far, P, textures, rgb_map,
-                       background, bg_per_batch, alpha_map, ts, eps, fix_batch_z);
+    hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
+                       n_large, visible_faces, (int)n, F, S, near, far);
+    // a few workgroups per CU loop over the queue (one per CU left the kernel latency-bound: config 4, 189 -> ~85 us);
+    // with an empty queue (any ordinary mesh) they read the counter and leave
+    hipLaunchKernelGGL(k_large_raster, dim3(1024), dim3(256), 0, st, faces, zbuf, large_list, n_large, F, S, near, far);
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, zbuf, face_index_map,
+                       weight_map, depth_map, face_inv_map, visible_faces, F, S, near, far, P,
+                       faces_z_ref ? faces_z_ref : faces, textures, rgb_map, background, bg_per_batch, alpha_map, ts, eps,
+                       fix_batch_z);
     return launch_status();
 }
 }  // namespace
 
 NR_API int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map,
-                                     float *face_inv_map, int32_t B, int32_t F, int32_t S, double near, double far,
-                                     void *workspace, size_t workspace_bytes, void *stream)
+                                     float *face_inv_map, uint8_t *visible_faces, int32_t B, int32_t F, int32_t S,
+                                     double near, double far, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return run_forward(faces, face_index_map, weight_map, depth_map, face_inv_map, B, F, S, near, far, workspace,
-                       workspace_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, 0, nullptr, 0, 0.0, 0);
+    return run_forward(faces, face_index_map, weight_map, depth_map, face_inv_map, visible_faces, B, F, S, near, far,
+                       workspace, workspace_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0,
+                       0.0, 0);
 }
 
 // Fused forward = Rasterize.forward_gpu (rasterize.py:467-513): visibility, texture sampling, background and alpha
 // behind one entry point; the shading runs inside the resolve pass, on the winner still in registers.
-NR_API int nr_forward_rasterize(const float *faces, const float *textures, int32_t *face_index_map, float *weight_map,
-                                float *depth_map, float *rgb_map, float *alpha_map, const float *background,
-                                int32_t bg_per_batch, int32_t B, int32_t F, int32_t S, int32_t ts, double near,
-                                double far, double eps, int32_t flags, void *workspace, size_t workspace_bytes,
-                                void *stream)
+NR_API int nr_forward_rasterize(const float *faces, const float *faces_z_ref, const float *textures,
+                                int32_t *face_index_map, float *weight_map, float *depth_map, float *rgb_map,
+                                float *alpha_map, uint8_t *visible_faces, const float *background, int32_t bg_per_batch,
+                                int32_t B, int32_t F, int32_t S, int32_t ts, double near, double far, double eps,
+                                int32_t flags, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (rgb_map) {
         if (!textures || !background) return NR_E_NULL;
         if (ts < 2 || ts > 1024) return NR_E_SIZE;
     }
-    return run_forward(faces, face_index_map, weight_map, depth_map, nullptr, B, F, S, near, far, workspace,
-                       workspace_bytes, (hipStream_t)stream, textures, rgb_map, background, bg_per_batch, alpha_map, ts,
-                       eps, (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0);
+    return run_forward(faces, face_index_map, weight_map, depth_map, nullptr, visible_faces, B, F, S, near, far,
+                       workspace, workspace_bytes, (hipStream_t)stream, faces_z_ref, textures, rgb_map, background,
+                       bg_per_batch, alpha_map, ts, eps, (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0);
 }
 
-NR_API int nr_forward_texture_sampling(const float *faces, const float *textures, const int32_t *face_index_map,
-                                       const float *weight_map, const float *depth_map, float *rgb_map,
-                                       int32_t *sampling_index_map, float *sampling_weight_map,
+NR_API int nr_forward_texture_sampling(const float *faces, const float *faces_z_ref, const float *textures,
+                                       const int32_t *face_index_map, const float *weight_map, const float *depth_map,
+                                       float *rgb_map, int32_t *sampling_index_map, float *sampling_weight_map,
                                        const float *background, int32_t bg_per_batch, float *alpha_map, int32_t B,
                                        int32_t F, int32_t S, int32_t ts, double eps, int32_t flags, void *stream)
 {
@@ -405,9 +412,9 @@ NR_API int nr_forward_texture_sampling(const float *faces, const float *textures
         if ((sampling_index_map == nullptr) != (sampling_weight_map == nullptr)) return NR_E_MODE;
     }
     const size_t n = (size_t)B * S * S;
-    hipLaunchKernelGGL(k_shade, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, textures,
-                       face_index_map, weight_map, depth_map, rgb_map, sampling_index_map, sampling_weight_map,
-                       background, bg_per_batch, alpha_map, F, S, ts, eps,
+    hipLaunchKernelGGL(k_shade, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces,
+                       faces_z_ref ? faces_z_ref : faces, textures, face_index_map, weight_map, depth_map, rgb_map,
+                       sampling_index_map, sampling_weight_map, background, bg_per_batch, alpha_map, F, S, ts, eps,
                        (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, n);
     return launch_status();
 }

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_forward(const float *__
     float w[3][3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const float *src = vb + (size_t)idx[k] * 3;
+        const float *src = vb + (size_t)min(max(idx[k], 0), Nv - 1) * 3;  // validated on the host; clamped for memory safety
         w[k][0] = src[0];
         w[k][1] = src[1];
         w[k][2] = src[2];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_backward(
     if (live) {
         const int32_t *idx = faces_idx + ((size_t)(P.idx_per_batch ? b : 0) * Nf + f) * 3;
         const float *vb = vertices + (size_t)b * Nv * 3;
-        const int vi[3] = {idx[0], idx[1], idx[2]};
+        const int vi[3] = {min(max(idx[0], 0), Nv - 1), min(max(idx[1], 0), Nv - 1), min(max(idx[2], 0), Nv - 1)};
         float w[3][3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {

@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void k_vertices_to_faces(const float *__restri
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_corners) return;
     const size_t b = i / corners_per_batch;
-    const int32_t v = faces_idx[idx_per_batch ? i : i - b * corners_per_batch];
+    // indices are validated on the host (IndexError, like the reference's get_item); the clamp only keeps a bad index that
+    // slipped through a raw C-ABI caller inside the buffer
+    const int32_t v = min(max(faces_idx[idx_per_batch ? i : i - b * corners_per_batch], 0), Nv - 1);
     const float *src = vertices + ((size_t)b * Nv + v) * 3;
     float *dst = out + i * 3;
     dst[0] = src[0];
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void k_vertices_to_faces_backward(const float 
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_corners) return;
     const size_t b = i / corners_per_batch;
-    const int32_t v = faces_idx[idx_per_batch ? i : i - b * corners_per_batch];
+    const int32_t v = min(max(faces_idx[idx_per_batch ? i : i - b * corners_per_batch], 0), Nv - 1);
     const float *g = grad_faces + i * 3;
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     float *dst = grad_vertices + ((size_t)b * Nv + v) * 3;

@@ -10,9 +10,12 @@ each rendering views [start, stop) of the global batch.  Two optional collective
   all_reduce_shared_grads   when mesh parameters are shared by all views (reference mesh.py:29-34 broadcasts
                       them), their gradients are summed over ranks -- a tiny [Nv,3] / [F,ts^3,3] all-reduce.
 
-Note on SURVEY quirk Q1: the reference samples textures with the face depth of *batch element 0*; under
-sharding that means "the first view of the local shard".  Use fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) when
-views differ in geometry and textures are non-uniform.
+SURVEY quirk Q1 under sharding: the reference samples textures with the vertex depths of *batch element 0*
+(rasterize.py:389).  A shard's element 0 is not the global one, so a sharded run with per-view cameras and non-uniform
+textures (BASELINE configs 2 and 4) would differ from the unsharded run.  `broadcast_reference_faces` ships rank 0's
+first projected view to every rank once per step (F*36 bytes: 177 KB for the teapot); passed as `Rasterize.faces_z_ref` /
+`Renderer.faces_z_ref` / `rasterize(..., faces_z_ref=)` it makes sharded and unsharded outputs and gradients identical
+bit for bit (tests/test_sharding_gpu.py).  With fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) nothing needs to be exchanged.
 """
 import os
 
@@ -55,8 +58,21 @@ def shard_bounds(total, rank, world):
 
 
 def shard(tensor, rank, world, dim=0):
+    """Rank `rank`'s slice of `tensor` along `dim`.  With fewer views than ranks the trailing ranks get an EMPTY slice:
+    the rasterizer needs at least one view per call (NR_E_SIZE), so such ranks must skip the render."""
     start, stop = shard_bounds(tensor.shape[dim], rank, world)
     return tensor.narrow(dim, start, stop - start)
+
+
+def broadcast_reference_faces(projected_faces, src=0):
+    """[F,3,3] faces of the GLOBAL batch element 0 on every rank: rank `src` (the owner of view 0) contributes
+    `projected_faces[0]` of its shard [b,F,3,3] (the rasterizer's input, i.e. after look_at / perspective /
+    vertices_to_faces).  One tiny broadcast; not differentiable (the reference back-propagates nothing through these
+    depths either: K7 treats the sampling weights as constants)."""
+    ref = projected_faces[0].detach().contiguous().clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(ref, src=src)
+    return ref
 
 
 def all_gather_images(images, total=None):
@@ -90,6 +106,9 @@ def all_reduce_shared_grads(parameters):
     """Sum the gradients of parameters shared by all views (vertices / textures of one mesh) over the ranks."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return
+    # every rank must issue the same sequence of collectives: a parameter without a gradient on this rank (an unused
+    # output, a shard in which the mesh is not visible) contributes zeros instead of being skipped
     for p in parameters:
-        if p.grad is not None:
-            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)

@@ -13,7 +13,7 @@ light colours -- keeps the module-by-module torch path of renderer.py, which mir
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, _util
 
 
 def _vec3(value):
@@ -68,7 +68,33 @@ def fusable(renderer, vertices, faces, textures):
     return True
 
 
+_STRUCT_CACHE = {}
+
+
+def _cached(kind, key, make):
+    """Camera / light structs per distinct parameter set: a fixed-shape optimisation loop (example 2, B = 1) is bound by
+    host time, and rebuilding two ctypes structs through NumPy costs more than the kernel they parameterise."""
+    k = (kind,) + key
+    v = _STRUCT_CACHE.get(k)
+    if v is None:
+        if len(_STRUCT_CACHE) > 128:
+            _STRUCT_CACHE.clear()
+        v = _STRUCT_CACHE[k] = make()
+    return v
+
+
+def _hashable(v):
+    return tuple(np.asarray(v, dtype=np.float64).reshape(-1).tolist())
+
+
 def _camera_struct(renderer):
+    key = (renderer.camera_mode, bool(renderer.perspective),
+           float(renderer.viewing_angle) if renderer.perspective else 0.0,
+           _hashable(renderer.camera_direction) if renderer.camera_mode == 'look' else ())
+    return _cached('camera', key, lambda: _make_camera_struct(renderer))
+
+
+def _make_camera_struct(renderer):
     cam = _lib.Camera()
     if renderer.camera_mode == 'look_at':
         cam.mode = _lib.NR_CAMERA_LOOK_AT
@@ -88,6 +114,13 @@ def _camera_struct(renderer):
 
 
 def _light_struct(renderer):
+    key = (float(renderer.light_intensity_ambient), float(renderer.light_intensity_directional),
+           _hashable(renderer.light_color_ambient), _hashable(renderer.light_color_directional),
+           _hashable(renderer.light_direction))
+    return _cached('light', key, lambda: _make_light_struct(renderer))
+
+
+def _make_light_struct(renderer):
     light = _lib.Light()
     light.intensity_ambient = float(renderer.light_intensity_ambient)
     light.intensity_directional = float(renderer.light_intensity_directional)
@@ -176,6 +209,7 @@ def _eye_tensor(eye, device):
 
 def project_and_light(renderer, vertices, faces, textures=None):
     """-> (faces [B,F,3,3], lit textures | None) for the rasterizer; call only when fusable(...)."""
+    _util.check_face_indices(faces, vertices.shape[1], vertices.device)
     camera = _camera_struct(renderer)
     light = _light_struct(renderer) if textures is not None else None
     eye = _eye_tensor(renderer.eye, vertices.device)

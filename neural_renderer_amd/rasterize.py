@@ -33,6 +33,11 @@ if 'NEURAL_RENDERER_UNSAFE' in os.environ and int(os.environ['NEURAL_RENDERER_UN
 # attribute of a Rasterize instance) uses the pixel's own batch element.
 FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 
+# K6 (backward_pixel_map) numerics.  Default: float terms through the hardware reciprocal, <= 1e-5 from the reference's
+# terms summed exactly (north star tolerance 1e-4).  NR_EXACT_GRADIENT=1 (read once, here) or the `exact_gradient`
+# attribute of a Rasterize instance: every term with the reference's own arithmetic, <= 2e-6, ~1.7x the K6 time.
+EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
+
 
 def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
@@ -110,14 +115,26 @@ class _RasterizeFunction(torch.autograd.Function):
             if return_alpha:
                 alpha_map = torch.empty((B, S, S), dtype=torch.float32, device=dev)
             flags = _lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg['fix_batch_z'] else 0
+            if cfg['exact_gradient']:
+                flags |= _lib.NR_FLAG_EXACT_GRADIENT
+            # batch element 0 of the GLOBAL batch when this call holds a shard of it (include/nr_hip.h)
+            z_ref = cfg.get('faces_z_ref')
+            if z_ref is not None:
+                z_ref = z_ref.detach().to(device=dev, dtype=torch.float32).contiguous()
+                if tuple(z_ref.shape) != (F, 3, 3):
+                    raise ValueError('faces_z_ref must have shape (num of faces, 3, 3), got %s' % (tuple(z_ref.shape),))
+            # per-face "owns a pixel" flags: a residual the K6 pipeline of the backward starts from
+            visible = torch.empty((B, F), dtype=torch.uint8, device=dev) if (return_rgb or return_alpha) else None
             # visibility + shading behind one call (rasterize.py:499-502)
             _lib.check(lib.nr_forward_rasterize(
-                faces_c.data_ptr(), _lib.ptr(textures_c), face_index_map.data_ptr(), _lib.ptr(weight_map),
-                _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(alpha_map), _lib.ptr(background), bg_per_batch,
-                B, F, S, ts, float(cfg['near']), float(cfg['far']), float(cfg['eps']), flags, workspace.data_ptr(),
-                ws_bytes, stream), 'nr_forward_rasterize')
+                faces_c.data_ptr(), _lib.ptr(z_ref), _lib.ptr(textures_c), face_index_map.data_ptr(),
+                _lib.ptr(weight_map), _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(alpha_map), _lib.ptr(visible),
+                _lib.ptr(background), bg_per_batch, B, F, S, ts, float(cfg['near']), float(cfg['far']),
+                float(cfg['eps']), flags, workspace.data_ptr(), ws_bytes, stream), 'nr_forward_rasterize')
 
         ctx.cfg = dict(cfg, B=B, F=F, S=S, ts=ts, flags=flags)
+        ctx.z_ref = z_ref
+        ctx.visible = visible
         ctx.set_materialize_grads(False)  # an unused output arrives as `None` in backward and its terms are skipped
         # residuals (the reference keeps them on `self`, rasterize.py:39-58); outputs among them go through
         # save_for_backward so that in-place edits by the caller are detected
@@ -157,12 +174,12 @@ class _RasterizeFunction(torch.autograd.Function):
             workspace = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             # K6 -> K7 -> K8 (rasterize.py:881-883) behind one call
             _lib.check(lib.nr_backward_rasterize(
-                faces_c.data_ptr(), face_index_map.data_ptr(), _lib.ptr(weight_map), _lib.ptr(depth_map),
-                _lib.ptr(rgb_map) if use_rgb else None, _lib.ptr(alpha_map) if use_alpha else None,
+                faces_c.data_ptr(), _lib.ptr(ctx.z_ref), face_index_map.data_ptr(), _lib.ptr(weight_map),
+                _lib.ptr(depth_map), _lib.ptr(rgb_map) if use_rgb else None, _lib.ptr(alpha_map) if use_alpha else None,
                 _lib.ptr(g_rgb) if use_rgb else None, _lib.ptr(g_alpha) if use_alpha else None,
                 _lib.ptr(g_depth) if use_depth else None, grad_faces.data_ptr(), _lib.ptr(grad_textures),
-                B, F, S, ts, float(cfg['eps']), cfg['flags'], workspace.data_ptr(), ws_bytes, stream),
-                'nr_backward_rasterize')
+                B, F, S, ts, float(cfg['eps']), cfg['flags'], _lib.ptr(ctx.visible), workspace.data_ptr(), ws_bytes,
+                stream), 'nr_backward_rasterize')
         return grad_faces, grad_textures, None
 
 
@@ -231,6 +248,10 @@ class Rasterize(object):
         self.return_alpha = return_alpha
         self.return_depth = return_depth
         self.fix_batch_z = FIX_TEXTURE_BATCH_Z
+        self.exact_gradient = EXACT_GRADIENT
+        # [F,3,3] faces of the global batch element 0 when this call renders a shard of a larger batch (SURVEY Q1:
+        # the reference samples textures with batch element 0's depths); None = element 0 of this call
+        self.faces_z_ref = None
         self.face_index_map = None
 
     def __call__(self, faces, textures=None):
@@ -238,7 +259,8 @@ class Rasterize(object):
                    background_color=self.background_color if self.background_color is not None
                    else DEFAULT_BACKGROUND_COLOR,
                    return_rgb=bool(self.return_rgb), return_alpha=bool(self.return_alpha),
-                   return_depth=bool(self.return_depth), fix_batch_z=bool(self.fix_batch_z))
+                   return_depth=bool(self.return_depth), fix_batch_z=bool(self.fix_batch_z),
+                   exact_gradient=bool(self.exact_gradient), faces_z_ref=self.faces_z_ref)
         if not self.return_rgb:
             textures = None
         rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg)
@@ -258,15 +280,17 @@ def rasterize_rgbad(
         return_rgb=True,
         return_alpha=True,
         return_depth=True,
+        faces_z_ref=None,
 ):
     """RGB, alpha and depth images from faces (and textures for RGB) -- reference rasterize.py:900-977.
 
     Returns a dict with 'rgb' [B, 3, image_size, image_size], 'alpha' and 'depth' [B, image_size, image_size]
-    (None when not requested)."""
+    (None when not requested).  `faces_z_ref` (not in the reference): see Rasterize.faces_z_ref."""
     inputs = [faces] if textures is None else [faces, textures]
     size = image_size * 2 if anti_aliasing else image_size  # 2x super-sampling, :945-951
-    rgb, alpha, depth = Rasterize(size, near, far, eps, background_color, return_rgb, return_alpha,
-                                  return_depth)(*inputs)
+    fn = Rasterize(size, near, far, eps, background_color, return_rgb, return_alpha, return_depth)
+    fn.faces_z_ref = faces_z_ref
+    rgb, alpha, depth = fn(*inputs)
     # transpose & vertical flip (:953-960) and 0.5x down-sampling (:962-969): one HIP kernel per direction
     rgb, alpha, depth = _ImageEpilogue.apply(rgb, alpha, depth, bool(anti_aliasing))
     return {
@@ -285,10 +309,12 @@ def rasterize(
         far=DEFAULT_FAR,
         eps=DEFAULT_EPS,
         background_color=DEFAULT_BACKGROUND_COLOR,
+        faces_z_ref=None,
 ):
     """RGB images [B, 3, image_size, image_size] -- reference rasterize.py:980-1008."""
     return rasterize_rgbad(
-        faces, textures, image_size, anti_aliasing, near, far, eps, background_color, True, False, False)['rgb']
+        faces, textures, image_size, anti_aliasing, near, far, eps, background_color, True, False, False,
+        faces_z_ref=faces_z_ref)['rgb']
 
 
 def rasterize_silhouettes(
@@ -316,9 +342,10 @@ def rasterize_depth(
 
 
 def use_unsafe_rasterizer(flag):
-    """Kept for API compatibility (rasterize.py:1063-1065).  The reference's "unsafe" kernel is a
-    per-face scan conversion with a per-pixel spin lock and an order-dependent tie rule; this
-    implementation's only rasterizer already culls by screen-space boxes and is deterministic, so the
-    flag selects nothing."""
+    """Kept for API compatibility (rasterize.py:1063-1065, env NEURAL_RENDERER_UNSAFE :15-16).  The reference's "unsafe"
+    kernel (K3, :102-236) is a per-face scan conversion with a per-pixel spin lock: same coverage and face indices as
+    the safe path, an order-dependent tie rule and weights that differ at the 1e-4 level.  The face-parallel
+    rasterizer here already is O(sum of screen boxes) -- what K3 buys the reference -- and deterministic, so both settings
+    run it and give bit-identical outputs (tests/test_hip_parity.py::test_unsafe_rasterizer_flag_is_equivalent)."""
     global USE_UNSAFE_IMPLEMENTATION
     USE_UNSAFE_IMPLEMENTATION = flag

@@ -43,6 +43,14 @@ class Renderer(object):
         # rasterization
         self.rasterizer_eps = 1e-3
 
+        # not in the reference: which implementation of the chain in front of the rasterizer the calls took -- 'fused'
+        # (one HIP kernel per direction, frontend.py) or 'torch' (module by module).  A benchmark asserts on this so that it
+        # cannot fall onto the ~160-launch path unnoticed.
+        self.last_frontend = None
+        self.frontend_calls = {'fused': 0, 'torch': 0}
+        # [F,3,3] faces of the global batch element 0 when this renderer draws a shard of a larger batch
+        self.faces_z_ref = None
+
     def _project(self, vertices, faces):
         """camera + perspective + gather (renderer.py:40-51, :60-71, :92-103)."""
         if self.camera_mode == 'look_at':
@@ -73,7 +81,10 @@ class Renderer(object):
 
     def _frontend(self, vertices, faces, textures=None):
         """-> (faces [B,F,3,3], lit textures | None): the fused HIP front-end when the call fits it, else torch."""
-        if frontend.fusable(self, vertices, faces, textures):
+        fused = frontend.fusable(self, vertices, faces, textures)
+        self.last_frontend = 'fused' if fused else 'torch'
+        self.frontend_calls[self.last_frontend] += 1
+        if fused:
             return frontend.project_and_light(self, vertices, faces, textures)
         return self._frontend_torch(vertices, faces, textures)
 
@@ -90,4 +101,4 @@ class Renderer(object):
         faces, textures = self._frontend(vertices, faces, textures)
         return rasterize(
             faces, textures, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
-            self.background_color)
+            self.background_color, faces_z_ref=self.faces_z_ref)

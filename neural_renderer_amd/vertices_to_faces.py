@@ -6,7 +6,7 @@ atomics instead of torch's sort-based `index_put_(accumulate=True)`, which alone
 (scripts/glue_profile.py).  CPU tensors (host-side glue, tests) take the plain torch path."""
 import torch
 
-from . import _lib
+from . import _lib, _util
 
 
 class _VerticesToFaces(torch.autograd.Function):
@@ -53,6 +53,7 @@ def vertices_to_faces(vertices, faces):
     assert faces.shape[2] == 3
 
     if vertices.is_cuda and vertices.dtype == torch.float32:
+        _util.check_face_indices(faces, vertices.shape[1], vertices.device)  # IndexError / ValueError, cached per tensor
         return _VerticesToFaces.apply(vertices, faces)
     bs, nv = vertices.shape[:2]
     faces = faces.long() + (torch.arange(bs, device=vertices.device, dtype=torch.long) * nv)[:, None, None]

@@ -24,14 +24,40 @@
  * reference's test-suite ships for the path (teapot_blender.png, test_depth.png,
  * test_rasterize{1,2}.png, the grad_ref constants).  backward_textures (K7) and
  * backward_depth_map (K8) have no effective reference test: "parity unpinned" for
- * those two, they are pinned only by this literal restatement plus finite differences.
+ * those two, they are pinned only by this literal restatement plus finite differences
+ * (oracle side) and by the analytic / finite-difference tests of tests/test_gradient_pins_gpu.py (GPU side).
+ *
+ * Threads: built with -fopenmp the loops run in parallel over units that do not interact -- pixels for K2 / K4 / K5,
+ * faces for K1 / K6, batch elements for K7 / K8 (whose per-face accumulation order therefore stays the pixel order) --
+ * so the results do not depend on the thread count (tests/test_oracle_threads.py).  oracle_set_threads(1) gives the
+ * single-thread port that bench.py times as `cpu_baseline` (cores = 1).
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define API __attribute__((visibility("default")))
+
+static int g_threads = 0; /* 0 = OpenMP default (all cores) */
+API void oracle_set_threads(int n) { g_threads = n > 0 ? n : 0; }
+API int oracle_get_threads(void)
+{
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+#ifdef _OPENMP
+#define NTHREADS (g_threads > 0 ? g_threads : omp_get_max_threads())
+#else
+#define NTHREADS 1
+#endif
 
 /* CUDA `(int)x` for float/double x: round toward zero, saturate, NaN -> 0. */
 static inline int f2i(double x)
@@ -61,6 +87,7 @@ API void oracle_forward_face_inv(const float *faces, float *faces_inv, int batch
     const int is = image_size;
     const long n = (long)batch_size * num_faces;
     memset(faces_inv, 0, sizeof(float) * 9 * (size_t)n); /* :240 xp.zeros_like */
+#pragma omp parallel for schedule(static) num_threads(NTHREADS)
     for (long i = 0; i < n; i++) {
         const float *face = faces + i * 9;
         float *face_inv_g = faces_inv + i * 9;
@@ -97,6 +124,7 @@ API void oracle_forward_face_index_map(const float *faces, const float *faces_in
     const int is = image_size;
     const int nf = num_faces;
     const long n = (long)batch_size * is * is;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(NTHREADS)
     for (long i = 0; i < n; i++) {
         const int bn = (int)(i / ((long)is * is));
         const int pn = (int)(i % ((long)is * is));
@@ -162,6 +190,98 @@ API void oracle_forward_face_index_map(const float *faces, const float *faces_in
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * K2, cache-blocked evaluation order (same arguments, same results bit for bit as oracle_forward_face_index_map;
+ * tests/test_oracle_threads.py asserts that).  The literal loop streams all faces once per pixel, which for a
+ * 655 360-face mesh is 23.6 MB per pixel; here a thread takes PB consecutive pixels of a row and scans the faces once
+ * for the block, keeping the running minimum of each pixel (:296-339) in small arrays.  Every pixel still meets the
+ * faces in ascending order with the strict `<` of :334, and every (pixel, face) evaluation is the expression of
+ * :306-331, so nothing about the result changes -- only the order in which independent pixels are visited.
+ * Used for the full-size BASELINE configurations (tests/test_full_size_gpu.py) and the all-cores cpu_baseline.
+ */
+#define K2_PB 64
+API void oracle_forward_face_index_map_blocked(const float *faces, const float *faces_inv, int32_t *face_index_map,
+                                               float *weight_map, float *depth_map, float *face_inv_map,
+                                               int batch_size, int num_faces, int image_size, double near,
+                                               double far, int return_depth)
+{
+    const int is = image_size;
+    const int nf = num_faces;
+    const int blocks_per_row = (is + K2_PB - 1) / K2_PB;
+    const long n_blocks = (long)batch_size * is * blocks_per_row;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(NTHREADS)
+    for (long blk = 0; blk < n_blocks; blk++) {
+        const int bn = (int)(blk / ((long)is * blocks_per_row));
+        const int rem = (int)(blk % ((long)is * blocks_per_row));
+        const int yi = rem / blocks_per_row;
+        const int x0 = (rem % blocks_per_row) * K2_PB;
+        const int nx = imin(K2_PB, is - x0);
+        const float yp = (float)((2. * yi + 1 - is) / is); /* :291 */
+        float xp[K2_PB], depth_min[K2_PB], weight_min[K2_PB][3];
+        int face_index_min[K2_PB];
+        for (int j = 0; j < nx; j++) {
+            xp[j] = (float)((2. * (x0 + j) + 1 - is) / is); /* :292 */
+            depth_min[j] = (float)far;                      /* :296 */
+            face_index_min[j] = -1;
+            weight_min[j][0] = weight_min[j][1] = weight_min[j][2] = 0;
+        }
+        const float *face = faces + (long)bn * nf * 9 - 9;
+        const float *face_inv = faces_inv + (long)bn * nf * 9 - 9;
+        for (int fn = 0; fn < nf; fn++) {
+            face += 9;
+            face_inv += 9;
+            if (is_backside(face)) continue; /* :306 */
+            /* the pixel-independent factors of :310-312 */
+            const float e0x = face[3] - face[0], e0y = face[4] - face[1];
+            const float e1x = face[6] - face[3], e1y = face[7] - face[4];
+            const float e2x = face[0] - face[6], e2y = face[1] - face[7];
+            const float a0 = (yp - face[1]) * e0x, a1 = (yp - face[4]) * e1x, a2 = (yp - face[7]) * e2x;
+            unsigned char hit[K2_PB];
+            int any = 0;
+            for (int j = 0; j < nx; j++) { /* :310-312 */
+                const int out = (a0 < (xp[j] - face[0]) * e0y) | (a1 < (xp[j] - face[3]) * e1y) |
+                                (a2 < (xp[j] - face[6]) * e2y);
+                hit[j] = (unsigned char)!out;
+                any |= !out;
+            }
+            if (!any) continue;
+            for (int j = 0; j < nx; j++) {
+                if (!hit[j]) continue;
+                const int xi = x0 + j;
+                float w[3]; /* :317-319 */
+                w[0] = face_inv[3 * 0 + 0] * (float)xi + face_inv[3 * 0 + 1] * (float)yi + face_inv[3 * 0 + 2];
+                w[1] = face_inv[3 * 1 + 0] * (float)xi + face_inv[3 * 1 + 1] * (float)yi + face_inv[3 * 1 + 2];
+                w[2] = face_inv[3 * 2 + 0] * (float)xi + face_inv[3 * 2 + 1] * (float)yi + face_inv[3 * 2 + 2];
+                float w_sum = 0; /* :322-327 */
+                for (int k = 0; k < 3; k++) {
+                    w[k] = (float)fmin(fmax((double)w[k], 0.), 1.);
+                    w_sum += w[k];
+                }
+                for (int k = 0; k < 3; k++) w[k] /= w_sum;
+                const float zp = (float)(1. / (double)(w[0] / face[2] + w[1] / face[5] + w[2] / face[8])); /* :330 */
+                if ((double)zp <= near || far <= (double)zp) continue;                                        /* :331 */
+                if (zp < depth_min[j]) { /* :334-339 */
+                    depth_min[j] = zp;
+                    face_index_min[j] = fn;
+                    for (int k = 0; k < 3; k++) weight_min[j][k] = w[k];
+                }
+            }
+        }
+        for (int j = 0; j < nx; j++) { /* :343-348 */
+            if (0 <= face_index_min[j]) {
+                const long i = ((long)bn * is + yi) * is + x0 + j;
+                depth_map[i] = depth_min[j];
+                face_index_map[i] = face_index_min[j];
+                for (int k = 0; k < 3; k++) weight_map[3 * i + k] = weight_min[j][k];
+                if (return_depth) {
+                    const float *fi = faces_inv + ((long)bn * nf + face_index_min[j]) * 9;
+                    for (int k = 0; k < 9; k++) face_inv_map[9 * i + k] = fi[k];
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * K4: rasterize.py:361-438 -- trilinear texture sampling.
  * rgb_map / sampling maps pre-initialised to 0 by the caller (:482-484).
  * fix_batch_z == 0 reproduces the reference literally: the face's z is read from
@@ -177,6 +297,7 @@ API void oracle_forward_texture_sampling(const float *faces, const float *textur
     const int nf = num_faces;
     const int ts = texture_size;
     const long n = (long)batch_size * is * is;
+#pragma omp parallel for schedule(static) num_threads(NTHREADS)
     for (long i = 0; i < n; i++) {
         const int face_index = face_index_map[i];
         if (0 <= face_index) {
@@ -235,6 +356,7 @@ API void oracle_forward_background_alpha(const int32_t *face_index_map, float *r
 {
     const int is = image_size;
     const long n = (long)batch_size * is * is;
+#pragma omp parallel for schedule(static) num_threads(NTHREADS)
     for (long i = 0; i < n; i++) {
         const int bn = (int)(i / ((long)is * is));
         const float mask = (0 <= face_index_map[i]) ? 1.0f : 0.0f; /* :461 */
@@ -266,6 +388,7 @@ API void oracle_backward_pixel_map(const float *faces, const int32_t *face_index
     const long n = (long)batch_size * num_faces;
     long long visits = 0;
     if ((!return_rgb) && (!return_alpha)) return; /* :523 */
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : visits) num_threads(NTHREADS)
     for (long i = 0; i < n; i++) {
         const int bn = (int)(i / num_faces);
         const int fn = (int)(i % num_faces);
@@ -431,11 +554,12 @@ API void oracle_backward_textures(const int32_t *face_index_map, const float *sa
     const int is = image_size;
     const int nf = num_faces;
     const int ts = texture_size;
-    const long n = (long)batch_size * is * is;
-    for (long i = 0; i < n; i++) {
+    /* one batch element per thread: a face's texels only receive terms from its own image, in pixel order */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(NTHREADS)
+    for (int bn = 0; bn < batch_size; bn++)
+    for (long i = (long)bn * is * is; i < (long)(bn + 1) * is * is; i++) {
         const int face_index = face_index_map[i];
         if (0 <= face_index) {
-            const int bn = (int)(i / ((long)is * is));
             const long toff = ((long)bn * nf + face_index) * ts * ts * ts * 3;
             float *grad_texture = grad_textures + toff;
             for (int pn = 0; pn < 8; pn++) {
@@ -463,11 +587,11 @@ API void oracle_backward_depth_map(const float *faces, const float *depth_map, c
     /* acc_d != NULL (NOT the reference): add the terms to this double buffer [B*F*9] instead of grad_faces. */
     const int is = image_size;
     const int nf = num_faces;
-    const long n = (long)batch_size * is * is;
-    for (long i = 0; i < n; i++) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(NTHREADS)
+    for (int bn = 0; bn < batch_size; bn++)
+    for (long i = (long)bn * is * is; i < (long)(bn + 1) * is * is; i++) {
         const int fn = face_index_map[i];
         if (0 <= fn) {
-            const int bn = (int)(i / ((long)is * is));
             const float *face = faces + ((long)bn * nf + fn) * 9;
             const float depth = depth_map[i];
             const float depth2 = depth * depth;
@@ -498,4 +622,4 @@ API void oracle_backward_depth_map(const float *faces, const float *depth_map, c
     }
 }
 
-API int oracle_version(void) { return 1; }
+API int oracle_version(void) { return 2; }

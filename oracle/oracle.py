@@ -39,7 +39,7 @@ _lib = None
 def build(force=False):
     """Compile nr_oracle.c with gcc (no contraction, no fast-math). Returns the .so path."""
     if force or (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
-        cmd = ['gcc', '-O2', '-std=c99', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared',
+        cmd = ['gcc', '-O2', '-std=c99', '-fopenmp', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared',
                '-fvisibility=hidden', _SRC, '-o', _LIB, '-lm']
         subprocess.check_call(cmd)
     return _LIB
@@ -50,7 +50,27 @@ def lib():
     if _lib is None:
         build()
         _lib = ctypes.CDLL(_LIB)
+        if _lib.oracle_version() < 2:  # a stale prebuilt library
+            build(force=True)
+            _lib = ctypes.CDLL(_LIB)
+        env = os.environ.get('NR_ORACLE_THREADS')
+        if env:
+            _lib.oracle_set_threads(int(env))
     return _lib
+
+
+def set_threads(n):
+    """Number of OpenMP threads of the C oracle (0 = all cores, the default).  Results do not depend on it."""
+    lib().oracle_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().oracle_get_threads())
+
+
+# Above this many (pixel, face) pairs the forward uses the cache-blocked evaluation order of K2 (bit-identical,
+# tests/test_oracle_threads.py); `Rasterize.blocked` overrides.
+BLOCKED_K2_THRESHOLD = 2 ** 33
 
 
 def _p(a, t):
@@ -85,6 +105,7 @@ class Rasterize(object):
         self.return_depth = bool(return_depth)
         self.fix_batch_z = bool(fix_batch_z)
         self.visits = None
+        self.blocked = None  # None: by size; True / False: force the cache-blocked / literal K2 loop order
 
     def __call__(self, faces, textures=None):
         L = lib()
@@ -113,7 +134,9 @@ class Rasterize(object):
         # :499 forward_face_index_map_gpu (safe path: K1 then K2)
         self.faces_inv = np.zeros_like(self.faces)
         L.oracle_forward_face_inv(_p(self.faces, _f32p), _p(self.faces_inv, _f32p), bs, nf, s)
-        L.oracle_forward_face_index_map(
+        blocked = self.blocked if self.blocked is not None else bs * s * s * nf >= BLOCKED_K2_THRESHOLD
+        k2 = L.oracle_forward_face_index_map_blocked if blocked else L.oracle_forward_face_index_map
+        k2(
             _p(self.faces, _f32p), _p(self.faces_inv, _f32p), _p(self.face_index_map, _i32p),
             _p(self.weight_map, _f32p), _p(self.depth_map, _f32p), _p(self.face_inv_map, _f32p),
             bs, nf, s, ctypes.c_double(self.near), ctypes.c_double(self.far), int(self.return_depth))
@@ -141,8 +164,9 @@ class Rasterize(object):
         depth_r = self.depth_map.copy() if self.return_depth else None
         return rgb_r, alpha_r, depth_r
 
-    def backward(self, grad_rgb=None, grad_alpha=None, grad_depth=None, accumulate_double=False):
-        """accumulate_double: keep K6's running sums in double (NOT the reference; see nr_oracle.c)."""
+    def backward(self, grad_rgb=None, grad_alpha=None, grad_depth=None, accumulate_double=False, skip_textures=False):
+        """accumulate_double: keep K6's running sums in double (NOT the reference; see nr_oracle.c).
+        skip_textures: leave K7 out (its output stays zero) -- for callers that only want grad_faces of a huge mesh."""
         L = lib()
         bs, nf, s = self.batch_size, self.num_faces, self.image_size
         # :851-855
@@ -170,7 +194,7 @@ class Rasterize(object):
         self.visits = visits.value
         _f64p = ctypes.POINTER(ctypes.c_double)
         # :882 backward_textures_gpu
-        if self.return_rgb:
+        if self.return_rgb and not skip_textures:
             acc = np.zeros(self.grad_textures.shape, np.float64) if accumulate_double else None
             L.oracle_backward_textures(
                 _p(self.face_index_map, _i32p), _p(self.sampling_weight_map, _f32p),

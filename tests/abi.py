@@ -18,12 +18,14 @@ def _stream():
 
 
 def forward(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, background=(0, 0, 0), flags=0,
-            return_rgb=False, return_alpha=True, return_depth=False, want_face_inv=False, want_sampling=False):
+            return_rgb=False, return_alpha=True, return_depth=False, want_face_inv=False, want_sampling=False,
+            faces_z_ref=None, want_visible=True):
     """Runs nr_forward_face_index_map (+ nr_forward_texture_sampling). Returns dict of device tensors."""
     lib = _lib.load()
     f = dev(faces, torch.float32)
     B, F = f.shape[:2]
-    out = {'faces': f}
+    out = {'faces': f, 'faces_z_ref': dev(faces_z_ref, torch.float32) if faces_z_ref is not None else None}
+    out['visible_faces'] = torch.full((B, F), 77, dtype=torch.uint8, device='cuda') if want_visible else None
     out['face_index_map'] = torch.full((B, S, S), 12345, dtype=torch.int32, device='cuda')
     out['weight_map'] = torch.full((B, S, S, 3), float('nan'), device='cuda')
     out['depth_map'] = torch.full((B, S, S), float('nan'), device='cuda')
@@ -33,7 +35,8 @@ def forward(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, backgroun
     ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
     _lib.check(lib.nr_forward_face_index_map(
         f.data_ptr(), out['face_index_map'].data_ptr(), out['weight_map'].data_ptr(), out['depth_map'].data_ptr(),
-        _lib.ptr(out['face_inv_map']), B, F, S, near, far, ws.data_ptr(), wsb, _stream()), 'fwd fi')
+        _lib.ptr(out['face_inv_map']), _lib.ptr(out['visible_faces']), B, F, S, near, far, ws.data_ptr(), wsb,
+        _stream()), 'fwd fi')
     out['workspace'] = ws
     ts = 0
     if return_rgb or return_alpha:
@@ -52,7 +55,7 @@ def forward(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, backgroun
             out['alpha_map'] = torch.full((B, S, S), float('nan'), device='cuda')
         out['textures'] = t
         _lib.check(lib.nr_forward_texture_sampling(
-            f.data_ptr(), _lib.ptr(t), out['face_index_map'].data_ptr(), out['weight_map'].data_ptr(),
+            f.data_ptr(), _lib.ptr(out['faces_z_ref']), _lib.ptr(t), out['face_index_map'].data_ptr(), out['weight_map'].data_ptr(),
             out['depth_map'].data_ptr(), _lib.ptr(out.get('rgb_map')), _lib.ptr(out.get('sampling_index_map')),
             _lib.ptr(out.get('sampling_weight_map')), _lib.ptr(bg), per_batch, _lib.ptr(out.get('alpha_map')),
             B, F, S, ts, eps, flags, _stream()), 'fwd shade')
@@ -60,7 +63,8 @@ def forward(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, backgroun
     return out
 
 
-def backward(fw, g_rgb=None, g_alpha=None, g_depth=None, use_sampling_maps=False, use_face_inv_map=False):
+def backward(fw, g_rgb=None, g_alpha=None, g_depth=None, use_sampling_maps=False, use_face_inv_map=False, k6_flags=0,
+             use_visible=True):
     """Runs K6 / K7 / K8 through the ABI on the residuals of `forward`. Returns (grad_faces, grad_textures)."""
     lib = _lib.load()
     B, F, S, ts = fw['B'], fw['F'], fw['S'], fw['ts']
@@ -76,8 +80,8 @@ def backward(fw, g_rgb=None, g_alpha=None, g_depth=None, use_sampling_maps=False
             fw['faces'].data_ptr(), fw['face_index_map'].data_ptr(),
             _lib.ptr(fw.get('rgb_map')) if gr is not None else None,
             _lib.ptr(fw.get('alpha_map')) if ga is not None else None, _lib.ptr(gr), _lib.ptr(ga),
-            grad_faces.data_ptr(), B, F, S, fw['eps'], int(gr is not None), int(ga is not None), ws.data_ptr(), wsb,
-            _stream()), 'bwd pixel_map')
+            grad_faces.data_ptr(), B, F, S, fw['eps'], int(gr is not None), int(ga is not None), k6_flags,
+            _lib.ptr(fw.get('visible_faces')) if use_visible else None, ws.data_ptr(), wsb, _stream()), 'bwd pixel_map')
     else:
         grad_faces.zero_()
     if gr is not None:
@@ -86,7 +90,8 @@ def backward(fw, g_rgb=None, g_alpha=None, g_depth=None, use_sampling_maps=False
         si = fw.get('sampling_index_map') if use_sampling_maps else None
         _lib.check(lib.nr_backward_textures(
             fw['face_index_map'].data_ptr(), _lib.ptr(sw), _lib.ptr(si), fw['faces'].data_ptr(),
-            fw['weight_map'].data_ptr(), fw['depth_map'].data_ptr(), gr.data_ptr(), grad_textures.data_ptr(),
+            _lib.ptr(fw.get('faces_z_ref')), fw['weight_map'].data_ptr(), fw['depth_map'].data_ptr(), gr.data_ptr(),
+            grad_textures.data_ptr(),
             B, F, S, ts, fw['eps'], fw['flags'], _stream()), 'bwd textures')
     if gd is not None:
         fim = fw.get('face_inv_map') if use_face_inv_map else None
@@ -101,7 +106,7 @@ def host(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
-def backward_fused(fw, g_rgb=None, g_alpha=None, g_depth=None):
+def backward_fused(fw, g_rgb=None, g_alpha=None, g_depth=None, k6_flags=0, use_visible=True):
     """nr_backward_rasterize (K6 -> K7 -> K8 behind one call) on the residuals of `forward`."""
     lib = _lib.load()
     B, F, S, ts = fw['B'], fw['F'], fw['S'], fw['ts']
@@ -113,21 +118,24 @@ def backward_fused(fw, g_rgb=None, g_alpha=None, g_depth=None):
     wsb = lib.nr_backward_workspace_bytes(B, F, S, int(gr is not None), int(ga is not None))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device='cuda')
     _lib.check(lib.nr_backward_rasterize(
-        fw['faces'].data_ptr(), fw['face_index_map'].data_ptr(), _lib.ptr(fw.get('weight_map')),
-        _lib.ptr(fw.get('depth_map')), _lib.ptr(fw.get('rgb_map')), _lib.ptr(fw.get('alpha_map')), _lib.ptr(gr),
-        _lib.ptr(ga), _lib.ptr(gd), grad_faces.data_ptr(), _lib.ptr(grad_textures), B, F, S, ts, fw['eps'],
-        fw['flags'], ws.data_ptr(), wsb, _stream()), 'bwd fused')
+        fw['faces'].data_ptr(), _lib.ptr(fw.get('faces_z_ref')), fw['face_index_map'].data_ptr(),
+        _lib.ptr(fw.get('weight_map')), _lib.ptr(fw.get('depth_map')), _lib.ptr(fw.get('rgb_map')),
+        _lib.ptr(fw.get('alpha_map')), _lib.ptr(gr), _lib.ptr(ga), _lib.ptr(gd), grad_faces.data_ptr(),
+        _lib.ptr(grad_textures), B, F, S, ts, fw['eps'], fw['flags'] | k6_flags,
+        _lib.ptr(fw.get('visible_faces')) if use_visible else None, ws.data_ptr(), wsb, _stream()), 'bwd fused')
     torch.cuda.synchronize()
     return grad_faces, grad_textures
 
 
 def forward_fused(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, background=(0, 0, 0), flags=0,
-                  return_rgb=False, return_alpha=True, return_depth=False):
+                  return_rgb=False, return_alpha=True, return_depth=False, faces_z_ref=None):
     """nr_forward_rasterize (visibility + shading behind one call)."""
     lib = _lib.load()
     f = dev(faces, torch.float32)
     B, F = f.shape[:2]
-    out = {'faces': f, 'face_index_map': torch.full((B, S, S), 12345, dtype=torch.int32, device='cuda'),
+    out = {'faces': f, 'faces_z_ref': dev(faces_z_ref, torch.float32) if faces_z_ref is not None else None,
+           'visible_faces': torch.full((B, F), 77, dtype=torch.uint8, device='cuda'),
+           'face_index_map': torch.full((B, S, S), 12345, dtype=torch.int32, device='cuda'),
            'weight_map': torch.full((B, S, S, 3), float('nan'), device='cuda'),
            'depth_map': torch.full((B, S, S), float('nan'), device='cuda')}
     t = bg = None
@@ -143,9 +151,10 @@ def forward_fused(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, bac
     wsb = lib.nr_forward_workspace_bytes(B, F, S)
     ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
     _lib.check(lib.nr_forward_rasterize(
-        f.data_ptr(), _lib.ptr(t), out['face_index_map'].data_ptr(), out['weight_map'].data_ptr(),
-        out['depth_map'].data_ptr(), _lib.ptr(out.get('rgb_map')), _lib.ptr(out.get('alpha_map')), _lib.ptr(bg),
-        per_batch, B, F, S, ts, near, far, eps, flags, ws.data_ptr(), wsb, _stream()), 'fwd fused')
+        f.data_ptr(), _lib.ptr(out['faces_z_ref']), _lib.ptr(t), out['face_index_map'].data_ptr(),
+        out['weight_map'].data_ptr(), out['depth_map'].data_ptr(), _lib.ptr(out.get('rgb_map')),
+        _lib.ptr(out.get('alpha_map')), out['visible_faces'].data_ptr(), _lib.ptr(bg), per_batch, B, F, S, ts, near, far,
+        eps, flags, ws.data_ptr(), wsb, _stream()), 'fwd fused')
     torch.cuda.synchronize()
     out.update(B=B, F=F, S=S, ts=ts, eps=eps, flags=flags, textures=t)
     return out

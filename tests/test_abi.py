@@ -23,10 +23,44 @@ def lib_path():
     return _build.build()
 
 
+def declared_prototypes():
+    """name -> list of C parameter types as include/nr_hip.h declares them ('ptr', 'i32', 'f64', 'f32', 'size')."""
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for name, params in re.findall(r'\b(nr_[a-z_0-9]+)\s*\(([^)]*)\)\s*;', src):
+        kinds = []
+        for prm in [x.strip() for x in params.split(',')]:
+            if prm in ('void', ''):
+                continue
+            if '*' in prm:
+                kinds.append('ptr')
+            elif prm.startswith('int32_t') or prm.startswith('int '):
+                kinds.append('i32')
+            elif prm.startswith('double'):
+                kinds.append('f64')
+            elif prm.startswith('float'):
+                kinds.append('f32')
+            elif prm.startswith('size_t'):
+                kinds.append('size')
+            else:
+                raise AssertionError('unparsed parameter %r of %s' % (prm, name))
+        out[name] = kinds
+    return out
+
+
 def test_header_and_binding_agree():
     names = declared_functions()
     assert 'nr_forward_face_index_map' in names and 'nr_backward_pixel_map' in names
     assert sorted(_lib.SIGNATURES) == names
+    # every parameter of every prototype, position by position, against the ctypes table the product binds with
+    kind_of = {ctypes.c_void_p: 'ptr', ctypes.c_int32: 'i32', ctypes.c_int: 'i32', ctypes.c_double: 'f64',
+               ctypes.c_float: 'f32', ctypes.c_size_t: 'size', ctypes.c_char_p: 'ptr'}
+    protos = declared_prototypes()
+    assert sorted(protos) == names
+    for name, (_, args) in _lib.SIGNATURES.items():
+        got = [kind_of.get(a, 'ptr') for a in args]  # POINTER(struct) types count as pointers
+        assert got == protos[name], (name, got, protos[name])
 
 
 def test_library_exports_every_declared_symbol(lib_path):
@@ -37,10 +71,10 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_host_only_entry_points(lib_path):
     lib = _lib.load()
-    assert lib.nr_version() == 110
+    assert lib.nr_version() == 200
     assert lib.nr_error_string(0) == b'success'
     assert b'workspace' in lib.nr_error_string(-3)
-    assert lib.nr_forward_workspace_bytes(64, 4928, 256) >= 64 * 4928 * (36 + 8)
+    assert lib.nr_forward_workspace_bytes(64, 4928, 256) >= 64 * 256 * 256 * 8 + 64 * 4928 * 4
     assert lib.nr_forward_workspace_bytes(0, 1, 1) == 0
     assert lib.nr_forward_workspace_bytes(1, 1, 20000) == 0
 
@@ -48,10 +82,13 @@ def test_host_only_entry_points(lib_path):
 def test_argument_errors_do_not_need_a_gpu(lib_path):
     lib = _lib.load()
     # NULL pointers / bad sizes are rejected before any launch
-    assert lib.nr_forward_face_index_map(None, None, None, None, None, 1, 1, 8, 0.1, 100.0, None, 0, None) == -1
+    assert lib.nr_forward_face_index_map(None, None, None, None, None, None, 1, 1, 8, 0.1, 100.0, None, 0, None) == -1
     assert lib.nr_backward_depth_map(None, None, None, None, None, None, None, 1, 1, 8, None) == -1
-    assert lib.nr_forward_texture_sampling(None, None, 1, None, None, None, None, None, None, 0, None,
+    assert lib.nr_forward_texture_sampling(None, None, None, 1, None, None, None, None, None, None, 0, None,
                                            1, 1, 8, 2, 1e-3, 0, None) == -4
+    # near <= 0 has its own code and message (the packed z-buffer needs positive depths)
+    assert lib.nr_forward_face_index_map(1, 1, None, None, None, None, 1, 1, 8, 0.0, 100.0, None, 0, None) == -5
+    assert b'near' in lib.nr_error_string(-5)
 
 
 def test_cpu_tensors_are_refused():

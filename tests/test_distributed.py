@@ -58,9 +58,20 @@ def _worker(rank, world, port, total, out_q):
     nrd.all_reduce_shared_grads([p])
     expect = float(sum(v + 1 for v in range(total)))
     ok_grad = bool(torch.allclose(p.grad, torch.full((3,), expect)))
+    # a shared parameter that received no gradient on rank 1 (e.g. the mesh is invisible in that shard): both ranks must
+    # still issue the same collectives, and the sum is rank 0's gradient
+    q = torch.nn.Parameter(torch.ones(2))
+    if rank == 0:
+        (q * 3.0).sum().backward()
+    nrd.all_reduce_shared_grads([q, p])
+    ok_grad = ok_grad and bool(torch.allclose(q.grad, torch.full((2,), 3.0)))
+    # Q1 under sharding: every rank ends up with rank 0's first projected view
+    faces_local = torch.arange((stop - start) * 4 * 9, dtype=torch.float32).reshape(stop - start, 4, 3, 3) + 1000.0 * rank
+    ref_faces = nrd.broadcast_reference_faces(faces_local if stop > start else torch.zeros(1, 4, 3, 3))
+    ok_ref = bool(torch.equal(ref_faces, torch.arange(36, dtype=torch.float32).reshape(4, 3, 3)))
     dist.barrier()
     dist.destroy_process_group()
-    out_q.put((rank, ok_gather, ok_gather2, ok_grad))
+    out_q.put((rank, ok_gather, ok_gather2, ok_grad and ok_ref))
 
 
 @pytest.mark.parametrize('total', [8, 5])
