@@ -6,20 +6,26 @@
         bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the rasterizer hot path (Rasterize forward + backward through the product's autograd
-operator, i.e. the five C-ABI stages) over one batch of 64 views of the teapot at raster size 256 with
-RGB + alpha + depth outputs all enabled.  Inputs (projected faces, lit textures, upstream gradients) are
-resident in HBM before the timed region.  The batch-of-views dimension shards across GPUs without any
+operator, i.e. the C-ABI entry points nr_forward_rasterize / nr_backward_rasterize) over one batch of 64 views of the
+teapot at raster size 256 with RGB + alpha + depth outputs all enabled.  Inputs (projected faces, lit textures, upstream
+gradients) are resident in HBM before the timed region.  The batch-of-views dimension shards across GPUs without any
 collective ("weak" scaling: 64 views per GPU); rank 0 prints ONE JSON line.
 
-Extra objects on the line (tier contract):
-  roofline      the dominant kernel's algorithmic HBM bytes / its measured average launch duration
-                (HIP events on the launch stream), against the 8 TB/s HBM3E peak
-  cpu_baseline  the C oracle (oracle/nr_oracle.c, a literal single-thread port of the reference's
-                algorithm) timed on a bounded sample of the same workload on this host
+Objects on the line besides the contract's keys:
+  roofline      the dominant stage's algorithmic HBM bytes / its measured average launch duration (HIP events on the launch
+                stream), against the 8 TB/s HBM3E peak; `whole_step` prices the whole fwd+bwd with SURVEY 8d's compulsory
+                bytes (92 P + (108 + 24 ts^3) N for rgb+alpha+depth); `valu_issue` is the secondary bound of the K6 kernel,
+                whose floor is instruction issue, not HBM
+  cpu_baseline  the C oracle (oracle/nr_oracle.c, a literal port of the reference's algorithm) on this host: one thread on
+                a bounded sample (`value`), all cores on the whole batch (`all_cores`), and the north star's naive NumPy
+                per-pixel loop on BASELINE configs[0] (`numpy_naive_config1`)
+  grad_check    parity of the benchmarked batch against the oracle: face_index_map mismatches (must be 0), max-abs and
+                max-rel errors of the gradients, all 64 views
+  extra_rows    the same step with anti-aliasing on (raster 512, the Renderer default) and with the all-ones upstream
+                gradient of the reference's misc/measure_time.py:60
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -32,6 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+NUM_SIMDS = 1024       # 256 CUs x 4 SIMDs
+NS_PER_WAVE_INSTR = 1.07  # FP32 VALU wave-instruction issue interval per SIMD, measured by microbenchmark
 
 
 def load_teapot():
@@ -64,9 +72,25 @@ def build_scene(device, batch, first_view, total_views, image_size, texture_size
     return faces.contiguous(), textures.contiguous()
 
 
+def upstream_gradients(faces, textures, S, eps, seed, all_ones=False):
+    """g = 2 (image - ref) with a seeded uniform reference (dense, both signs); all_ones: the gradient of
+    sum(images) as in the reference's misc/measure_time.py:60 (K6's `diff_grad <= 0` branch then skips half the work)."""
+    import neural_renderer_amd as nr
+    dev = faces.device
+    gen = torch.Generator(device='cpu').manual_seed(seed)
+    with torch.no_grad():
+        rgb0, alpha0, depth0 = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)(faces, textures)
+        if all_ones:
+            return torch.ones_like(rgb0), torch.ones_like(alpha0), torch.ones_like(depth0)
+        g_rgb = (2 * (rgb0 - torch.rand(rgb0.shape, generator=gen).to(dev))).contiguous()
+        g_alpha = (2 * (alpha0 - torch.rand(alpha0.shape, generator=gen).to(dev))).contiguous()
+        g_depth = (2 * (depth0 / 100.0 - torch.rand(depth0.shape, generator=gen).to(dev)) / 100.0).contiguous()
+    return g_rgb, g_alpha, g_depth
+
+
 # dominant kernel of each stage call (the rest of a stage are small helper launches, see profiles/README.md)
 STAGE_KERNEL = {
-    'forward_face_index_map': 'k_face_raster', 'forward_texture_sampling': 'k_shade', 'backward_pixel_map': 'k_bpm_band',
+    'forward_face_index_map': 'k_face_raster', 'forward_texture_sampling': 'k_shade', 'backward_pixel_map': 'k_bpm_fast',
     'backward_textures': 'k_backward_textures_face', 'backward_depth_map': 'k_backward_depth_face',
 }
 
@@ -76,16 +100,23 @@ def algorithmic_bytes(B, F, S, ts):
     recomputable intermediates count zero) -- DESIGN.md 'Kernels'."""
     P, N = B * S * S, B * F
     return {
-        'face_setup': N * (36 + 36 + 8),
-        'raster_tiles': N * (36 + 36 + 8) + P * (4 + 12 + 4),
-        'shade': P * (4 + 12 + 4) + N * 12 * ts ** 3 + P * (12 + 4),
+        'forward_face_index_map': N * 36 + P * (4 + 12 + 4),
+        'forward_texture_sampling': P * (4 + 12 + 4) + N * 12 * ts ** 3 + P * (12 + 4),
         'backward_pixel_map': P * (4 + 12 + 4 + 12 + 4) + N * 72,
         'backward_textures': P * (4 + 12 + 4 + 12) + N * 24 * ts ** 3,
         'backward_depth_map': P * (4 + 12 + 4 + 4) + N * 72,
     }
 
 
-def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
+def whole_step_bytes(B, F, S, ts):
+    """SURVEY 8d 'Algorithmic bytes' for one Rasterize fwd+bwd with rgb + alpha + depth: forward writes rgb 12 + alpha 4 +
+    depth 4 + face_index 4 + weight 12, backward reads the three gradients 20, rgb 12, alpha 4 and the residuals 20:
+    92 B per pixel; per face 36 (faces, forward) + 36 (faces, backward) + 36 (grad_faces) + 24 ts^3 (textures read,
+    grad_textures written)."""
+    return 92 * B * S * S + (108 + 24 * ts ** 3) * B * F
+
+
+def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flags=0):
     """Average duration of each C-ABI stage, measured with events on the stream the kernels are launched on."""
     from neural_renderer_amd import _lib
     lib = _lib.load()
@@ -98,6 +129,7 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
     dm = torch.empty((B, S, S), device=dev)
     rgb = torch.empty((B, S, S, 3), device=dev)
     am = torch.empty((B, S, S), device=dev)
+    vis = torch.empty((B, F), dtype=torch.uint8, device=dev)
     bg = torch.zeros(3, device=dev)
     gf = torch.empty_like(faces)
     gt = torch.empty_like(textures)
@@ -108,16 +140,16 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
 
     calls = {
         'forward_face_index_map': lambda: lib.nr_forward_face_index_map(
-            faces.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), None, B, F, S, 0.1, 100.0, ws.data_ptr(),
-            wsb, st),
+            faces.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), None, vis.data_ptr(), B, F, S, 0.1, 100.0,
+            ws.data_ptr(), wsb, st),
         'forward_texture_sampling': lambda: lib.nr_forward_texture_sampling(
-            faces.data_ptr(), textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(), None,
+            faces.data_ptr(), None, textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(), None,
             None, bg.data_ptr(), 0, am.data_ptr(), B, F, S, ts, eps, 0, st),
         'backward_pixel_map': lambda: lib.nr_backward_pixel_map(
             faces.data_ptr(), fi.data_ptr(), rgb.data_ptr(), am.data_ptr(), g_rgb.data_ptr(), g_alpha.data_ptr(),
-            gf.data_ptr(), B, F, S, eps, 1, 1, bws.data_ptr(), bwsb, st),
+            gf.data_ptr(), B, F, S, eps, 1, 1, k6_flags, vis.data_ptr(), bws.data_ptr(), bwsb, st),
         'backward_textures': lambda: lib.nr_backward_textures(
-            fi.data_ptr(), None, None, faces.data_ptr(), wm.data_ptr(), dm.data_ptr(), g_rgb.data_ptr(),
+            fi.data_ptr(), None, None, faces.data_ptr(), None, wm.data_ptr(), dm.data_ptr(), g_rgb.data_ptr(),
             gt.data_ptr(), B, F, S, ts, eps, 0, st),
         'backward_depth_map': lambda: lib.nr_backward_depth_map(
             faces.data_ptr(), dm.data_ptr(), fi.data_ptr(), None, wm.data_ptr(), g_depth.data_ptr(), gf.data_ptr(),
@@ -125,12 +157,12 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
     }
     # the two fused entry points the autograd operator actually calls
     calls['fused_forward_rasterize'] = lambda: lib.nr_forward_rasterize(
-        faces.data_ptr(), textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(),
-        am.data_ptr(), bg.data_ptr(), 0, B, F, S, ts, 0.1, 100.0, eps, 0, ws.data_ptr(), wsb, st)
+        faces.data_ptr(), None, textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(),
+        am.data_ptr(), vis.data_ptr(), bg.data_ptr(), 0, B, F, S, ts, 0.1, 100.0, eps, 0, ws.data_ptr(), wsb, st)
     calls['fused_backward_rasterize'] = lambda: lib.nr_backward_rasterize(
-        faces.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(), am.data_ptr(), g_rgb.data_ptr(),
-        g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(), gt.data_ptr(), B, F, S, ts, eps, 0, bws.data_ptr(), bwsb,
-        st)
+        faces.data_ptr(), None, fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(), am.data_ptr(),
+        g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(), gt.data_ptr(), B, F, S, ts, eps, k6_flags,
+        vis.data_ptr(), bws.data_ptr(), bwsb, st)
     out = {}
     for name, call in calls.items():
         for _ in range(2):
@@ -144,6 +176,17 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters):
         torch.cuda.synchronize(dev)
         out[name] = e0.elapsed_time(e1) * 1e3 / iters  # us
     return out
+
+
+def time_step(step, dev, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps * 1e3
 
 
 def renderer_end_to_end(device, batch, first_view, total_views, image_size, texture_size, iters=10):
@@ -161,16 +204,6 @@ def renderer_end_to_end(device, batch, first_view, total_views, image_size, text
     r.eye = torch.tensor([nr.get_points_from_angles(2.732, 30., 360.0 * (first_view + i) / total_views)
                           for i in range(batch)], dtype=torch.float32, device=device)
 
-    def timed(fn):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            fn()
-        torch.cuda.synchronize(device)
-        return (time.perf_counter() - t0) / iters * 1e3
-
     def rgb():
         vertices.grad = None
         textures.grad = None
@@ -180,31 +213,119 @@ def renderer_end_to_end(device, batch, first_view, total_views, image_size, text
         vertices.grad = None
         r.render_silhouettes(vertices, faces).square().sum().backward()
 
-    return {'render_fwd_bwd_ms': timed(rgb), 'render_silhouettes_fwd_bwd_ms': timed(sil),
-            'what': 'Renderer.render / render_silhouettes + squared-sum loss, forward + backward, %d views, %dx%d, '
-                    'anti_aliasing off' % (batch, image_size, image_size)}
+    out = {'render_fwd_bwd_ms': time_step(rgb, device, iters, 3), 'render_silhouettes_fwd_bwd_ms': time_step(sil, device, iters, 3),
+           'what': 'Renderer.render / render_silhouettes + squared-sum loss, forward + backward, %d views, %dx%d, '
+                   'anti_aliasing off' % (batch, image_size, image_size),
+           'frontend': r.last_frontend, 'frontend_calls': dict(r.frontend_calls)}
+    # the fused HIP front-end must be what ran: the module-by-module torch path is ~160 launches slower
+    assert r.frontend_calls['torch'] == 0 and r.last_frontend == 'fused', r.frontend_calls
+    return out
 
 
-def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views):
-    """The C oracle on `sample_views` views of the same workload, one host thread."""
+def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views, light=False):
+    """The C oracle on this host: one thread on `sample_views` views (the contract's `value`, kind "port"), all cores on
+    the whole batch, and the naive NumPy per-pixel loop on BASELINE configs[0]."""
     from oracle import oracle as O
     O.build()
-    f = faces[:sample_views].cpu().numpy()
-    t = textures[:sample_views].cpu().numpy()
-    gr, ga, gd = (x[:sample_views].cpu().numpy() for x in (g_rgb, g_alpha, g_depth))
-    t0 = time.perf_counter()
-    fn = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
-    fn(f, t)
-    t1 = time.perf_counter()
-    fn.backward(gr, ga, gd)
-    t2 = time.perf_counter()
-    pixels = sample_views * S * S
-    return {
-        'value': pixels / (t2 - t0) / 1e6, 'unit': 'Mpixel/s', 'cores': 1, 'kind': 'port',
-        'sample': '%d of the 64 teapot views, %dx%d, rgb+alpha+depth fwd+bwd, oracle/nr_oracle.c (gcc -O2), '
-                  'fwd %.2f s bwd %.2f s' % (sample_views, S, S, t1 - t0, t2 - t1),
+
+    def run(n_views, threads, blocked):
+        f = faces[:n_views].cpu().numpy()
+        t = textures[:n_views].cpu().numpy()
+        gr, ga, gd = (x[:n_views].cpu().numpy() for x in (g_rgb, g_alpha, g_depth))
+        O.set_threads(threads)
+        try:
+            t0 = time.perf_counter()
+            fn = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+            fn.blocked = blocked
+            fn(f, t)
+            t1 = time.perf_counter()
+            fn.backward(gr, ga, gd)
+            t2 = time.perf_counter()
+        finally:
+            O.set_threads(0)
+        return n_views * S * S / (t2 - t0) / 1e6, t1 - t0, t2 - t1
+
+    v1, f1, b1 = run(sample_views, 1, False)
+    out = {
+        'value': v1, 'unit': 'Mpixel/s', 'cores': 1, 'kind': 'port',
+        'sample': '%d of the %d teapot views, %dx%d, rgb+alpha+depth fwd+bwd, oracle/nr_oracle.c (gcc -O2, literal loop '
+                  'order), fwd %.2f s bwd %.2f s' % (sample_views, faces.shape[0], S, S, f1, b1),
         'host_cpus': os.cpu_count(),
     }
+    n_all = int(faces.shape[0])
+    va, fa, ba = run(n_all, 0, True)
+    out['all_cores'] = {
+        'value': va, 'unit': 'Mpixel/s', 'cores': O.get_threads(), 'kind': 'port',
+        'sample': 'all %d views, OpenMP build of the same oracle with the cache-blocked K2 loop order (bit-identical '
+                  'results), fwd %.2f s bwd %.2f s' % (n_all, fa, ba)}
+    if not light:
+        # BASELINE configs[0] / north star "naive NumPy per-pixel loop": teapot, 1 view, 64x64 silhouette
+        from oracle import numpy_naive as N
+        f64 = build_scene_cpu_view(64)
+        t0 = time.perf_counter()
+        fi, _, _ = N.forward_face_index_map(f64, 64, 0.1, 100)[:3]
+        alpha = N.forward_alpha_map(fi)
+        t1 = time.perf_counter()
+        g = np.random.default_rng(0).normal(size=alpha.shape).astype(np.float32)
+        N.backward_pixel_map(f64, fi, None, alpha, None, g, 1e-4)
+        t2 = time.perf_counter()
+        out['numpy_naive_config1'] = {
+            'value': 64 * 64 / (t2 - t0) / 1e6, 'unit': 'Mpixel/s', 'cores': 1, 'kind': 'port',
+            'sample': 'BASELINE configs[0]: teapot, 1 view, 64x64 silhouette, oracle/numpy_naive.py (one Python iteration '
+                      'per pixel over all faces), fwd %.2f s bwd %.2f s' % (t1 - t0, t2 - t1)}
+    return out
+
+
+def build_scene_cpu_view(S):
+    """One teapot view (azimuth 0) as float32 NumPy faces [1,F,3,3] through the oracle's glue (CPU only)."""
+    from oracle import oracle as O
+    v, f = load_teapot()
+    f = np.concatenate((f, f[:, ::-1]), axis=0)
+    eye = O.get_points_from_angles(2.732, 30., 0.)
+    vv = O.perspective(O.look_at(v[None], eye), 30.)
+    return O.vertices_to_faces(vv, f[None]).astype(np.float32)
+
+
+def grad_check(nr_fn_fi, faces, textures, S, eps, g_rgb, g_alpha, g_depth, n_views):
+    """Parity of the benchmarked batch: face_index_map mismatches and gradient errors against the oracle (sums of the
+    reference's float terms carried in double), `n_views` views."""
+    from oracle import oracle as O
+    O.build()
+    ref = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+    ref.blocked = True
+    ref(faces[:n_views].detach().cpu().numpy(), textures[:n_views].detach().cpu().numpy())
+    r_gf, r_gt = ref.backward(g_rgb[:n_views].cpu().numpy(), g_alpha[:n_views].cpu().numpy(),
+                              g_depth[:n_views].cpu().numpy(), accumulate_double=True)
+    gf, gt = faces.grad[:n_views].cpu().numpy(), textures.grad[:n_views].cpu().numpy()
+    fi = nr_fn_fi[:n_views].cpu().numpy()
+
+    def stats(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        err = np.abs(a - b)
+        nz = np.abs(b) > 0
+        rel = err[nz] / np.abs(b[nz])
+        floor = 1e-3 * np.abs(b).max()
+        return {'max_abs_err': float(err.max()), 'max_abs': float(np.abs(b).max()),
+                'max_rel_err_elementwise': float(rel.max()) if rel.size else 0.0,
+                'frac_elements_within_1e-4_rel': float(np.mean(rel <= 1e-4)) if rel.size else 1.0,
+                'max_rel_err_floor_1e-3_of_max': float((err / np.maximum(np.abs(b), floor)).max())}
+    return {'face_index_mismatch': int((fi != ref.face_index_map).sum()), 'grad_faces': stats(gf, r_gf),
+            'grad_textures': stats(gt, r_gt),
+            'checked': '%d views of rank 0 vs oracle (terms summed in double); elementwise max-rel-err is dominated by entries '
+                       'that cancel to ~0 (the tests bound the floor form at 1e-5)' % n_views}
+
+
+def profile_records():
+    """Counter-derived figures of the committed profiles (they cannot be collected inside a timed run): HBM traffic of the
+    dominant stage and the VALU instruction count of the K6 kernel.  Labelled with their source file."""
+    out = {}
+    p = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    if os.path.exists(p):
+        try:
+            out['pmc'] = json.load(open(p))
+        except Exception:
+            pass
+    return out
 
 
 def main():
@@ -216,15 +337,19 @@ def main():
     ap.add_argument('--image-size', type=int, default=256, help='raster size S (anti-aliasing off)')
     ap.add_argument('--texture-size', type=int, default=2)
     ap.add_argument('--cpu-sample-views', type=int, default=32,
-                    help='views timed on the CPU oracle, rank 0 of a 1-GPU run only (0 = skip); 32 views ~ 13 s')
+                    help='views timed on ONE host thread of the CPU oracle, rank 0 of a 1-GPU run only (0 = skip all CPU '
+                         'baselines); 32 views ~ 13 s')
     ap.add_argument('--stage-iters', type=int, default=20)
+    ap.add_argument('--check-views', type=int, default=64, help='views compared with the oracle (all host cores)')
     ap.add_argument('--gather', action='store_true', help='also all_gather the rendered images each step (RCCL)')
-    ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph (measured: no gain, the stream is GPU-bound)')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph')
+    ap.add_argument('--exact', action='store_true', help='K6 with the reference\'s own arithmetic (NR_FLAG_EXACT_GRADIENT)')
+    ap.add_argument('--light', action='store_true', help='headline step + stage timings only (no extra rows, no Renderer '
+                                                         'end-to-end, oracle check on 2 views)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run' % (world, args.gpus))
     if not torch.cuda.is_available():
@@ -241,54 +366,39 @@ def main():
     F = faces.shape[1]
     faces.requires_grad_(True)
     textures.requires_grad_(True)
-
-    # upstream gradients: dense, g = 2 (image - ref) with a seeded uniform reference
-    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
-    with torch.no_grad():
-        rgb0, alpha0, depth0 = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)(faces, textures)
-        g_rgb = (2 * (rgb0 - torch.rand(rgb0.shape, generator=gen).to(dev))).contiguous()
-        g_alpha = (2 * (alpha0 - torch.rand(alpha0.shape, generator=gen).to(dev))).contiguous()
-        g_depth = (2 * (depth0 / 100.0 - torch.rand(depth0.shape, generator=gen).to(dev)) / 100.0).contiguous()
-        del rgb0, alpha0, depth0
+    g_rgb, g_alpha, g_depth = upstream_gradients(faces, textures, S, eps, 1234 + rank)
 
     gather_buf = None
     if args.gather and world > 1:
         gather_buf = torch.empty((world * B, S, S, 3), device=dev)
+    last = {}
 
-    def step():
-        faces.grad = None
-        textures.grad = None
-        rgb, alpha, depth = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)(faces, textures)
-        if gather_buf is not None:
-            dist.all_gather_into_tensor(gather_buf, rgb.detach())
-        torch.autograd.backward([rgb, alpha, depth], [g_rgb, g_alpha, g_depth])
+    def make_step(f, t, size, grads):
+        def step():
+            f.grad = None
+            t.grad = None
+            fn = nr.Rasterize(size, 0.1, 100, eps, (0, 0, 0), True, True, True)
+            fn.exact_gradient = args.exact
+            rgb, alpha, depth = fn(f, t)
+            if gather_buf is not None:
+                dist.all_gather_into_tensor(gather_buf, rgb.detach())
+            torch.autograd.backward([rgb, alpha, depth], list(grads))
+            last['fi'] = fn.face_index_map
+        return step
+
+    step = make_step(faces, textures, S, (g_rgb, g_alpha, g_depth))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Optional: capture the step (~15 launches) once in a HIP graph and replay it.  Measured on MI355X: 0.947 ms
-    # replayed vs 0.941 ms eager -- the stream is already GPU-bound, so eager launches stay the default.
+    # Optional: capture the step once in a HIP graph and replay it (B = 64 is GPU-bound: no gain; small batches are
+    # host-bound and gain, see scripts/bench_configs.py).
     run, mode = step, 'eager'
     if args.graph and gather_buf is None:
-        try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            run, mode = graph.replay, 'hipgraph'
-        except Exception as ex:  # pragma: no cover
-            if rank == 0:
-                print('graph capture failed (%s); timing eager launches' % ex, file=sys.stderr)
-            run, mode = step, 'eager'
-            torch.cuda.synchronize(dev)
+        from neural_renderer_amd.graph import capture
+        run, mode = capture(step, dev), 'hipgraph'
 
     for _ in range(args.warmup):
         run()
@@ -300,14 +410,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eager_ms = None
     if mode == 'hipgraph':  # also report the eager number
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        eager_ms = time_step(step, dev, args.steps, 2)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -318,57 +421,64 @@ def main():
     value = total_pixels / (ms_per_step * 1e-3) / 1e6
 
     if rank == 0:
-        # parity of the benchmarked configuration: gradient of view 0 against the oracle
-        from oracle import oracle as O
-        O.build()
-        ref = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
-        ref(faces[:1].detach().cpu().numpy(), textures[:1].detach().cpu().numpy())
-        r_gf, r_gt = ref.backward(g_rgb[:1].cpu().numpy(), g_alpha[:1].cpu().numpy(), g_depth[:1].cpu().numpy())
-        gf, gt = faces.grad[:1].cpu().numpy(), textures.grad[:1].cpu().numpy()
-        grad_err = {
-            'grad_faces_max_abs_err': float(np.abs(gf - r_gf).max()),
-            'grad_faces_max_abs': float(np.abs(r_gf).max()),
-            'grad_textures_max_abs_err': float(np.abs(gt - r_gt).max()),
-            'grad_textures_max_abs': float(np.abs(r_gt).max()),
-            'checked': 'view 0 of rank 0 vs oracle',
-        }
+        step()  # gradients of the checked batch (a graph replay leaves them in the captured tensors' .grad as well)
+        torch.cuda.synchronize(dev)
+        check = grad_check(last['fi'], faces, textures, S, eps, g_rgb, g_alpha, g_depth,
+                           min(B, 2 if args.light else args.check_views))
 
-        stages = time_stages(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth, args.stage_iters)
-        ab = algorithmic_bytes(B, F, S, ts)
-        # kernel -> owning stage timing.  The forward visibility stage is two kernels (setup + tiles).
-        stage_bytes = {
-            'forward_face_index_map': ab['face_setup'] + ab['raster_tiles'],
-            'forward_texture_sampling': ab['shade'],
-            'backward_pixel_map': ab['backward_pixel_map'],
-            'backward_textures': ab['backward_textures'],
-            'backward_depth_map': ab['backward_depth_map'],
-        }
+        k6_flags = 2 if args.exact else 0
+        stages = time_stages(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth, args.stage_iters, k6_flags)
+        stage_bytes = algorithmic_bytes(B, F, S, ts)
         dominant = max(stage_bytes, key=lambda k: stages[k])
         achieved = stage_bytes[dominant] / (stages[dominant] * 1e-6) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(dominant, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        prof = profile_records().get('pmc', {})
+        traffic_rec = prof.get(dominant, {})
+        step_bytes = whole_step_bytes(B, F, S, ts)
         roofline = {
-            'bound': 'hbm', 'kernel': STAGE_KERNEL.get(dominant, dominant), 'stage': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+            'bound': 'hbm', 'kernel': ('k_bpm_band' if args.exact and dominant == 'backward_pixel_map' else STAGE_KERNEL.get(dominant, dominant)),
+            'stage': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': None,
+            'traffic_from_profiles': {
+                'hbm_bytes_per_launch': traffic_rec.get('hbm_bytes_per_launch'), 'source': 'profiles/pmc_latest.json',
+                'note': 'FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_profile_round.sh on the committed build; NOT measured '
+                        'in this run (counters cannot be collected inside a timed run)'},
             'algorithmic_bytes_per_launch': stage_bytes[dominant], 'avg_launch_us': stages[dominant],
             'timing': 'HIP events on the launch stream around the stage call nr_%s (the dominant kernel plus its '
                       'helper launches; profiles/README.md lists the per-kernel rocprofv3 durations they add up from)' % dominant,
             'whole_step': {
-                'algorithmic_bytes': sum(stage_bytes.values()),
-                'achieved': sum(stage_bytes.values()) / (ms_per_step * 1e-3) / 1e9,
-                'frac': sum(stage_bytes.values()) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'algorithmic_bytes': step_bytes, 'definition': 'SURVEY 8d: 92 B/pixel + (108 + 24 ts^3) B/face for rgb+alpha+depth',
+                'achieved': step_bytes / (ms_per_step * 1e-3) / 1e9,
+                'frac': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
-        e2e = renderer_end_to_end(dev, B, rank * B, world * B, S, ts)
+        valu = prof.get('_valu_issue', {})
+        if valu.get('insts_valu_per_launch'):
+            floor_us = valu['insts_valu_per_launch'] * NS_PER_WAVE_INSTR / NUM_SIMDS * 1e-3
+            roofline['valu_issue'] = {
+                'kernel': valu.get('kernel'), 'insts_valu_per_launch': valu['insts_valu_per_launch'],
+                'ns_per_wave_instr_per_simd': NS_PER_WAVE_INSTR, 'simds': NUM_SIMDS, 'issue_floor_us': floor_us,
+                'stage_us': stages['backward_pixel_map'], 'frac': floor_us / stages['backward_pixel_map'],
+                'source': 'SQ_INSTS_VALU from profiles/pmc_latest.json (' + str(valu.get('source')) + '); stage time measured in this run'}
+        extra_rows, e2e = [], None
+        if not args.light:
+            # anti-aliasing on: raster 2 x image_size (the Renderer default), same views
+            faces2 = faces.detach().clone().requires_grad_(True)
+            tex2 = textures.detach().clone().requires_grad_(True)
+            g2 = upstream_gradients(faces2, tex2, 2 * S, eps, 4321)
+            ms2 = time_step(make_step(faces2, tex2, 2 * S, g2), dev, max(3, args.steps // 4), 2)
+            extra_rows.append({'row': 'anti_aliasing on: raster %dx%d for image_size %d' % (2 * S, 2 * S, S), 'ms_per_step': ms2,
+                               'mpixel_per_s_raster': B * 4 * S * S / (ms2 * 1e-3) / 1e6,
+                               'mpixel_per_s_image': B * S * S / (ms2 * 1e-3) / 1e6})
+            del faces2, tex2, g2
+            ones = upstream_gradients(faces, textures, S, eps, 0, all_ones=True)
+            ms3 = time_step(make_step(faces, textures, S, ones), dev, args.steps, 2)
+            extra_rows.append({'row': 'all-ones upstream gradient (reference misc/measure_time.py:60)', 'ms_per_step': ms3,
+                               'mpixel_per_s_raster': B * S * S / (ms3 * 1e-3) / 1e6})
+            e2e = renderer_end_to_end(dev, B, rank * B, world * B, S, ts)
         cpu = None
         if args.cpu_sample_views > 0 and world == 1:
             cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
-                               min(args.cpu_sample_views, B))
+                               min(args.cpu_sample_views, B), light=args.light)
         line = {
             'metric': 'rasterize fwd+bwd Mpixels/sec @256x256 batch=64', 'value': value, 'unit': 'Mpixel/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -378,11 +488,12 @@ def main():
                             '(anti_aliasing off), texture_size %d, rgb+alpha+depth forward + backward through the '
                             'Rasterize autograd operator' % (F, B, S, S, ts),
                 'views_per_gpu': B, 'image_size': S, 'num_faces': F, 'texture_size': ts, 'eps': eps,
+                'k6_numerics': 'exact (reference arithmetic per term)' if args.exact else 'default (float terms via v_rcp_f32, <= 1e-5)',
                 'parallelism': 'batch-of-views sharded over %d GPU(s), no collective%s'
                                % (world, ' + all_gather(rgb)' if gather_buf is not None else ''),
             },
-            'roofline': roofline, 'cpu_baseline': cpu, 'stages_us': stages, 'grad_check': grad_err,
-            'launch_mode': mode, 'eager_ms_per_step': eager_ms, 'renderer_end_to_end': e2e,
+            'roofline': roofline, 'cpu_baseline': cpu, 'stages_us': stages, 'grad_check': check,
+            'extra_rows': extra_rows, 'launch_mode': mode, 'eager_ms_per_step': eager_ms, 'renderer_end_to_end': e2e,
         }
         print(json.dumps(line))
     if dist is not None:

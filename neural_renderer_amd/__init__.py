@@ -18,8 +18,10 @@ from .load_obj import load_obj
 from .mesh import Mesh
 from .optimizers import Adam
 from .save_obj import save_obj
+# not in the reference: multi-GPU helpers and the captured-graph helper for fixed-shape loops
+from . import distributed, graph
 
-__version__ = '0.1.1'
+__version__ = '0.2.0'
 __all__ = ['Rasterize', 'rasterize', 'rasterize_depth', 'rasterize_rgbad', 'rasterize_silhouettes', 'use_unsafe_rasterizer',
            'Renderer', 'cross', 'get_points_from_angles', 'lighting', 'look', 'look_at', 'perspective', 'vertices_to_faces',
            'load_obj', 'Mesh', 'Adam', 'save_obj']

@@ -1,0 +1,37 @@
+"""Captured-HIP-graph helper for fixed-shape loops (not in the reference; SURVEY has no counterpart).
+
+A render / optimisation step at small batch sizes (example 2: one 512x512 view; BASELINE config 2: 16 views) is bound by
+host time: ~15 kernel launches, a dozen allocations and two autograd.Function round trips take longer to ISSUE than the
+GPU needs to run them.  Every launch of libnr_hip.so goes to the caller's stream and none of them synchronises or calls a
+capture-hostile API, so a whole step -- forward, loss, backward, optimizer -- can be captured once with
+torch.cuda.CUDAGraph (= hipGraph on ROCm) and replayed with one host call.
+
+    step = nr.graph.capture(lambda: train_step(), device)     # train_step reads / writes fixed tensors
+    for _ in range(300):
+        step()
+
+Rules of graph capture apply: the callable must use the same tensors every time (update inputs with `.copy_()`), must not
+synchronise or move data to the host, and an optimizer must keep its step counter on the device
+(`torch.optim.Adam(..., capturable=True)`).  The library's only per-process state -- the dynamic-LDS limit already granted
+to a kernel -- is settled by the warm-up calls, which run outside the capture."""
+import torch
+
+
+def capture(fn, device=None, warmup=3):
+    """Run `fn` `warmup` times on a side stream (allocator and kernel attributes settle), capture one more call into a
+    graph and return a zero-argument callable that replays it.  Tensors created inside `fn` live in the graph's private
+    pool: read results from the tensors `fn` assigns to (e.g. `.grad` fields or pre-allocated outputs)."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            fn()
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize(device)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    replay = graph.replay
+    replay.graph = graph  # keep the graph (and its memory pool) alive with the callable
+    return replay

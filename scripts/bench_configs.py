@@ -33,7 +33,7 @@ def timeit(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-def run(name, faces, textures, S, modes, eps, iters=10):
+def run(name, faces, textures, S, modes, eps, iters=10, graph=False):
     rgb, alpha, depth = modes
     faces = faces.clone().requires_grad_(True)
     if textures is not None:
@@ -59,10 +59,14 @@ def run(name, faces, textures, S, modes, eps, iters=10):
 
     ms = timeit(step, iters)
     ms_f = timeit(fwd, iters)
-    print(json.dumps({'config': name, 'B': B, 'F': F, 'S': S, 'ts': 0 if textures is None else textures.shape[2],
-                      'modes': ''.join(c for c, m in zip('rad', modes) if m), 'coverage': round(cov, 4),
-                      'ms_fwd_bwd': round(ms, 4), 'ms_fwd': round(ms_f, 4),
-                      'mpixel_s': round(B * S * S / ms / 1e3, 1)}), flush=True)
+    row = {'config': name, 'B': B, 'F': F, 'S': S, 'ts': 0 if textures is None else textures.shape[2],
+           'modes': ''.join(c for c, m in zip('rad', modes) if m), 'coverage': round(cov, 4),
+           'ms_fwd_bwd': round(ms, 4), 'ms_fwd': round(ms_f, 4), 'mpixel_s': round(B * S * S / ms / 1e3, 1)}
+    if graph:  # the same step replayed from a captured HIP graph (neural_renderer_amd.graph): host-bound sizes only
+        replay = nr.graph.capture(step, dev)
+        ms_g = timeit(replay, iters)
+        row.update(ms_fwd_bwd_hipgraph=round(ms_g, 4), mpixel_s_hipgraph=round(B * S * S / ms_g / 1e3, 1))
+    print(json.dumps(row), flush=True)
 
 
 def main():
@@ -74,7 +78,7 @@ def main():
             run('%s S%d' % (name, S), faces, textures, S, modes, eps)
     # config 2: 16 azimuth views, RGB + depth + silhouette
     faces, textures = bench.build_scene(dev, 16, 0, 16, 256, 2)
-    run('C2 teapot 16 views', faces, textures, 256, (True, True, True), 1e-3)
+    run('C2 teapot 16 views', faces, textures, 256, (True, True, True), 1e-3, iters=30, graph=True)
     # config 3: example2, teapot -> rectangle silhouette loss through the public Renderer (256x256, anti-aliasing on), 300 Adam steps
     sys.path.insert(0, os.path.join(ROOT, 'examples'))
     import make_data
@@ -96,6 +100,29 @@ def main():
     ms = (time.perf_counter() - t0) / 300 * 1e3
     print(json.dumps({'config': 'C3 example2 vertex optimisation, 300 Adam steps', 'B': 1, 'S': 512, 'ms_per_step': round(ms, 4),
                       'loss_first': round(float(losses[0]), 2), 'loss_last': round(float(losses[-1]), 2)}), flush=True)
+    # the same loop with the whole step (render, loss, backward, Adam) captured once in a HIP graph
+    model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    loss_buf = torch.zeros((), device=dev)
+
+    def train_step():
+        opt.zero_grad(set_to_none=False)
+        loss = model()
+        loss.backward()
+        opt.step()
+        loss_buf.copy_(loss.detach())
+
+    replay = nr.graph.capture(train_step, dev, warmup=3)  # 3 warm-up + 1 captured step are real Adam steps
+    first = float(loss_buf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(296):
+        replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 296 * 1e3
+    print(json.dumps({'config': 'C3 example2, whole step replayed from a HIP graph (Adam capturable)', 'B': 1, 'S': 512,
+                      'ms_per_step': round(ms, 4), 'loss_after_4_steps': round(first, 2),
+                      'loss_last': round(float(loss_buf), 2)}), flush=True)
     # config 4 (per-GPU share): 64 distinct ~5k-face meshes (10 240 with fill_back), ts 4 random textures, 256x256 RGB
     from test_hip_parity import icosphere, project_mesh
     rng = np.random.default_rng(1234)

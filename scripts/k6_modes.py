@@ -27,6 +27,7 @@ def t(call, n=10):
     for _ in range(n): call()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-a_only = lambda: lib.nr_backward_pixel_map(faces.data_ptr(), fi.data_ptr(), None, alpha.data_ptr(), None, g.data_ptr(), gf.data_ptr(), B, F, S, 1e-4, 0, 1, ws.data_ptr(), wsb, st)
-r_only = lambda: lib.nr_backward_pixel_map(faces.data_ptr(), fi.data_ptr(), rgb.data_ptr(), None, g_rgb.data_ptr(), None, gf.data_ptr(), B, F, S, 1e-3, 1, 0, ws.data_ptr(), wsb, st)
-print(os.environ.get('NR_K6_LDS_KB'), 'alpha-only K6 us', round(t(a_only), 1), 'rgb-only', round(t(r_only), 1))
+for flags, label in ((0, 'default'), (2, 'exact')):
+    a_only = lambda: lib.nr_backward_pixel_map(faces.data_ptr(), fi.data_ptr(), None, alpha.data_ptr(), None, g.data_ptr(), gf.data_ptr(), B, F, S, 1e-4, 0, 1, flags, None, ws.data_ptr(), wsb, st)
+    r_only = lambda: lib.nr_backward_pixel_map(faces.data_ptr(), fi.data_ptr(), rgb.data_ptr(), None, g_rgb.data_ptr(), None, gf.data_ptr(), B, F, S, 1e-3, 1, 0, flags, None, ws.data_ptr(), wsb, st)
+    print(label, 'alpha-only K6 us', round(t(a_only), 1), 'rgb-only', round(t(r_only), 1))

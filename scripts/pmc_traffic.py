@@ -12,6 +12,8 @@ import sys
 
 STAGE_OF = {  # kernel-name substring -> bench.py stage key
     'k_bpm_band': 'backward_pixel_map',
+    'k_bpm_fast': 'backward_pixel_map',
+    'k_compact_small': 'backward_pixel_map',
     'k_face_raster': 'forward_face_index_map',
     'k_resolve': 'forward_face_index_map',
     'k_shade': 'forward_texture_sampling',

@@ -14,5 +14,6 @@ with torch.no_grad():
     g_rgb = (2 * (rgb0 - torch.rand(rgb0.shape, generator=gen).to(dev))).contiguous()
     g_alpha = (2 * (alpha0 - torch.rand(alpha0.shape, generator=gen).to(dev))).contiguous()
     g_depth = (2 * (depth0 / 100.0 - torch.rand(depth0.shape, generator=gen).to(dev)) / 100.0).contiguous()
-st = bench.time_stages(faces, textures, S, 1e-3, g_rgb, g_alpha, g_depth, int(os.environ.get('ITERS', 10)))
+st = bench.time_stages(faces, textures, S, 1e-3, g_rgb, g_alpha, g_depth, int(os.environ.get('ITERS', 10)),
+                       int(os.environ.get('NR_STAGE_FLAGS', 0)))
 print(os.environ.get('TAG', ''), json.dumps({k: round(v, 1) for k, v in st.items()}))

@@ -29,8 +29,17 @@ def test_bench_json_line():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['achieved'] > 0
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c and c['unit'] == d['unit']
+    assert c['all_cores']['value'] > 0 and c['all_cores']['cores'] >= 1 and c['numpy_naive_config1']['value'] > 0
     g = d['grad_check']
-    assert g['grad_faces_max_abs_err'] <= 1e-4 * g['grad_faces_max_abs']
+    assert g['face_index_mismatch'] == 0
+    assert g['grad_faces']['max_abs_err'] <= 1e-4 * g['grad_faces']['max_abs']
+    assert g['grad_textures']['max_abs_err'] <= 1e-4 * g['grad_textures']['max_abs']
+    assert g['grad_faces']['max_rel_err_floor_1e-3_of_max'] <= 1e-5
+    w = r['whole_step']
+    assert w['algorithmic_bytes'] == 92 * 4 * 256 * 256 + (108 + 24 * 8) * 4 * d['config']['num_faces']
+    assert r['traffic'] is None and 'traffic_from_profiles' in r
+    assert len(d['extra_rows']) == 2 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
+    assert d['renderer_end_to_end']['frontend'] == 'fused'
 
 
 def test_bench_refuses_to_run_without_a_gpu():
