@@ -312,7 +312,7 @@ def grad_check(nr_fn_fi, faces, textures, S, eps, g_rgb, g_alpha, g_depth, n_vie
     return {'face_index_mismatch': int((fi != ref.face_index_map).sum()), 'grad_faces': stats(gf, r_gf),
             'grad_textures': stats(gt, r_gt),
             'checked': '%d views of rank 0 vs oracle (terms summed in double); elementwise max-rel-err is dominated by entries '
-                       'that cancel to ~0 (the tests bound the floor form at 1e-5)' % n_views}
+                       'that cancel to ~0 (the tests bound the floor form by the north star\'s 1e-4; NR_FLAG_EXACT_GRADIENT: 2e-6)' % n_views}
 
 
 def profile_records():
@@ -368,9 +368,7 @@ def main():
     textures.requires_grad_(True)
     g_rgb, g_alpha, g_depth = upstream_gradients(faces, textures, S, eps, 1234 + rank)
 
-    gather_buf = None
-    if args.gather and world > 1:
-        gather_buf = torch.empty((world * B, S, S, 3), device=dev)
+    gather = args.gather and world > 1
     last = {}
 
     def make_step(f, t, size, grads):
@@ -380,8 +378,8 @@ def main():
             fn = nr.Rasterize(size, 0.1, 100, eps, (0, 0, 0), True, True, True)
             fn.exact_gradient = args.exact
             rgb, alpha, depth = fn(f, t)
-            if gather_buf is not None:
-                dist.all_gather_into_tensor(gather_buf, rgb.detach())
+            if gather:  # the downstream loss wants the whole batch: one all-gather of the rendered shards (RCCL over xGMI)
+                last['gathered'] = nrd.all_gather_images(rgb.detach(), total=world * B)
             torch.autograd.backward([rgb, alpha, depth], list(grads))
             last['fi'] = fn.face_index_map
         return step
@@ -396,7 +394,7 @@ def main():
     # Optional: capture the step once in a HIP graph and replay it (B = 64 is GPU-bound: no gain; small batches are
     # host-bound and gain, see scripts/bench_configs.py).
     run, mode = step, 'eager'
-    if args.graph and gather_buf is None:
+    if args.graph and not gather:
         from neural_renderer_amd.graph import capture
         run, mode = capture(step, dev), 'hipgraph'
 
@@ -490,7 +488,7 @@ def main():
                 'views_per_gpu': B, 'image_size': S, 'num_faces': F, 'texture_size': ts, 'eps': eps,
                 'k6_numerics': 'exact (reference arithmetic per term)' if args.exact else 'default (float terms via v_rcp_f32, <= 1e-5)',
                 'parallelism': 'batch-of-views sharded over %d GPU(s), no collective%s'
-                               % (world, ' + all_gather(rgb)' if gather_buf is not None else ''),
+                               % (world, ' + all_gather(rgb)' if gather else ''),
             },
             'roofline': roofline, 'cpu_baseline': cpu, 'stages_us': stages, 'grad_check': check,
             'extra_rows': extra_rows, 'launch_mode': mode, 'eager_ms_per_step': eager_ms, 'renderer_end_to_end': e2e,

@@ -45,5 +45,21 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_variant(tag, defines, verbose=False):
+    """Development aid: the same sources with extra -D macros into libnr_hip_<tag>.so, so that one GPU session can time
+    alternatives of a kernel side by side (scripts pick the library through the NR_HIP_LIB environment variable, read by
+    neural_renderer_amd._lib -- the library itself reads no environment).  Not used by the product."""
+    out = os.path.join(HERE, 'libnr_hip_%s.so' % tag)
+    cmd = [hipcc()] + HIPCC_FLAGS + ['-D%s' % d for d in defines] + SOURCES + ['-o', out]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 2:  # python -m neural_renderer_amd._build <tag> NAME=VALUE ...
+        print(build_variant(sys.argv[1], sys.argv[2:], verbose=True))
+    else:
+        print(build(force=True, verbose=True))

@@ -69,7 +69,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get('NR_HIP_LIB') or _build.LIB_PATH  # NR_HIP_LIB: a variant build (development timing runs)
     if not os.path.exists(path):
         raise NRError('%s not found: build it with `python -m neural_renderer_amd._build` '
                       '(or __graft_entry__.build()); there is no CPU/eager fallback.' % path)

@@ -253,15 +253,17 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 //   k_bpm_band  EXACT: every per-pixel term is computed with the reference's arithmetic (IEEE division, the double
 //          `dist +- eps`), sums in double: the result is the correctly rounded sum of the reference's terms up to double
 //          round-off (<= 2e-6 against the exactly summed oracle).
-//   k_bpm_fast  the north star's tolerance (1e-4) spent where it buys time: per pixel the band keeps
-//          q = sum_c I_c * g_c and the gradients g_c (24 B instead of 36 B), so a visit is diff = q - sum_c ref_c * g_c
-//          (4 fma), dist = fma(c * 2/S, t, +-eps) in float, diff * v_rcp_f32(dist), float sums over the <= 15 terms of a
-//          segment, double from there on.  Per-term deviation ~1e-7; measured <= 1e-5 on a face gradient across the
-//          test suite (tests assert it).  ~30 issue slots per visit instead of ~95.
+//   k_bpm_fast  the north star's tolerance (1e-4) spent where it buys time: fused multiply-adds for the colour difference,
+//          dist = fma(c * 2/S, t, +-eps) in float and diff * v_rcp_f32(dist) instead of two IEEE divisions and the double
+//          `dist +- eps`, float sums over the <= 15 terms of a segment, double from there on; pixel data as 40-byte records
+//          read with three LDS instructions.  ~24 issue slots per visit instead of ~95; deviation see the kernel's comment.
 constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per pass
 constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
-constexpr int SEG = 15;          // pixels of a sweep walked by one thread (odd: consecutive segments of a
+#ifndef NR_SEG
+#define NR_SEG 15
+#endif
+constexpr int SEG = NR_SEG;      // pixels of a sweep walked by one thread (odd: consecutive segments of a
                                  // sweep start 15 dwords apart, i.e. on different LDS banks)
 
 struct __attribute__((aligned(16))) BandLine {
@@ -271,15 +273,6 @@ struct __attribute__((aligned(16))) BandLine {
     int tgt;      // slot | v0 << 16 | v1 << 18
     float cross, c0, c1;
     int fn;
-};
-
-// the fast kernel's record: the same 32 bytes (c0 / c1 pre-multiplied by 2 / S) + the colours of the in / out pixel
-struct __attribute__((aligned(16))) FastLine {
-    int in_rng, out_rng, geo, tgt;
-    float cross, c0k, c1k;
-    int fn;
-    float ref_in[4];   // alpha, r, g, b of the in pixel  (reference colour of the OUT sweep)
-    float ref_out[4];  // alpha, r, g, b of the out pixel (reference colour of the IN sweep)
 };
 
 __global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict__ fi_map,
@@ -479,7 +472,7 @@ struct SegRange {
     bool mode_in;
 };
 __device__ __forceinline__ SegRange decode_segment(int sid, int total_full, int n_win, const int *s_pref,
-                                                   const int *line_words /* BandLine / FastLine array */, int stride_words)
+                                                   const int *line_words /* BandLine array */, int stride_words)
 {
     SegRange r;
     const bool is_full = sid < total_full;
@@ -824,16 +817,42 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
 }
 
 // --------------------------------------------------------------------------------------------------
-// The tolerance-mode band kernel (default).  Same pipeline as k_bpm_band; differences:
-//   * LDS pixel data: face index, q = sum_c I_c * g_c, and the gradients g_c (SoA, [line][d1]);
-//   * line records carry the colours of the in / out pixel (read from the maps in global memory, L2 hits);
-//   * a visit is 4 fma + compare + (fma, rcp, fma) x 2 in float.
+// The tolerance-mode band kernel (default).  Same pipeline and same line setup as k_bpm_band (which pixels are visited must
+// not depend on the mode); differences:
+//   * LDS pixel data as RECORDS of NP 8-byte pairs, [line][d1]: (face index, alpha) (r, g) (b, g_alpha) (g_r, g_g) (g_b, -)
+//     -- 40 bytes, read with ds_read2_b64 / ds_read_b64 at immediate offsets (3 LDS instructions and one wait per visit
+//     instead of 9 + 9).  Consecutive segments of a sweep start SEG * 10 = 150 dwords apart, i.e. 22 banks: the 8-byte reads
+//     of 32 lanes cover every bank exactly once.  Alpha-only rasters use (face index, alpha) (g_alpha, -): 16 bytes;
+//   * a visit: diff = sum_c (I_c - ref_c) * g_c with fused multiply-adds (:631-638, :709-716), then per vertex
+//     dist = fma(c * 2/S, t, +-eps) in float and diff * v_rcp_f32(dist), float sums over the <= 15 terms of a segment,
+//     double from there on: ~24 issue slots per visit instead of ~95.
+// Deviation: every term is within ~2 ulp of the reference's (its IEEE division and double `dist +- eps`); a face gradient is
+// a sum of up to thousands of such terms of both signs, so after cancellation the deviation measured against the exactly
+// summed reference terms is 1e-6 .. 3e-5 of the largest gradient (tests bound it by the north star's 1e-4) -- the same
+// metric puts the reference's OWN serial float summation at 1e-5 .. 1e-3 from the exact sum.
 // Why `0 < dist` can be decided on t = d1 - d1_cross alone: c0 = (p1x - p0x) / (p1x - d0) and c1 = (p1x - p0x) / (d0 - p0x)
 // are quotients of equally signed numbers whenever the contribution is taken (d0 lies between p0x and p1x and differs from
 // the vertex in the denominator, :648 / :653), i.e. c >= 1 > 0, and 2 / S > 0: sign(dist) = sign(t), and dist = +-0 exactly
 // when t = 0 (then `0 < dist` is false: - eps, as here).  When the contribution is NOT taken the coefficient is +-Inf / NaN;
 // the lane then accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
-template <bool RGB, bool ALPHA>
+#ifdef NR_K6_PHASES  // development build: cycles spent per phase, summed over workgroups (scripts/k6_phases.py)
+__device__ unsigned long long g_k6_phase[8];
+#define NR_PHASE_BEGIN() unsigned long long ph_t = clock64()
+#define NR_PHASE(k)                                                                 \
+    do {                                                                            \
+        __syncthreads();                                                            \
+        if (threadIdx.x == 0) {                                                     \
+            const unsigned long long now = clock64();                               \
+            atomicAdd(&g_k6_phase[k], now - ph_t);                                  \
+            ph_t = now;                                                             \
+        }                                                                           \
+    } while (0)
+#else
+#define NR_PHASE_BEGIN() do {} while (0)
+#define NR_PHASE(k) do {} while (0)
+#endif
+
+template <bool RGB, bool ALPHA, int WIN>
 __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
@@ -851,34 +870,38 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const int nld = band_hi - band_lo + 1;
     const int n_vis = vis_count[b];
     const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
-    if (!band_has_lines(rng_ba, n_vis, band_lo, band_hi)) return;  // step 0
+    NR_PHASE_BEGIN();
+    if (!band_has_lines(rng_ba, n_vis, band_lo, band_hi)) {  // step 0
+        NR_PHASE(0);
+        return;
+    }
+    NR_PHASE(0);
 
     size_t off = 0;
     auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    // pixel records, [line][d1], NP 8-byte pairs each: (face index, q) (g_alpha | g_r, g_r | g_g) (g_g, g_b).  One record =
-    // NP ds_read_b64 with immediate offsets (a single wait); consecutive segments of a sweep are SEG * NP * 2 dwords apart,
-    // which spreads the 8-byte reads of a wave over all banks for NP = 3 (90 dwords: every even bank once per 32 lanes).
-    constexpr int NP = RGB ? 3 : 2;
+    constexpr int NP = RGB ? 5 : 2;  // 8-byte pairs per pixel record
     float2 *s_px = (float2 *)carve((size_t)W * SP * NP * 8);
-    FastLine *s_line = (FastLine *)carve(sizeof(FastLine) * BAND_WIN);
-    int *s_rec = (int *)carve(4 * BAND_WIN);
-    int *s_pref = (int *)carve(4 * BAND_WIN);
-    int *s_recfn = (int *)carve(4 * BAND_WIN);
+    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
+    int *s_rec = (int *)carve(4 * WIN);
+    int *s_pref = (int *)carve(4 * WIN);
+    int *s_recfn = (int *)carve(4 * WIN);
     double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);
     int *s_slotpos = (int *)carve(4 * ACC_SLOTS);
     int *s_tmp = (int *)carve(4 * 16);
 
-    // ---- 1. stage the band.  One thread owns one pixel: it needs all of the pixel's colours and gradients for q.
+    // ---- 1. stage the band: one thread per pixel writes the pixel's record
     const size_t img = (size_t)b * S * S;
     auto put = [&](int l, int fi, float al, float ga, float r, float g, float bl, float gr, float gg, float gb) {
-        float q = 0.0f;
-        if (ALPHA) q = al * ga;
-        if (RGB) { q = __builtin_fmaf(r, gr, q); q = __builtin_fmaf(g, gg, q); q = __builtin_fmaf(bl, gb, q); }
         float2 *rec = s_px + (size_t)l * NP;
-        rec[0] = make_float2(__int_as_float(fi), q);
-        if (RGB && ALPHA) { rec[1] = make_float2(ga, gr); rec[2] = make_float2(gg, gb); }
-        else if (RGB) { rec[1] = make_float2(gr, gg); rec[2] = make_float2(gb, 0.0f); }
-        else rec[1] = make_float2(ga, 0.0f);
+        rec[0] = make_float2(__int_as_float(fi), al);
+        if (RGB) {
+            rec[1] = make_float2(r, g);
+            rec[2] = make_float2(bl, ga);
+            rec[3] = make_float2(gr, gg);
+            rec[4] = make_float2(gb, 0.0f);
+        } else {
+            rec[1] = make_float2(ga, 0.0f);
+        }
     };
     if (axis) {  // a band line is an image row: thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
         for (int i = tid; i < nld * S; i += BAND_THREADS) {
@@ -935,6 +958,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     }
     if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
     __syncthreads();
+    NR_PHASE(1);
 
     const float fs = (float)S;
     const float k2s = 2.0f / fs;
@@ -958,6 +982,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
         const int line_off = packed_off & 0xfffff, slot = packed_off >> 20;
         const int total_lines = total_packed & 0xfffff;
         if (nl > 0 && slot < ACC_SLOTS) s_slotpos[slot] = chunk + tid;
+        NR_PHASE(2);
 
         for (int win = 0; win < total_lines; win += win_lines) {
             if (nl > 0 && line_off < win + win_lines && line_off + nl > win) {
@@ -972,9 +997,10 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             }
             __syncthreads();
             const int n_win = min(total_lines - win, win_lines);
+            NR_PHASE(3);
 
-            // ---- 3. line setup, one line per thread: rasterize.py:543-579, :594-609, :665-672 (reference arithmetic: the
-            //         crossing points decide WHICH pixels are visited, which must not depend on the mode)
+            // ---- 3. line setup, one line per thread: rasterize.py:543-579, :604-609, :665-672 (the reference's arithmetic:
+            //         the crossing points decide WHICH pixels are visited, which must not depend on the mode)
             if (tid < n_win) {
                 const int rec = s_rec[tid];
                 const int slot = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
@@ -991,12 +1017,10 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                 if (axis == 0) direction = (p0x < p1x) ? -1 : 1; else direction = (p0x < p1x) ? 1 : -1;  // :559-564
                 const int d0 = band_lo + ld;
                 const float d0f = (float)d0;
-                FastLine r;
+                BandLine r;
                 r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = slot | (i0 << 16) | (i1 << 18);
-                r.cross = r.c0k = r.c1k = 0.0f;
+                r.cross = r.c0 = r.c1 = 0.0f;
                 r.fn = rfn;
-#pragma unroll
-                for (int k = 0; k < 4; k++) r.ref_in[k] = r.ref_out[k] = 0.0f;
                 const float d1_cross = (p1y - p0y) / (p1x - p0x) * (d0f - p0x) + p0y;                  // :573
                 const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);     // :574
                 const int d1_out = d1_in + direction;                                                 // :575
@@ -1004,15 +1028,15 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                     int flags = (0 < direction) ? 8 : 0;
                     if (p1x != d0f) flags |= 2;
                     if (p0x != d0f) flags |= 4;
-                    r.c0k = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor x 2 / S
-                    r.c1k = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
+                    r.c0 = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor x 2 / S
+                    r.c1 = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
                     if (__float_as_int(s_px[(size_t)(ld * SP + d1_in) * NP].x) == rfn) {  // :604-609
                         const int lim = (0 < direction) ? S - 1 : 0;
                         const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
                         r.out_rng = o_from | (o_to << 16);
                         flags |= 1;
                     }
-                    float d0_cross2;                          // :665-672
+                    float d0_cross2;                         // :665-672
                     if ((d0f - p0x) * (d0f - p2x) < 0)
                         d0_cross2 = (p2y - p0y) / (p2x - p0x) * (d0f - p0x) + p0y;
                     else
@@ -1022,23 +1046,16 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                     r.in_rng = i_from | (i_to << 16);
                     r.geo = d1_in | (ld << 16) | (flags << 24);
                     r.cross = d1_cross;
-                    // colours of the in / out pixel (:594-601) from the maps themselves
-                    const size_t g_in = axis ? img + (size_t)d0 * S + d1_in : img + (size_t)d1_in * S + d0;
-                    const size_t g_out = axis ? img + (size_t)d0 * S + d1_out : img + (size_t)d1_out * S + d0;
-                    if (ALPHA) { r.ref_in[0] = alpha_map[g_in]; r.ref_out[0] = alpha_map[g_out]; }
-                    if (RGB) {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) { r.ref_in[1 + k] = rgb_map[3 * g_in + k]; r.ref_out[1 + k] = rgb_map[3 * g_out + k]; }
-                    }
                 }
                 s_line[tid] = r;
             }
             __syncthreads();
+            NR_PHASE(4);
 
             // ---- 4. sweeps, one segment per thread (see k_bpm_band)
             int n_seg = 0;
             if (tid < n_win) {
-                const FastLine &L = s_line[tid];
+                const BandLine &L = s_line[tid];
                 const int il = (L.in_rng >> 16) - (L.in_rng & 0xffff) + 1, ol = (L.out_rng >> 16) - (L.out_rng & 0xffff) + 1;
                 const int full = (il > 0 ? il / SEG : 0) + (ol > 0 ? ol / SEG : 0);
                 const int part = (il > 0 && il % SEG != 0) + (ol > 0 && ol % SEG != 0);
@@ -1048,18 +1065,24 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
             if (tid < n_win) s_pref[tid] = seg_off;
             __syncthreads();
+            NR_PHASE(5);
             const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
+#ifndef NR_K6_NO_SWEEPS
             for (int sid = tid; sid < total_all; sid += BAND_THREADS) {
                 const SegRange sr = decode_segment(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
-                                                   (int)(sizeof(FastLine) / 4));
-                const FastLine *L = &s_line[sr.line];
+                                                   (int)(sizeof(BandLine) / 4));
+                const BandLine *L = &s_line[sr.line];
                 const int4 h = *reinterpret_cast<const int4 *>(L);
                 const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
                 const bool mode_in = sr.mode_in;
-                // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
-                const float4 ref = *reinterpret_cast<const float4 *>(mode_in ? L->ref_out : L->ref_in);
                 const int flags = (h.z >> 24) & 0xff;
                 const int base = ((h.z >> 16) & 0xff) * SP;
+                const int d1_in = h.z & 0xffff;
+                // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
+                const float2 *rp = s_px + (size_t)(base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in)) * NP;
+                float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
+                if (ALPHA) ra = rp[0].y;
+                if (RGB) { const float2 q = rp[1]; rr = q.x; rg = q.y; rb = rp[2].x; }
                 const float cross = c.x, c0k = c.y, c1k = c.z;
                 const int fnr = __float_as_int(c.w);
                 float f0 = 0.0f, f1 = 0.0f;
@@ -1067,23 +1090,18 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                 const int own = mode_in ? fnr : -2;  // only the in sweep tests ownership (:707); -2 is no face index
                 const float2 *px = s_px + (size_t)(base + sr.s_from) * NP;
                 for (int d1 = sr.s_from; d1 <= sr.s_to; ++d1, d1f += 1.0f, px += NP) {
-                    const float2 r0 = px[0], r1 = px[1];
-                    float diff = r0.y;  // sum_c I_c g_c - sum_c ref_c g_c  (:631-638, :709-716)
-                    if (RGB && ALPHA) {
-                        const float2 r2 = px[2];
-                        diff = __builtin_fmaf(-ref.x, r1.x, diff);
-                        diff = __builtin_fmaf(-ref.y, r1.y, diff);
-                        diff = __builtin_fmaf(-ref.z, r2.x, diff);
-                        diff = __builtin_fmaf(-ref.w, r2.y, diff);
-                    } else if (RGB) {
-                        const float2 r2 = px[2];
-                        diff = __builtin_fmaf(-ref.y, r1.x, diff);
-                        diff = __builtin_fmaf(-ref.z, r1.y, diff);
-                        diff = __builtin_fmaf(-ref.w, r2.x, diff);
+                    const float2 p0 = px[0], p1 = px[1];
+                    float diff;  // sum_c (I_c - ref_c) g_c  (:631-638, :709-716)
+                    if (RGB) {
+                        const float2 p2 = px[2], p3 = px[3], p4 = px[4];
+                        diff = ALPHA ? (p0.y - ra) * p2.y : 0.0f;
+                        diff = __builtin_fmaf(p1.x - rr, p3.x, diff);
+                        diff = __builtin_fmaf(p1.y - rg, p3.y, diff);
+                        diff = __builtin_fmaf(p2.x - rb, p4.x, diff);
                     } else {
-                        diff = __builtin_fmaf(-ref.x, r1.x, diff);
+                        diff = (p0.y - ra) * p1.x;
                     }
-                    const int fi = __float_as_int(r0.x);
+                    const int fi = __float_as_int(p0.x);
                     const bool owned = (mode_in ? fi : -2) == own;                   // :707
                     if (!owned || diff <= 0.0f) continue;                            // :647 / :717
                     const float t = d1f - cross;
@@ -1103,7 +1121,9 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                     if (a1 != 0.0) atomicAdd(dst + 2 * v1, a1);
                 }
             }
+#endif
             __syncthreads();
+            NR_PHASE(6);
         }
 
         // ---- 5. per-face sums of this chunk -> global double scratch
@@ -1117,6 +1137,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             }
         }
         __syncthreads();
+        NR_PHASE(7);
     }
 }
 
@@ -1164,22 +1185,31 @@ BpmLayout bpm_layout(int B, int F)
     return L;
 }
 
-constexpr size_t BAND_COMMON_LDS = 12 * BAND_WIN + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16;
-constexpr size_t LDS_BUDGET = 53 * 1024 + 512;  // three workgroups per 160 KB CU
+#ifndef NR_K6_LDS_BUDGET_KB
+#define NR_K6_LDS_BUDGET_KB 53
+#endif
+constexpr size_t LDS_BUDGET = NR_K6_LDS_BUDGET_KB * 1024 + 512;  // 53 KB: three workgroups per 160 KB CU
+constexpr int FAST_WIN_SMALL = 128;
 
-// band width (lines per workgroup) for the given raster size and modes; 0 = does not fit (global fallback)
-int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes)
+constexpr size_t band_fixed_lds(int win) { return (sizeof(BandLine) + 12) * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16; }
+
+// band width (lines per workgroup) and line window for the given raster size and modes; 0 = does not fit (global fallback)
+int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *win)
 {
-    const size_t per_px = exact ? 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0) : (rgb ? 24 : 16);
-    const size_t fixed = BAND_COMMON_LDS + (exact ? sizeof(BandLine) : sizeof(FastLine)) * BAND_WIN;
+    const size_t per_px = exact ? 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0) : (rgb ? 40 : 16);
     const size_t SP = (size_t)S + 4;
     // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
     // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
     for (int W = 4; W >= 1; W >>= 1) {
-        const size_t need = (size_t)W * SP * per_px + fixed;
-        if (need <= LDS_BUDGET || (W == 1 && need <= 160 * 1024)) {
-            *lds_bytes = need;
-            return W;
+        // the fast kernel's 40-byte records leave room for 256 line records only in narrow bands; three workgroups per CU
+        // with a 128-line window beat two with 256 (the phases of co-resident workgroups overlap)
+        for (int w = BAND_WIN; w >= (exact ? BAND_WIN : FAST_WIN_SMALL); w >>= 1) {
+            const size_t need = (size_t)W * SP * per_px + band_fixed_lds(w);
+            if (need <= LDS_BUDGET || (W == 1 && w == (exact ? BAND_WIN : FAST_WIN_SMALL) && need <= 160 * 1024)) {
+                *lds_bytes = need;
+                *win = w;
+                return W;
+            }
         }
     }
     return 0;
@@ -1219,17 +1249,17 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
     return 0;
 }
 
-template <bool RGB, bool ALPHA>
+template <bool RGB, bool ALPHA, int WIN>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch, int B,
                 int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
 {
     static LdsLimit limit;
-    auto kern = k_bpm_fast<RGB, ALPHA>;
+    auto kern = k_bpm_fast<RGB, ALPHA, WIN>;
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
-                       vis_list, vis_count, rng, scratch, F, S, W, S + 4, (float)eps, B, win_lines);
+                       vis_list, vis_count, rng, scratch, F, S, W, S + 4, (float)eps, B, min(win_lines, WIN));
     return 0;
 }
 
@@ -1261,7 +1291,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const bool exact = (flags & NR_FLAG_EXACT_GRADIENT) != 0;
 
     size_t lds = 0;
-    const int W = band_width(S, rgb, alpha, exact, &lds);
+    int win = BAND_WIN;
+    const int W = band_width(S, rgb, alpha, exact, &lds, &win);
     if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
         const dim3 grid((unsigned)n), block(WAVE);
         if (rgb && alpha)
@@ -1320,8 +1351,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
 #undef NR_BAND
     } else {
 #define NR_FAST(R, A)                                                                                                   \
-    launch_fast<R, A>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, \
-                      scratch, B, F, S, W, lds, eps, win_lines, st)
+    (win == BAND_WIN                                                                                                    \
+         ? launch_fast<R, A, BAND_WIN>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
+                                       vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st)                     \
+         : launch_fast<R, A, FAST_WIN_SMALL>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,    \
+                                             vis_list, vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st))
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
     }
@@ -1382,3 +1416,16 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
     }
     return 0;
 }
+
+#ifdef NR_K6_PHASES
+// development build only (not declared in include/nr_hip.h): cycles per phase of k_bpm_fast summed over workgroups
+NR_API int nr_debug_k6_phases(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_k6_phase), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_k6_phase), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif

@@ -106,7 +106,11 @@ __device__ __forceinline__ Cand face_candidates(float x0, float y0, float x1, fl
     const bool wild = !(len2 < __builtin_inff()) || !(fabsf(den) < __builtin_inff()) ||
                       !(fmaxf(fmaxf(fabsf(px[0]), fabsf(px[1])), fabsf(px[2])) < big) ||
                       !(fmaxf(fmaxf(fabsf(py[0]), fabsf(py[1])), fabsf(py[2])) < big);
-    if (thin && !wild) {
+    // A face is "thin" relative to its longest edge; with vertices far off-screen (a perspective division by z near 0) that
+    // edge can be 10^5 pixels long and the face still several pixels high on screen.  The 4-pixel strip is only conservative
+    // while 2^-18 * (longest edge in pixels) stays below half a pixel; beyond that the whole image is the candidate set.
+    const bool strip_ok = len2 * fs * fs * 0.25f * 0x1p-36f <= 0.25f;
+    if (thin && !wild && strip_ok) {
         // the longest edge: its direction from the NDC differences (exact for close vertices -- in pixel units a
         // micro-triangle's edge would be a few ulps of noise), its position from one endpoint in pixel units
         const int k = (l0 >= l1 && l0 >= l2) ? 0 : (l1 >= l2 ? 1 : 2);

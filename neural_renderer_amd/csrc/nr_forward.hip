@@ -7,6 +7,8 @@
 //   k_shade         F3  per pixel: trilinear texture sampling + background + alpha        (ref K4+K5, :361-465)
 #include "nr_device.h"
 
+#include <algorithm>
+
 using namespace nr;
 
 namespace {
@@ -116,16 +118,16 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                                                      unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
                                                      int S, double near_d, double far_d)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride loop: with gridDim.x * 256 / LPF >= n_faces_total every group takes exactly one face
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t / LPF < n_faces_total; t += gridDim.x * blockDim.x) {
     const int i = t / LPF, sub = t - i * LPF;
-    if (i >= n_faces_total) return;
     if (visible_faces && sub == 0) visible_faces[i] = 0;  // k_resolve raises the flags of the faces that win a pixel
     const float *f = faces + (size_t)i * 9;
     const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-    if (cd.n == 0) return;  // back faces, off-screen faces, coincident vertices
+    if (cd.n == 0) continue;  // back faces, off-screen faces, coincident vertices
     if (cd.strip || cd.n > SMALL_AREA) {  // strips (needles) and large boxes: a whole workgroup each, k_large_raster
         if (sub == 0) large_list[atomicAdd(n_large, 1) + 1] = i;  // the counter starts at -1 (one fill with the z-buffer)
-        return;
+        continue;
     }
     FaceGeo g;
     float inv[9];
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
         unsigned long long *zrow = zimg + (size_t)py * S;
         for (int px = cd.x_lo; px <= x_hi; ++px)
             raster_pixel(g, fnu, px, py, pixel_center_p(px, S, inv_s, pow2), yp, near_d, far_d, zrow);
+    }
     }
 }
 
@@ -358,8 +361,13 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     // one fill: ZEMPTY words and, right behind them, the large-face counter at -1
     const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
     if (he != hipSuccess) return (int)he;
-    hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
-                       n_large, visible_faces, (int)n, F, S, near, far);
+#ifdef NR_FWD_PERSIST  // development build: a resident grid walking the faces instead of one group of lanes per face
+    const unsigned fr_grid = (unsigned)std::min<size_t>((n * LPF + 255) / 256, (size_t)256 * NR_FWD_PERSIST);
+#else
+    const unsigned fr_grid = (unsigned)((n * LPF + 255) / 256);
+#endif
+    hipLaunchKernelGGL(k_face_raster, dim3(fr_grid), dim3(256), 0, st, faces, zbuf, large_list, n_large, visible_faces,
+                       (int)n, F, S, near, far);
     // a few workgroups per CU loop over the queue (one per CU left the kernel latency-bound: config 4, 189 -> ~85 us);
     // with an empty queue (any ordinary mesh) they read the counter and leave
     hipLaunchKernelGGL(k_large_raster, dim3(1024), dim3(256), 0, st, faces, zbuf, large_list, n_large, F, S, near, far);

@@ -82,6 +82,9 @@ def all_gather_images(images, total=None):
         return images
     world, rank = dist.get_world_size(), dist.get_rank()
     images = images.contiguous()
+    if images.is_cuda and dist.get_backend() == 'gloo':
+        # gloo (CPU rendezvous, e.g. several ranks sharing one GPU in a test) gathers host tensors: stage through the host
+        return all_gather_images(images.cpu(), total).to(images.device)
     if total is None:
         n = torch.tensor([images.shape[0]], device=images.device, dtype=torch.int64)
         sizes = [torch.zeros_like(n) for _ in range(world)]

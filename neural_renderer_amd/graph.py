@@ -32,6 +32,14 @@ def capture(fn, device=None, warmup=3):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         fn()
-    replay = graph.replay
-    replay.graph = graph  # keep the graph (and its memory pool) alive with the callable
-    return replay
+    return _Replay(graph)
+
+
+class _Replay(object):
+    """Zero-argument callable that replays a captured graph (and keeps it, with its memory pool, alive)."""
+
+    def __init__(self, graph):
+        self.graph = graph
+
+    def __call__(self):
+        self.graph.replay()

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Development GPU session: selected tests with full logs, one fuzz scene under the microscope, stage timings of variant
+# builds (NR_HIP_LIB), the per-phase profile of k_bpm_fast, the other BASELINE configurations.
+TAG=${1:-exp}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+rm -f gpurun_out/parity_errors.jsonl
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for f in ${TESTS:-tests/test_hip_parity.py tests/test_fuzz_gpu.py tests/test_full_size_gpu.py tests/test_multi_rank_gpu.py tests/test_bench_contract.py}; do
+  n=$(basename $f .py)
+  timeout 600 python -m pytest $f -m gpu -q --tb=short -p no:cacheprovider > $OUT/$n.log 2>&1
+  echo "=== $f: $(tail -1 $OUT/$n.log)"
+done
+cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
+timeout 120 python scripts/debug_fuzz_case.py 3 6 > $OUT/fuzz_3_6.log 2>&1
+for v in "" ${VARIANTS}; do
+  if [ -z "$v" ]; then unset NR_HIP_LIB; else export NR_HIP_LIB=$PWD/neural_renderer_amd/libnr_hip_$v.so; fi
+  TAG=base$v ITERS=20 timeout 200 python scripts/stage_times.py 2>/dev/null | tail -1 >> $OUT/variants.log
+done
+export NR_HIP_LIB=$PWD/neural_renderer_amd/libnr_hip_phases.so
+timeout 200 python scripts/k6_phases.py > $OUT/phases.log 2>&1
+unset NR_HIP_LIB
+if [ -n "$CONFIGS" ]; then timeout 900 python scripts/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err; fi
+cat $OUT/variants.log; cat $OUT/phases.log | tail -12; cat $OUT/fuzz_3_6.log | tail -8
+grep -E "^FAILED|^ERROR" $OUT/*.log | cut -c1-200 | head -40
+[ -n "$CONFIGS" ] && (cat $OUT/configs.jsonl | cut -c1-300; tail -3 $OUT/configs.err)

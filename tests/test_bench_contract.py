@@ -34,7 +34,7 @@ def test_bench_json_line():
     assert g['face_index_mismatch'] == 0
     assert g['grad_faces']['max_abs_err'] <= 1e-4 * g['grad_faces']['max_abs']
     assert g['grad_textures']['max_abs_err'] <= 1e-4 * g['grad_textures']['max_abs']
-    assert g['grad_faces']['max_rel_err_floor_1e-3_of_max'] <= 1e-5
+    assert g['grad_faces']['max_rel_err_floor_1e-3_of_max'] <= 1e-4
     w = r['whole_step']
     assert w['algorithmic_bytes'] == 92 * 4 * 256 * 256 + (108 + 24 * 8) * 4 * d['config']['num_faces']
     assert r['traffic'] is None and 'traffic_from_profiles' in r
