@@ -371,20 +371,21 @@ def main():
     gather = args.gather and world > 1
     last = {}
 
-    def make_step(f, t, size, grads):
+    def make_step(f, t, size, grads, with_gather=False):
         def step():
             f.grad = None
             t.grad = None
             fn = nr.Rasterize(size, 0.1, 100, eps, (0, 0, 0), True, True, True)
             fn.exact_gradient = args.exact
             rgb, alpha, depth = fn(f, t)
-            if gather:  # the downstream loss wants the whole batch: one all-gather of the rendered shards (RCCL over xGMI)
+            if with_gather:  # the downstream loss wants the whole batch: one all-gather of the rendered shards (RCCL / xGMI)
                 last['gathered'] = nrd.all_gather_images(rgb.detach(), total=world * B)
             torch.autograd.backward([rgb, alpha, depth], list(grads))
             last['fi'] = fn.face_index_map
         return step
 
-    step = make_step(faces, textures, S, (g_rgb, g_alpha, g_depth))
+    step = make_step(faces, textures, S, (g_rgb, g_alpha, g_depth), with_gather=gather)
+    local_step = make_step(faces, textures, S, (g_rgb, g_alpha, g_depth))  # rank-local work only: no collective inside
 
     def barrier():
         if dist is not None:
@@ -408,7 +409,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eager_ms = None
     if mode == 'hipgraph':  # also report the eager number
-        eager_ms = time_step(step, dev, args.steps, 2)
+        eager_ms = time_step(local_step, dev, args.steps, 2)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -419,7 +420,7 @@ def main():
     value = total_pixels / (ms_per_step * 1e-3) / 1e6
 
     if rank == 0:
-        step()  # gradients of the checked batch (a graph replay leaves them in the captured tensors' .grad as well)
+        local_step()  # gradients of the checked batch; rank 0 alone runs this, so it must not contain a collective
         torch.cuda.synchronize(dev)
         check = grad_check(last['fi'], faces, textures, S, eps, g_rgb, g_alpha, g_depth,
                            min(B, 2 if args.light else args.check_views))

@@ -300,7 +300,7 @@ __device__ __forceinline__ unsigned edge_range(float p0x, float p1x, int S)
 // chasing list -> vertices each) and six zeroed double sums.
 __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int S, const float *__restrict__ faces,
                                              int *__restrict__ vis_list, unsigned *__restrict__ rng,
-                                             double *__restrict__ scratch)
+                                             double *__restrict__ scratch, int *band_count, int n_bands, int W)
 {
     vis_list[(size_t)b * F + pos] = fn;
     const float *f = faces + ((size_t)b * F + fn) * 9;
@@ -311,8 +311,17 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
     unsigned *r0 = rng + (((size_t)b * 2 + 0) * F + pos) * 3, *r1 = rng + (((size_t)b * 2 + 1) * F + pos) * 3;
 #pragma unroll
     for (int e = 0; e < 3; e++) {
-        r0[e] = edge_range(px[e], px[(e + 1) % 3], S);
-        r1[e] = edge_range(py[e], py[(e + 1) % 3], S);
+        const unsigned ra = edge_range(px[e], px[(e + 1) % 3], S), rb = edge_range(py[e], py[(e + 1) % 3], S);
+        r0[e] = ra;
+        r1[e] = rb;
+        // lines per (axis, band of W lines): a band workgroup whose count is zero leaves at once
+#pragma unroll
+        for (int axis = 0; axis < 2; axis++) {
+            const unsigned r = axis ? rb : ra;
+            const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+            for (int band = lo / W; band * W <= hi; ++band)  // lo > hi (RNG_EMPTY): no iteration
+                atomicAdd(band_count + axis * n_bands + band, min(hi, band * W + W - 1) - max(lo, band * W) + 1);
+        }
     }
     double2 *z = reinterpret_cast<double2 *>(scratch + ((size_t)b * F + pos) * 6);
     z[0] = z[1] = z[2] = make_double2(0.0, 0.0);
@@ -329,10 +338,14 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char
                                                              int *__restrict__ vis_list, int *__restrict__ vis_count,
                                                              int *__restrict__ slot_of, int F, int n_chunks,
                                                              const float *__restrict__ faces, unsigned *__restrict__ rng,
-                                                             double *__restrict__ scratch, int S)
+                                                             double *__restrict__ scratch, int S,
+                                                             int *__restrict__ band_lines, int n_bands, int W)
 {
+    extern __shared__ int s_band[];  // [2][n_bands] lines per band of this image
     __shared__ int s_wcnt[VIS_CHUNK / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) s_band[i] = 0;
+    __syncthreads();
     int base = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int fn = chunk * VIS_CHUNK + tid;
@@ -350,18 +363,23 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char
         if (fn < F) {
             const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
             slot_of[(size_t)b * F + fn] = pos;
-            if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch);
+            if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W);
         }
         base += tot;
     }
+    __syncthreads();
+    for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) band_lines[(size_t)b * 2 * n_bands + i] = s_band[i];
     if (tid == 0) vis_count[b] = base;
 }
 
 __global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char *__restrict__ flags,
-                                                             int *__restrict__ chunk_count, int F, int n_chunks)
+                                                             int *__restrict__ chunk_count, int F, int n_chunks,
+                                                             int *__restrict__ band_lines, int n_bands)
 {
     __shared__ int s_wcnt[VIS_CHUNK / 64];
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the image's band counters are accumulated with global atomics by k_compact_visible: zero them here (one launch earlier)
+    for (int i = chunk * VIS_CHUNK + tid; i < 2 * n_bands; i += n_chunks * VIS_CHUNK) band_lines[(size_t)b * 2 * n_bands + i] = 0;
     const int fn = chunk * VIS_CHUNK + tid;
     const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
     const unsigned long long m = __ballot(v);
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
                                                                int *__restrict__ slot_of, int F, int n_chunks,
                                                                const float *__restrict__ faces,
                                                                unsigned *__restrict__ rng, double *__restrict__ scratch,
-                                                               int S)
+                                                               int S, int *__restrict__ band_lines, int n_bands, int W)
 {
     __shared__ int s_wcnt[VIS_CHUNK / 64];
     __shared__ int s_part[VIS_CHUNK / 64];
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
     if (fn < F) {
         const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
         slot_of[(size_t)b * F + fn] = pos;
-        if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch);
+        if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch, band_lines + (size_t)b * 2 * n_bands, n_bands, W);
     }
     if (chunk == n_chunks - 1 && tid == 0) {
         int base = 0;
@@ -452,17 +470,6 @@ __device__ __forceinline__ int vis_position(const int *__restrict__ list, int n,
         if (list[mid] < fn) lo = mid + 1; else hi = mid;
     }
     return lo;
-}
-
-// lines of the image's visible faces inside [band_lo, band_hi] along `axis`: does the band have any work?
-__device__ __forceinline__ bool band_has_lines(const unsigned *__restrict__ rng_ba, int n_vis, int band_lo, int band_hi)
-{
-    bool any = false;
-    for (int i = threadIdx.x; i < 3 * n_vis; i += BAND_THREADS) {
-        const unsigned pr = rng_ba[i];
-        any |= min((int)(pr >> 16), band_hi) >= max((int)(pr & 0xffffu), band_lo);
-    }
-    return __syncthreads_or(any) != 0;
 }
 
 // Segment id -> (line, sweep, pixel range): shared by the two band kernels.  s_pref holds, per line of the window, the
@@ -514,7 +521,8 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
-    double *__restrict__ scratch, int F, int S, int W, int SP, double eps, int B, int win_lines)
+    double *__restrict__ scratch, const int *__restrict__ band_lines, int F, int S, int W, int SP, double eps, int B,
+    int win_lines)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -529,9 +537,9 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
+    if (band_lines[((size_t)b * 2 + axis) * n_bands + band] == 0) return;  // step 0: no visible face has a line here
     const int n_vis = vis_count[b];
     const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
-    if (!band_has_lines(rng_ba, n_vis, band_lo, band_hi)) return;  // step 0
 
     // ---- LDS carve-out
     size_t off = 0;
@@ -818,23 +826,22 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
 
 // --------------------------------------------------------------------------------------------------
 // The tolerance-mode band kernel (default).  Same pipeline and same line setup as k_bpm_band (which pixels are visited must
-// not depend on the mode); differences:
-//   * LDS pixel data as RECORDS of NP 8-byte pairs, [line][d1]: (face index, alpha) (r, g) (b, g_alpha) (g_r, g_g) (g_b, -)
-//     -- 40 bytes, read with ds_read2_b64 / ds_read_b64 at immediate offsets (3 LDS instructions and one wait per visit
-//     instead of 9 + 9).  Consecutive segments of a sweep start SEG * 10 = 150 dwords apart, i.e. 22 banks: the 8-byte reads
-//     of 32 lanes cover every bank exactly once.  Alpha-only rasters use (face index, alpha) (g_alpha, -): 16 bytes;
-//   * a visit: diff = sum_c (I_c - ref_c) * g_c with fused multiply-adds (:631-638, :709-716), then per vertex
-//     dist = fma(c * 2/S, t, +-eps) in float and diff * v_rcp_f32(dist), float sums over the <= 15 terms of a segment,
-//     double from there on: ~24 issue slots per visit instead of ~95.
-// Deviation: every term is within ~2 ulp of the reference's (its IEEE division and double `dist +- eps`); a face gradient is
-// a sum of up to thousands of such terms of both signs, so after cancellation the deviation measured against the exactly
-// summed reference terms is 1e-6 .. 3e-5 of the largest gradient (tests bound it by the north star's 1e-4) -- the same
-// metric puts the reference's OWN serial float summation at 1e-5 .. 1e-3 from the exact sum.
-// Why `0 < dist` can be decided on t = d1 - d1_cross alone: c0 = (p1x - p0x) / (p1x - d0) and c1 = (p1x - p0x) / (d0 - p0x)
-// are quotients of equally signed numbers whenever the contribution is taken (d0 lies between p0x and p1x and differs from
-// the vertex in the denominator, :648 / :653), i.e. c >= 1 > 0, and 2 / S > 0: sign(dist) = sign(t), and dist = +-0 exactly
-// when t = 0 (then `0 < dist` is false: - eps, as here).  When the contribution is NOT taken the coefficient is +-Inf / NaN;
-// the lane then accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
+// not depend on the mode).  The sweeps of this kernel are bound by LDS bandwidth (64 lanes reading 64 unrelated pixels:
+// ~2-3 bank conflicts per access), so what it optimises is bytes per visit:
+//   * LDS pixel data in three arrays [line][d1]: the face index (4 B), the GRADIENTS (g_alpha, g_r, g_g, g_b: 16 B, one
+//     ds_read_b128) and the COLOURS (alpha, r, g, b: 16 B).  Seven of eight visits of an out sweep land on pixels no face
+//     covers, whose colour is the image's background (K5, rasterize.py:440-465: uncovered pixels of rgb_map hold the
+//     background colour, of alpha_map 0 -- the maps this entry point is documented to take): for those the colour is not
+//     read at all, it is a per-band constant picked up during staging.  20 bytes per visit instead of 36;
+//   * diff = sum_c (I_c - ref_c) * g_c with the reference's own operations and order (:631-638, :709-716: bit-identical,
+//     so `diff <= 0` decides exactly as the reference does), then per vertex dist = c * 2/S * t, +- eps by its sign in float,
+//     diff * v_rcp_f32(dist), float sums over the <= 15 terms of a segment, double from there on.
+// Deviation: a term differs from the reference's (IEEE division, double `dist +- eps`) by ~1-2 ulp; a face gradient is a sum
+// of up to thousands of such terms of both signs, so after cancellation the deviation against the exactly summed reference
+// terms is 1e-7 .. 1e-5 of the largest gradient (tests bound it by the north star's 1e-4) -- the same metric puts the
+// reference's OWN serial float summation at 1e-5 .. 1e-3 from the exact sum.
+// When a contribution is not taken (:648 / :653: d0 equals the vertex) its coefficient is +-Inf / NaN; the lane then
+// accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
 #ifdef NR_K6_PHASES  // development build: cycles spent per phase, summed over workgroups (scripts/k6_phases.py)
 __device__ unsigned long long g_k6_phase[8];
 #define NR_PHASE_BEGIN() unsigned long long ph_t = clock64()
@@ -857,7 +864,8 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
-    double *__restrict__ scratch, int F, int S, int W, int SP, float eps_f, int B, int win_lines)
+    double *__restrict__ scratch, const int *__restrict__ band_lines, int F, int S, int W, int SP, float eps_f, int B,
+    int win_lines)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -868,19 +876,17 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
+    if (band_lines[((size_t)b * 2 + axis) * n_bands + band] == 0) return;  // step 0: no visible face has a line here
     const int n_vis = vis_count[b];
     const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
     NR_PHASE_BEGIN();
-    if (!band_has_lines(rng_ba, n_vis, band_lo, band_hi)) {  // step 0
-        NR_PHASE(0);
-        return;
-    }
-    NR_PHASE(0);
 
     size_t off = 0;
     auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    constexpr int NP = RGB ? 5 : 2;  // 8-byte pairs per pixel record
-    float2 *s_px = (float2 *)carve((size_t)W * SP * NP * 8);
+    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient / colour arrays: (alpha, r, g, b) or alpha alone
+    int *s_fi = (int *)carve((size_t)W * SP * 4);
+    float *s_g = (float *)carve((size_t)W * SP * NC * 4);
+    float *s_c = (float *)carve((size_t)W * SP * NC * 4);
     BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
     int *s_rec = (int *)carve(4 * WIN);
     int *s_pref = (int *)carve(4 * WIN);
@@ -888,19 +894,20 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);
     int *s_slotpos = (int *)carve(4 * ACC_SLOTS);
     int *s_tmp = (int *)carve(4 * 16);
+    float *s_bg = (float *)carve(16);  // colour of the band's uncovered pixels (alpha, r, g, b)
 
-    // ---- 1. stage the band: one thread per pixel writes the pixel's record
+    // ---- 1. stage the band: one thread per pixel
     const size_t img = (size_t)b * S * S;
     auto put = [&](int l, int fi, float al, float ga, float r, float g, float bl, float gr, float gg, float gb) {
-        float2 *rec = s_px + (size_t)l * NP;
-        rec[0] = make_float2(__int_as_float(fi), al);
+        s_fi[l] = fi;
         if (RGB) {
-            rec[1] = make_float2(r, g);
-            rec[2] = make_float2(bl, ga);
-            rec[3] = make_float2(gr, gg);
-            rec[4] = make_float2(gb, 0.0f);
+            *reinterpret_cast<float4 *>(s_g + 4 * (size_t)l) = make_float4(ga, gr, gg, gb);
+            *reinterpret_cast<float4 *>(s_c + 4 * (size_t)l) = make_float4(al, r, g, bl);
+            if (fi < 0) *reinterpret_cast<float4 *>(s_bg) = make_float4(al, r, g, bl);  // same value from every such pixel
         } else {
-            rec[1] = make_float2(ga, 0.0f);
+            s_g[l] = ga;
+            s_c[l] = al;
+            if (fi < 0) s_bg[0] = al;
         }
     };
     if (axis) {  // a band line is an image row: thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
@@ -1030,7 +1037,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                     if (p0x != d0f) flags |= 4;
                     r.c0 = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor x 2 / S
                     r.c1 = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
-                    if (__float_as_int(s_px[(size_t)(ld * SP + d1_in) * NP].x) == rfn) {  // :604-609
+                    if (s_fi[ld * SP + d1_in] == rfn) {  // :604-609
                         const int lim = (0 < direction) ? S - 1 : 0;
                         const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
                         r.out_rng = o_from | (o_to << 16);
@@ -1079,35 +1086,54 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                 const int base = ((h.z >> 16) & 0xff) * SP;
                 const int d1_in = h.z & 0xffff;
                 // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
-                const float2 *rp = s_px + (size_t)(base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in)) * NP;
+                const int lref = base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
                 float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
-                if (ALPHA) ra = rp[0].y;
-                if (RGB) { const float2 q = rp[1]; rr = q.x; rg = q.y; rb = rp[2].x; }
+                if (RGB) {
+                    const float4 q = *reinterpret_cast<const float4 *>(s_c + 4 * (size_t)lref);
+                    ra = q.x; rr = q.y; rg = q.z; rb = q.w;
+                } else {
+                    ra = s_c[lref];
+                }
+                float ba = 0.0f, br = 0.0f, bgn = 0.0f, bb = 0.0f;  // colour of an uncovered pixel
+                if (RGB) {
+                    const float4 q = *reinterpret_cast<const float4 *>(s_bg);
+                    ba = q.x; br = q.y; bgn = q.z; bb = q.w;
+                } else {
+                    ba = s_bg[0];
+                }
                 const float cross = c.x, c0k = c.y, c1k = c.z;
                 const int fnr = __float_as_int(c.w);
                 float f0 = 0.0f, f1 = 0.0f;
                 float d1f = (float)sr.s_from;
-                const int own = mode_in ? fnr : -2;  // only the in sweep tests ownership (:707); -2 is no face index
-                const float2 *px = s_px + (size_t)(base + sr.s_from) * NP;
-                for (int d1 = sr.s_from; d1 <= sr.s_to; ++d1, d1f += 1.0f, px += NP) {
-                    const float2 p0 = px[0], p1 = px[1];
-                    float diff;  // sum_c (I_c - ref_c) g_c  (:631-638, :709-716)
+                for (int l = base + sr.s_from; l <= base + sr.s_to; ++l, d1f += 1.0f) {
+                    // face index and gradients are requested together (one LDS round trip); only a covered pixel pays a
+                    // second one for its colour
+                    const int fi = s_fi[l];
+                    float diff = 0.0f;  // :631-638 / :709-716, the reference's operations in its order
                     if (RGB) {
-                        const float2 p2 = px[2], p3 = px[3], p4 = px[4];
-                        diff = ALPHA ? (p0.y - ra) * p2.y : 0.0f;
-                        diff = __builtin_fmaf(p1.x - rr, p3.x, diff);
-                        diff = __builtin_fmaf(p1.y - rg, p3.y, diff);
-                        diff = __builtin_fmaf(p2.x - rb, p4.x, diff);
+                        const float4 g4 = *reinterpret_cast<const float4 *>(s_g + 4 * (size_t)l);
+                        float ia = ba, ir = br, ig = bgn, ib = bb;
+                        if (fi >= 0) {  // a covered pixel: its own colour
+                            const float4 c4 = *reinterpret_cast<const float4 *>(s_c + 4 * (size_t)l);
+                            ia = c4.x; ir = c4.y; ig = c4.z; ib = c4.w;
+                        }
+                        if (ALPHA) diff += (ia - ra) * g4.x;
+                        diff += (ir - rr) * g4.y;
+                        diff += (ig - rg) * g4.z;
+                        diff += (ib - rb) * g4.w;
                     } else {
-                        diff = (p0.y - ra) * p1.x;
+                        const float ga = s_g[l];
+                        const float ia = (fi >= 0) ? s_c[l] : ba;
+                        diff += (ia - ra) * ga;
                     }
-                    const int fi = __float_as_int(p0.x);
-                    const bool owned = (mode_in ? fi : -2) == own;                   // :707
-                    if (!owned || diff <= 0.0f) continue;                            // :647 / :717
+                    if (mode_in && fi != fnr) continue;  // :707 (the out sweep does not test ownership)
+                    if (diff <= 0.0f) continue;  // :647 / :717
                     const float t = d1f - cross;
-                    const float e = (0.0f < t) ? eps_f : -eps_f;  // sign(dist) = sign(t), see above
-                    f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(__builtin_fmaf(c0k, t, e)), f0);  // :649-652
-                    f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(__builtin_fmaf(c1k, t, e)), f1);  // :654-657
+                    const float x0 = c0k * t, x1 = c1k * t;                                   // :649 / :654 (2 / S folded into c)
+                    const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                     // :650 / :655
+                    const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
+                    f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y0), f0);                // :651
+                    f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
                 }
                 const double a0 = (flags & 2) ? (double)f0 : 0.0, a1 = (flags & 4) ? (double)f1 : 0.0;  // :648 / :653
                 const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
@@ -1165,11 +1191,11 @@ __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__
 // ====================================================================================================
 
 struct BpmLayout {
-    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, total;
+    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, band_off, total;
     int n_chunks;
 };
 
-BpmLayout bpm_layout(int B, int F)
+BpmLayout bpm_layout(int B, int F, int S)
 {
     BpmLayout L;
     const size_t n = (size_t)B * F;
@@ -1181,7 +1207,8 @@ BpmLayout bpm_layout(int B, int F)
     L.list_off = L.chunk_off + align_up((size_t)B * L.n_chunks * sizeof(int), 256);
     L.rng_off = L.list_off + align_up(n * sizeof(int), 256);
     L.slot_off = L.rng_off + align_up(n * 6 * sizeof(unsigned), 256);  // rng: [B][axis][position][edge]
-    L.total = L.slot_off + n * sizeof(int);
+    L.band_off = L.slot_off + align_up(n * sizeof(int), 256);
+    L.total = L.band_off + (size_t)B * 2 * S * sizeof(int);  // lines per (image, axis, band): at most S bands (W = 1)
     return L;
 }
 
@@ -1191,12 +1218,12 @@ BpmLayout bpm_layout(int B, int F)
 constexpr size_t LDS_BUDGET = NR_K6_LDS_BUDGET_KB * 1024 + 512;  // 53 KB: three workgroups per 160 KB CU
 constexpr int FAST_WIN_SMALL = 128;
 
-constexpr size_t band_fixed_lds(int win) { return (sizeof(BandLine) + 12) * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16; }
+constexpr size_t band_fixed_lds(int win) { return (sizeof(BandLine) + 12) * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 16 + 10 * 16; }
 
 // band width (lines per workgroup) and line window for the given raster size and modes; 0 = does not fit (global fallback)
 int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *win)
 {
-    const size_t per_px = exact ? 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0) : (rgb ? 40 : 16);
+    const size_t per_px = exact ? 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0) : (rgb ? 36 : 12);
     const size_t SP = (size_t)S + 4;
     // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
     // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
@@ -1236,8 +1263,8 @@ struct LdsLimit {
 
 template <bool RGB, bool ALPHA, bool POW2>
 int launch_band(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
-                const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch, int B,
-                int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
+                const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
+                const int *band_lines, int B, int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
 {
     static LdsLimit limit;  // one per instantiation
     auto kern = k_bpm_band<RGB, ALPHA, POW2>;
@@ -1245,21 +1272,21 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     const dim3 grid(xcd_grid(total_wg));  // 1-D: the kernel maps ids to (image, axis, band) per XCD
     hipLaunchKernelGGL(kern, grid, dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha, vis_list,
-                       vis_count, rng, scratch, F, S, W, S + 4, eps, B, win_lines);
+                       vis_count, rng, scratch, band_lines, F, S, W, S + 4, eps, B, win_lines);
     return 0;
 }
 
 template <bool RGB, bool ALPHA, int WIN>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
-                const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch, int B,
-                int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
+                const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
+                const int *band_lines, int B, int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
 {
     static LdsLimit limit;
     auto kern = k_bpm_fast<RGB, ALPHA, WIN>;
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
-                       vis_list, vis_count, rng, scratch, F, S, W, S + 4, (float)eps, B, min(win_lines, WIN));
+                       vis_list, vis_count, rng, scratch, band_lines, F, S, W, S + 4, (float)eps, B, min(win_lines, WIN));
     return 0;
 }
 
@@ -1269,7 +1296,7 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
 {
     (void)return_rgb; (void)return_alpha;
     if (check_sizes(B, F, S)) return 0;
-    return bpm_layout(B, F).total;
+    return bpm_layout(B, F, S).total;
 }
 
 int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
@@ -1307,9 +1334,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         return launch_status();
     }
 
-    const BpmLayout L = bpm_layout(B, F);
+    const BpmLayout L = bpm_layout(B, F, S);
     if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
     unsigned char *ws = (unsigned char *)workspace;
+    int *band_lines = (int *)(ws + L.band_off);
+    const int n_bands = (S + W - 1) / W;
     double *scratch = (double *)(ws + L.scratch_off);
     int *vis_count = (int *)(ws + L.count_off);
     int *vis_list = (int *)(ws + L.list_off);
@@ -1328,14 +1357,15 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         vflags = f;
     }
     if (L.n_chunks <= SMALL_CHUNKS) {
-        hipLaunchKernelGGL(k_compact_small, dim3((unsigned)B), dim3(VIS_CHUNK), 0, st, vflags, vis_list, vis_count, slot_of,
-                           F, L.n_chunks, faces, rng, scratch, S);
+        hipLaunchKernelGGL(k_compact_small, dim3((unsigned)B), dim3(VIS_CHUNK), (size_t)2 * n_bands * sizeof(int), st, vflags,
+                           vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W);
     } else {
         int *chunk_count = (int *)(ws + L.chunk_off);
         hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
-                           chunk_count, F, L.n_chunks);
+                           chunk_count, F, L.n_chunks, band_lines, n_bands);
         hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
-                           chunk_count, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S);
+                           chunk_count, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines,
+                           n_bands, W);
     }
     // lines per window: the packed segment scan keeps the count of full segments in 16 bits (<= win * 2 * S / SEG)
     const int win_lines = max(1, min(BAND_WIN, (int)(65535ll * SEG / (2ll * S))));
@@ -1344,18 +1374,18 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         const bool pow2 = (S & (S - 1)) == 0;
 #define NR_BAND(R, A)                                                                                                  \
     (pow2 ? launch_band<R, A, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list,  \
-                                    vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st)                       \
+                                    vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st)                       \
           : launch_band<R, A, false>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
-                                     vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st))
+                                     vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st))
         rc = (rgb && alpha) ? NR_BAND(true, true) : (rgb ? NR_BAND(true, false) : NR_BAND(false, true));
 #undef NR_BAND
     } else {
 #define NR_FAST(R, A)                                                                                                   \
     (win == BAND_WIN                                                                                                    \
          ? launch_fast<R, A, BAND_WIN>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
-                                       vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st)                     \
+                                       vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st)                     \
          : launch_fast<R, A, FAST_WIN_SMALL>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,    \
-                                             vis_list, vis_count, rng, scratch, B, F, S, W, lds, eps, win_lines, st))
+                                             vis_list, vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st))
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
     }

@@ -20,6 +20,16 @@ done
 export NR_HIP_LIB=$PWD/neural_renderer_amd/libnr_hip_phases.so
 timeout 200 python scripts/k6_phases.py > $OUT/phases.log 2>&1
 unset NR_HIP_LIB
+if [ -n "$BENCH" ]; then timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
+    print('value', round(d['value'], 1), 'ms', round(d['ms_per_step'], 4), {k: round(v, 1) for k, v in d['stages_us'].items()})
+    print(json.dumps(d['grad_check'])[:700]); print(d['extra_rows'], d['renderer_end_to_end'])
+except Exception as e:
+    print('bench parse failed', e); print(open('$OUT/bench.err').read()[-2000:])
+PY
+fi
 if [ -n "$CONFIGS" ]; then timeout 900 python scripts/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err; fi
 cat $OUT/variants.log; cat $OUT/phases.log | tail -12; cat $OUT/fuzz_3_6.log | tail -8
 grep -E "^FAILED|^ERROR" $OUT/*.log | cut -c1-200 | head -40

@@ -32,8 +32,14 @@ def test_bench_two_ranks_on_one_gpu(gather):
            '--cpu-sample-views', '0', '--stage-iters', '2', '--light']
     if gather:
         cmd.append('--gather')
-    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     out_dir = os.path.join(ROOT, 'gpurun_out')
+    try:
+        res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired as ex:  # a rank waiting in a collective the other never enters
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, 'two_ranks_one_gpu_TIMEOUT.log'), 'w') as f:
+                f.write(' '.join(cmd) + '\n' + str(ex.stdout)[-4000:] + '\n--- stderr ---\n' + str(ex.stderr)[-4000:])
+        raise
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, 'two_ranks_one_gpu%s.log' % ('_gather' if gather else '')), 'w') as f:
             f.write('$ NR_DIST_DEVICE=0 NR_DIST_BACKEND=gloo ' + ' '.join(cmd) + '\n' + res.stdout + '\n--- stderr ---\n' +
