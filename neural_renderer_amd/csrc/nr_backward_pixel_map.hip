@@ -1101,39 +1101,80 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                 } else {
                     ba = s_bg[0];
                 }
+                const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;  // (I - ref) of an uncovered pixel
+                const int own_mask = mode_in ? -1 : 0;
                 const float cross = c.x, c0k = c.y, c1k = c.z;
                 const int fnr = __float_as_int(c.w);
                 float f0 = 0.0f, f1 = 0.0f;
                 float d1f = (float)sr.s_from;
-                for (int l = base + sr.s_from; l <= base + sr.s_to; ++l, d1f += 1.0f) {
-                    // face index and gradients are requested together (one LDS round trip); only a covered pixel pays a
-                    // second one for its colour
-                    const int fi = s_fi[l];
-                    float diff = 0.0f;  // :631-638 / :709-716, the reference's operations in its order
+                // One pixel visit.  The face index and the gradients of a pixel are requested together (one LDS round trip);
+                // only a covered pixel pays a second one for its colour.
+                auto visit = [&](int l, int fi, float ga, float gr, float gg, float gb, float d1v) {
+                    // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its
+                    // leading `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the
+                    // background colour, whose difference to the reference colour is a constant of the segment; a covered
+                    // one reads its own colour -- a wave whose 64 pixels are all uncovered skips that block altogether.
+                    float diff;
                     if (RGB) {
-                        const float4 g4 = *reinterpret_cast<const float4 *>(s_g + 4 * (size_t)l);
-                        float ia = ba, ir = br, ig = bgn, ib = bb;
-                        if (fi >= 0) {  // a covered pixel: its own colour
+                        diff = ALPHA ? dba * ga + dbr * gr : dbr * gr;
+                        diff += dbg * gg;
+                        diff += dbb * gb;
+                        if (fi >= 0) {
                             const float4 c4 = *reinterpret_cast<const float4 *>(s_c + 4 * (size_t)l);
-                            ia = c4.x; ir = c4.y; ig = c4.z; ib = c4.w;
+                            diff = ALPHA ? (c4.x - ra) * ga + (c4.y - rr) * gr : (c4.y - rr) * gr;
+                            diff += (c4.z - rg) * gg;
+                            diff += (c4.w - rb) * gb;
                         }
-                        if (ALPHA) diff += (ia - ra) * g4.x;
-                        diff += (ir - rr) * g4.y;
-                        diff += (ig - rg) * g4.z;
-                        diff += (ib - rb) * g4.w;
                     } else {
-                        const float ga = s_g[l];
-                        const float ia = (fi >= 0) ? s_c[l] : ba;
-                        diff += (ia - ra) * ga;
+                        diff = dba * ga;
+                        if (fi >= 0) diff = (s_c[l] - ra) * ga;
                     }
-                    if (mode_in && fi != fnr) continue;  // :707 (the out sweep does not test ownership)
-                    if (diff <= 0.0f) continue;  // :647 / :717
-                    const float t = d1f - cross;
+                    // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
+                    // control flow on the sweep kind
+                    if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) return;
+                    const float t = d1v - cross;
                     const float x0 = c0k * t, x1 = c1k * t;                                   // :649 / :654 (2 / S folded into c)
                     const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                     // :650 / :655
                     const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
                     f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y0), f0);                // :651
                     f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
+                };
+                auto load_g = [&](int l, float &ga, float &gr, float &gg, float &gb) {
+                    if (RGB) {
+                        const float4 g4 = *reinterpret_cast<const float4 *>(s_g + 4 * (size_t)l);
+                        ga = g4.x; gr = g4.y; gg = g4.z; gb = g4.w;
+                    } else {
+                        ga = s_g[l]; gr = gg = gb = 0.0f;
+                    }
+                };
+                int l = base + sr.s_from;
+                const int l_end = base + sr.s_to;
+#if defined(NR_K6_UNROLL) && NR_K6_UNROLL == 3
+                for (; l + 2 <= l_end; l += 3, d1f += 3.0f) {  // three pixels' LDS requests in flight at once
+                    const int fa = s_fi[l], fb = s_fi[l + 1], fc = s_fi[l + 2];
+                    float a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_, c0_, c1_, c2_, c3_;
+                    load_g(l, a0_, a1_, a2_, a3_);
+                    load_g(l + 1, b0_, b1_, b2_, b3_);
+                    load_g(l + 2, c0_, c1_, c2_, c3_);
+                    visit(l, fa, a0_, a1_, a2_, a3_, d1f);
+                    visit(l + 1, fb, b0_, b1_, b2_, b3_, d1f + 1.0f);
+                    visit(l + 2, fc, c0_, c1_, c2_, c3_, d1f + 2.0f);
+                }
+#elif defined(NR_K6_UNROLL) && NR_K6_UNROLL == 2
+                for (; l + 1 <= l_end; l += 2, d1f += 2.0f) {  // two pixels' LDS requests in flight at once
+                    const int fa = s_fi[l], fb = s_fi[l + 1];
+                    float a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_;
+                    load_g(l, a0_, a1_, a2_, a3_);
+                    load_g(l + 1, b0_, b1_, b2_, b3_);
+                    visit(l, fa, a0_, a1_, a2_, a3_, d1f);
+                    visit(l + 1, fb, b0_, b1_, b2_, b3_, d1f + 1.0f);
+                }
+#endif
+                for (; l <= l_end; ++l, d1f += 1.0f) {
+                    const int fi = s_fi[l];
+                    float ga, gr, gg, gb;
+                    load_g(l, ga, gr, gg, gb);
+                    visit(l, fi, ga, gr, gg, gb, d1f);
                 }
                 const double a0 = (flags & 2) ? (double)f0 : 0.0, a1 = (flags & 4) ? (double)f1 : 0.0;  // :648 / :653
                 const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
