@@ -71,6 +71,9 @@ extern "C" {
                                          Default (flag clear): float terms through v_rcp_f32, <= 1e-5 (tolerance 1e-4). */
 #define NR_FLAG_K6_GLOBAL 4           /* K6: force the global-memory kernel that otherwise only serves rasters whose band
                                          does not fit in LDS (a testing aid) */
+#define NR_FLAG_K6_SCAN 8             /* K6: let every band workgroup derive its lines from the image's visible-face list
+                                         itself, the path that otherwise only serves images whose line records exceed the
+                                         workspace's record buffer (a testing aid) */
 
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):

@@ -52,6 +52,7 @@ SIGNATURES = {
 NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
 NR_FLAG_EXACT_GRADIENT = 2
 NR_FLAG_K6_GLOBAL = 4
+NR_FLAG_K6_SCAN = 8
 NR_E_NEAR = -5
 NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1

@@ -327,6 +327,9 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
     z[0] = z[1] = z[2] = make_double2(0.0, 0.0);
 }
 
+__device__ __forceinline__ void band_prefix(const int *cnt, int n2, int *__restrict__ start_out, int *__restrict__ cursor_out,
+                                            int *__restrict__ ok_out, size_t cap);
+
 // Ordered compaction.  Meshes of up to SMALL_CHUNKS * 1024 faces: one workgroup per image walks the chunks in order
 // (one launch).  Larger meshes (config 5: 655 360 faces, B = 1) would be serialised in that one workgroup, so they take two
 // launches: k_count_visible counts the flags of each 1024-face chunk, k_compact_visible turns the counts of the preceding
@@ -339,7 +342,9 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char
                                                              int *__restrict__ slot_of, int F, int n_chunks,
                                                              const float *__restrict__ faces, unsigned *__restrict__ rng,
                                                              double *__restrict__ scratch, int S,
-                                                             int *__restrict__ band_lines, int n_bands, int W)
+                                                             int *__restrict__ band_lines, int n_bands, int W,
+                                                             int *__restrict__ band_start, int *__restrict__ band_cursor,
+                                                             int *__restrict__ lines_ok, size_t cap)
 {
     extern __shared__ int s_band[];  // [2][n_bands] lines per band of this image
     __shared__ int s_wcnt[VIS_CHUNK / 64];
@@ -369,6 +374,9 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char
     }
     __syncthreads();
     for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) band_lines[(size_t)b * 2 * n_bands + i] = s_band[i];
+    // where each band's records start in the image's buffer (k_line_setup fills it next), and whether they fit at all
+    band_prefix(s_band, 2 * n_bands, band_start + (size_t)b * 2 * n_bands, band_cursor + (size_t)b * 2 * n_bands, lines_ok + b,
+                cap);
     if (tid == 0) vis_count[b] = base;
 }
 
@@ -859,55 +867,190 @@ __device__ unsigned long long g_k6_phase[8];
 #define NR_PHASE(k) do {} while (0)
 #endif
 
-template <bool RGB, bool ALPHA, int WIN>
-__global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
-    const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
-    const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
-    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
-    double *__restrict__ scratch, const int *__restrict__ band_lines, int F, int S, int W, int SP, float eps_f, int B,
-    int win_lines)
+// One line record of the fast kernel (rasterize.py:543-579, :604-609, :665-672; the reference's arithmetic: the crossing
+// points decide WHICH pixels are visited, which must not depend on the mode).  fv: the face's 9 floats; (e, axis, d0): the
+// line; ld = d0 - first line of its band; owner_of(d1): face index of pixel (d0, d1) along the axis.
+template <typename OwnerOf>
+__device__ __forceinline__ BandLine make_fast_line(const float *__restrict__ fv, int e, int axis, int d0, int ld, int S,
+                                                   int rfn, int tgt, OwnerOf owner_of)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const float fs = (float)S, k2s = 2.0f / fs;
+    const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+    float fp[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { fp[k] = to_pixel(fv[3 * k], fs); fp[3 + k] = to_pixel(fv[3 * k + 1], fs); }
+    const int ox = axis ? 3 : 0, oy = axis ? 0 : 3;  // p[num][dim] = pp[num][(dim + axis) % 2] (:556)
+    const float p0x = fp[ox + i0], p0y = fp[oy + i0], p1x = fp[ox + i1], p1y = fp[oy + i1];
+    const float p2x = fp[ox + i2], p2y = fp[oy + i2];
+    int direction;
+    if (axis == 0) direction = (p0x < p1x) ? -1 : 1; else direction = (p0x < p1x) ? 1 : -1;  // :559-564
+    const float d0f = (float)d0;
+    BandLine r;
+    r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = tgt;
+    r.cross = r.c0 = r.c1 = 0.0f;
+    r.fn = rfn;
+    const float d1_cross = (p1y - p0y) / (p1x - p0x) * (d0f - p0x) + p0y;                  // :573
+    const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);     // :574
+    const int d1_out = d1_in + direction;                                                 // :575
+    if (!(d1_in < 0 || S <= d1_in) && !(d1_out < 0 || S <= d1_out)) {                     // :578-579
+        int flags = (0 < direction) ? 8 : 0;
+        if (p1x != d0f) flags |= 2;
+        if (p0x != d0f) flags |= 4;
+        r.c0 = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor x 2 / S
+        r.c1 = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
+        if (owner_of(d1_in) == rfn) {            // :604-609
+            const int lim = (0 < direction) ? S - 1 : 0;
+            const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
+            r.out_rng = o_from | (o_to << 16);
+            flags |= 1;
+        }
+        float d0_cross2;                         // :665-672
+        if ((d0f - p0x) * (d0f - p2x) < 0)
+            d0_cross2 = (p2y - p0y) / (p2x - p0x) * (d0f - p0x) + p0y;
+        else
+            d0_cross2 = (p1y - p2y) / (p1x - p2x) * (d0f - p2x) + p2y;
+        const int lim2 = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
+        const int i_from = max(min(d1_in, lim2), 0), i_to = min(max(d1_in, lim2), S - 1);
+        r.in_rng = i_from | (i_to << 16);
+        r.geo = d1_in | (ld << 16) | (flags << 24);
+        r.cross = d1_cross;
+    }
+    return r;
+}
+
+// per-line packed segment counts: full segments in the low 16 bits, partial ones above
+__device__ __forceinline__ int line_segments(int in_rng, int out_rng)
+{
+    const int il = (in_rng >> 16) - (in_rng & 0xffff) + 1, ol = (out_rng >> 16) - (out_rng & 0xffff) + 1;
+    const int full = (il > 0 ? il / SEG : 0) + (ol > 0 ? ol / SEG : 0);
+    const int part = (il > 0 && il % SEG != 0) + (ol > 0 && ol % SEG != 0);
+    return full | (part << 16);
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_line_setup: the line records of every (visible face, edge, axis, line d0), written band by band into line_buf so that
+// a band workgroup finds its lines as one dense array (no face scan, no record compaction, no line setup inside the band
+// kernel -- together ~40 % of its cycles when they ran there on <= 256 of its 512 threads).
+//   item = (image b, list position pos, axis, edge): LPI lanes share an item and stride over its lines; a record goes to slot
+//   band_start[b][axis][band] + atomicAdd(cursor[b][axis][band], 1) of the image's buffer (the order inside a band is
+//   irrelevant: every record is accumulated independently).  tgt = pos | v0 << 28 | v1 << 30.
+// Images whose lines exceed the buffer's capacity (lines_ok[b] == 0) are skipped here and take the scan path of k_bpm_fast.
+constexpr int LPI = 4;
+
+__global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ faces, const int32_t *__restrict__ fi_map,
+                                                    const int *__restrict__ vis_list, const int *__restrict__ vis_count,
+                                                    const unsigned *__restrict__ rng, const int *__restrict__ band_start,
+                                                    int *__restrict__ band_cursor, const int *__restrict__ lines_ok,
+                                                    BandLine *__restrict__ line_buf, size_t cap, int B, int F, int S, int W,
+                                                    int n_bands)
+{
+    extern __shared__ int s_first[];  // [B + 1] first item of each image
+    if (threadIdx.x < 64) {  // exclusive prefix of 6 * vis_count over the images (first wave, a slice per lane)
+        const int lane = threadIdx.x, per = (B + 63) / 64;
+        int local = 0;
+        for (int i = lane * per; i < min(B, (lane + 1) * per); ++i) local += 6 * vis_count[i];
+        int inc = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, WAVE);
+            if (lane >= o) inc += t;
+        }
+        int run = inc - local;
+        for (int i = lane * per; i < min(B, (lane + 1) * per); ++i) { s_first[i] = run; run += 6 * vis_count[i]; }
+        if (lane == 63) s_first[B] = inc;
+    }
+    __syncthreads();
+    const int n_items = s_first[B];
+    const int groups = gridDim.x * (blockDim.x / LPI);
+    for (int item = blockIdx.x * (blockDim.x / LPI) + threadIdx.x / LPI; item < n_items; item += groups) {
+        const int sub = threadIdx.x % LPI;
+        int lo = 0, hi = B - 1;  // image: last b with s_first[b] <= item
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_first[mid] <= item) lo = mid; else hi = mid - 1;
+        }
+        const int b = lo;
+        if (!lines_ok[b]) continue;
+        const int r = item - s_first[b];
+        const int pos = r / 6, ae = r - 6 * pos, axis = ae / 3, e = ae - 3 * axis;
+        const unsigned pr = rng[(((size_t)b * 2 + axis) * F + pos) * 3 + e];
+        const int d_lo = (int)(pr & 0xffffu), d_hi = (int)(pr >> 16);
+        if (d_hi < d_lo) continue;
+        const int fn = vis_list[(size_t)b * F + pos];
+        const float *fv = faces + ((size_t)b * F + fn) * 9;
+        const size_t img = (size_t)b * S * S;
+        const int tgt = pos | (e << 28) | (((e + 1) % 3) << 30);
+        for (int d0 = d_lo + sub; d0 <= d_hi; d0 += LPI) {
+            const int band = d0 / W, ld = d0 - band * W;
+            const BandLine rec = make_fast_line(fv, e, axis, d0, ld, S, fn, tgt, [&](int d1) {
+                return fi_map[axis ? img + (size_t)d0 * S + d1 : img + (size_t)d1 * S + d0];
+            });
+            const size_t bi = ((size_t)b * 2 + axis) * n_bands + band;
+            const int slot = atomicAdd(band_cursor + bi, 1);
+            line_buf[(size_t)b * cap + band_start[bi] + slot] = rec;
+        }
+    }
+}
+
+// exclusive prefix of an image's 2 * n_bands line counts (first wave of the block), the image's total and the verdict
+// whether its records fit the buffer; zeroes the fill cursors
+__device__ __forceinline__ void band_prefix(const int *cnt, int n2, int *__restrict__ start_out, int *__restrict__ cursor_out,
+                                            int *__restrict__ ok_out, size_t cap)
+{
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, per = (n2 + 63) / 64;
+    int local = 0;
+    for (int i = lane * per; i < min(n2, (lane + 1) * per); ++i) local += cnt[i];
+    int inc = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    int run = inc - local;
+    for (int i = lane * per; i < min(n2, (lane + 1) * per); ++i) {
+        start_out[i] = run;
+        cursor_out[i] = 0;
+        run += cnt[i];
+    }
+    const int total = __shfl(inc, 63, WAVE);
+    if (lane == 0) *ok_out = ((size_t)total <= cap) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_band_scan(const int *__restrict__ band_lines, int *__restrict__ band_start,
+                                                   int *__restrict__ band_cursor, int *__restrict__ lines_ok, int n_bands,
+                                                   size_t cap, int force_scan)
+{
+    const size_t o = (size_t)blockIdx.x * 2 * n_bands;
+    band_prefix(band_lines + o, 2 * n_bands, band_start + o, band_cursor + o, lines_ok + blockIdx.x, force_scan ? 0 : cap);
+}
+
+// --------------------------------------------------------------------------------------------------
+// pieces of k_bpm_fast
+struct FastPx {  // LDS pixel data of a band, [line][d1]
+    int *fi;     // face index
+    float *g;    // gradients (g_alpha, g_r, g_g, g_b) -- or g_alpha alone
+    float *c;    // colours   (alpha, r, g, b)         -- or alpha alone
+    float *bg;   // colour of the band's uncovered pixels
+};
+
+template <bool RGB, bool ALPHA>
+__device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__restrict__ fi_map,
+                                           const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
+                                           const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, size_t img,
+                                           int axis, int band_lo, int nld, int S, int SP)
+{
     const int tid = threadIdx.x;
-    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
-    const unsigned total_wg = n_bands * 2u * (unsigned)B;
-    const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_band)
-    if (logical >= total_wg) return;
-    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
-    const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
-    const int nld = band_hi - band_lo + 1;
-    if (band_lines[((size_t)b * 2 + axis) * n_bands + band] == 0) return;  // step 0: no visible face has a line here
-    const int n_vis = vis_count[b];
-    const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
-    NR_PHASE_BEGIN();
-
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient / colour arrays: (alpha, r, g, b) or alpha alone
-    int *s_fi = (int *)carve((size_t)W * SP * 4);
-    float *s_g = (float *)carve((size_t)W * SP * NC * 4);
-    float *s_c = (float *)carve((size_t)W * SP * NC * 4);
-    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
-    int *s_rec = (int *)carve(4 * WIN);
-    int *s_pref = (int *)carve(4 * WIN);
-    int *s_recfn = (int *)carve(4 * WIN);
-    double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);
-    int *s_slotpos = (int *)carve(4 * ACC_SLOTS);
-    int *s_tmp = (int *)carve(4 * 16);
-    float *s_bg = (float *)carve(16);  // colour of the band's uncovered pixels (alpha, r, g, b)
-
-    // ---- 1. stage the band: one thread per pixel
-    const size_t img = (size_t)b * S * S;
     auto put = [&](int l, int fi, float al, float ga, float r, float g, float bl, float gr, float gg, float gb) {
-        s_fi[l] = fi;
+        px.fi[l] = fi;
         if (RGB) {
-            *reinterpret_cast<float4 *>(s_g + 4 * (size_t)l) = make_float4(ga, gr, gg, gb);
-            *reinterpret_cast<float4 *>(s_c + 4 * (size_t)l) = make_float4(al, r, g, bl);
-            if (fi < 0) *reinterpret_cast<float4 *>(s_bg) = make_float4(al, r, g, bl);  // same value from every such pixel
+            *reinterpret_cast<float4 *>(px.g + 4 * (size_t)l) = make_float4(ga, gr, gg, gb);
+            *reinterpret_cast<float4 *>(px.c + 4 * (size_t)l) = make_float4(al, r, g, bl);
+            if (fi < 0) *reinterpret_cast<float4 *>(px.bg) = make_float4(al, r, g, bl);  // same value from every such pixel
         } else {
-            s_g[l] = ga;
-            s_c[l] = al;
-            if (fi < 0) s_bg[0] = al;
+            px.g[l] = ga;
+            px.c[l] = al;
+            if (fi < 0) px.bg[0] = al;
         }
     };
     if (axis) {  // a band line is an image row: thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
@@ -963,13 +1106,174 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             put(ld * SP + d1, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
         }
     }
-    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
-    __syncthreads();
+}
+
+// Step 4 for the n_win line records in s_line (their packed segment counts already scanned into s_pref): one segment per
+// thread.  The two sums of a segment go to acc[acc_index(line, k)] (ds_add_f64), k = 0 / 1 for the edge's first / second
+// vertex; acc_index returns a negative value for "no LDS slot" and spill() then takes the sum.
+template <bool RGB, bool ALPHA, typename AccIndex, typename Spill>
+__device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_line, const int *s_pref, int n_win,
+                                            int total_seg, int SP, float eps_f, double *acc, AccIndex acc_index, Spill spill)
+{
+    const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
+    for (int sid = threadIdx.x; sid < total_all; sid += BAND_THREADS) {
+        const SegRange sr = decode_segment(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
+                                           (int)(sizeof(BandLine) / 4));
+        const BandLine *L = &s_line[sr.line];
+        const int4 h = *reinterpret_cast<const int4 *>(L);
+        const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
+        const bool mode_in = sr.mode_in;
+        const int flags = (h.z >> 24) & 0xff;
+        const int base = ((h.z >> 16) & 0xff) * SP;
+        const int d1_in = h.z & 0xffff;
+        // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
+        const int lref = base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
+        float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
+        float ba = 0.0f, br = 0.0f, bgn = 0.0f, bb = 0.0f;  // colour of an uncovered pixel
+        if (RGB) {
+            const float4 q = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)lref);
+            ra = q.x; rr = q.y; rg = q.z; rb = q.w;
+            const float4 w = *reinterpret_cast<const float4 *>(px.bg);
+            ba = w.x; br = w.y; bgn = w.z; bb = w.w;
+        } else {
+            ra = px.c[lref];
+            ba = px.bg[0];
+        }
+        const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;  // (I - ref) of an uncovered pixel
+        const int own_mask = mode_in ? -1 : 0;
+        const float cross = c.x, c0k = c.y, c1k = c.z;
+        const int fnr = __float_as_int(c.w);
+        float f0 = 0.0f, f1 = 0.0f;
+        float d1f = (float)sr.s_from;
+        for (int l = base + sr.s_from; l <= base + sr.s_to; ++l, d1f += 1.0f) {
+            // One pixel visit.  Face index and gradients are requested together (one LDS round trip); only a covered
+            // pixel pays a second one for its colour.
+            const int fi = px.fi[l];
+            // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its
+            // leading `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the
+            // background colour, whose difference to the reference colour is a constant of the segment; a covered one
+            // reads its own colour -- a wave whose 64 pixels are all uncovered skips that block altogether.
+            float diff;
+            if (RGB) {
+                const float4 g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
+                diff = ALPHA ? dba * g4.x + dbr * g4.y : dbr * g4.y;
+                diff += dbg * g4.z;
+                diff += dbb * g4.w;
+                if (fi >= 0) {
+                    const float4 c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l);
+                    diff = ALPHA ? (c4.x - ra) * g4.x + (c4.y - rr) * g4.y : (c4.y - rr) * g4.y;
+                    diff += (c4.z - rg) * g4.z;
+                    diff += (c4.w - rb) * g4.w;
+                }
+            } else {
+                const float ga = px.g[l];
+                diff = dba * ga;
+                if (fi >= 0) diff = (px.c[l] - ra) * ga;
+            }
+            // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
+            // control flow on the sweep kind
+            if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) continue;
+            const float t = d1f - cross;
+            const float x0 = c0k * t, x1 = c1k * t;                                   // :649 / :654 (2 / S folded into c)
+            const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                     // :650 / :655
+            const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
+            f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y0), f0);                // :651
+            f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
+        }
+        const double a0 = (flags & 2) ? (double)f0 : 0.0, a1 = (flags & 4) ? (double)f1 : 0.0;  // :648 / :653
+        if (a0 != 0.0) { const int i0 = acc_index(sr.line, h.w, 0); if (i0 >= 0) atomicAdd(&acc[i0], a0); else spill(h.w, fnr, 0, a0); }
+        if (a1 != 0.0) { const int i1 = acc_index(sr.line, h.w, 1); if (i1 >= 0) atomicAdd(&acc[i1], a1); else spill(h.w, fnr, 1, a1); }
+    }
+}
+
+template <bool RGB, bool ALPHA, int WIN>
+__global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
+    const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
+    const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
+    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
+    double *__restrict__ scratch, const int *__restrict__ band_lines, const int *__restrict__ band_start,
+    const int *__restrict__ lines_ok, const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int SP,
+    float eps_f, int B, int win_lines)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
+    const unsigned total_wg = n_bands * 2u * (unsigned)B;
+    const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_band)
+    if (logical >= total_wg) return;
+    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
+    const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
+    const int nld = band_hi - band_lo + 1;
+    const size_t bidx = ((size_t)b * 2 + axis) * n_bands + band;
+    const int n_band_lines = band_lines[bidx];
+    if (n_band_lines == 0) return;  // step 0: no visible face has a line here
+    NR_PHASE_BEGIN();
+
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
+    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient / colour arrays: (alpha, r, g, b) or alpha alone
+    FastPx px;
+    px.fi = (int *)carve((size_t)W * SP * 4);
+    px.g = (float *)carve((size_t)W * SP * NC * 4);
+    px.c = (float *)carve((size_t)W * SP * NC * 4);
+    px.bg = (float *)carve(16);
+    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
+    int *s_pref = (int *)carve(4 * WIN);
+    int *s_tmp = (int *)carve(4 * 16);
+    unsigned char *rest = smem + off;  // the two paths below lay out what is left differently
+
+    // ---- 1. stage the band
+    const size_t img = (size_t)b * S * S;
+    fast_stage<RGB, ALPHA>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, img, axis, band_lo, nld, S, SP);
     NR_PHASE(1);
 
-    const float fs = (float)S;
-    const float k2s = 2.0f / fs;
+    if (lines_ok[b]) {
+        // ================= records path: the band's line records were written by k_line_setup =================
+        double *s_lacc = (double *)rest;  // [WIN][2] sums of each line for its edge's two vertices
+        const BandLine *recs = line_buf + (size_t)b * cap + band_start[bidx];
+        for (int win = 0; win < n_band_lines; win += win_lines) {
+            const int n_win = min(n_band_lines - win, win_lines);
+            int n_seg = 0;
+            if (tid < n_win) {
+                const BandLine r = recs[win + tid];
+                s_line[tid] = r;
+                n_seg = line_segments(r.in_rng, r.out_rng);
+            }
+            if (tid < 2 * n_win) s_lacc[tid] = 0.0;
+            int total_seg = 0;
+            const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);  // (two barriers inside: s_line is visible after)
+            if (tid < n_win) s_pref[tid] = seg_off;
+            __syncthreads();
+            NR_PHASE(5);
+#ifndef NR_K6_NO_SWEEPS
+            fast_sweeps<RGB, ALPHA>(px, s_line, s_pref, n_win, total_seg, SP, eps_f, s_lacc,
+                                    [](int line, int, int k) { return 2 * line + k; }, [](int, int, int, double) {});
+#endif
+            __syncthreads();
+            NR_PHASE(6);
+            if (tid < 2 * n_win) {  // line sums -> global double scratch [list position][vertex][x|y]
+                const double a = s_lacc[tid];
+                if (a != 0.0) {
+                    const int tgt = s_line[tid >> 1].tgt;
+                    const int pos = tgt & 0x0fffffff, v = (tid & 1) ? (tgt >> 30) & 3 : (tgt >> 28) & 3;
+                    atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * v + (1 - axis), a);
+                }
+            }
+            __syncthreads();
+            NR_PHASE(7);
+        }
+        return;
+    }
 
+    // ================= scan path (an image with more lines than the record buffer holds): as k_bpm_band =================
+    int *s_rec = (int *)rest;
+    int *s_recfn = s_rec + WIN;
+    double *s_acc = (double *)(s_recfn + WIN);          // WIN is a multiple of 4: 8-byte aligned
+    int *s_slotpos = (int *)(s_acc + 3 * ACC_SLOTS);
+    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
+    __syncthreads();
+    const int n_vis = vis_count[b];
+    const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
     for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
         // ---- 2. one visible face per thread: lines of its 3 edges inside the band
         int fn = -1, nl = 0;
@@ -1006,188 +1310,35 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             const int n_win = min(total_lines - win, win_lines);
             NR_PHASE(3);
 
-            // ---- 3. line setup, one line per thread: rasterize.py:543-579, :604-609, :665-672 (the reference's arithmetic:
-            //         the crossing points decide WHICH pixels are visited, which must not depend on the mode)
-            if (tid < n_win) {
-                const int rec = s_rec[tid];
-                const int slot = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
-                const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
-                const int rfn = s_recfn[tid];
-                const float *fv = faces + ((size_t)b * F + rfn) * 9;
-                float fp[6];
-#pragma unroll
-                for (int k = 0; k < 3; k++) { fp[k] = to_pixel(fv[3 * k], fs); fp[3 + k] = to_pixel(fv[3 * k + 1], fs); }
-                const int ox = axis ? 3 : 0, oy = axis ? 0 : 3;  // p[num][dim] = pp[num][(dim + axis) % 2] (:556)
-                const float p0x = fp[ox + i0], p0y = fp[oy + i0], p1x = fp[ox + i1], p1y = fp[oy + i1];
-                const float p2x = fp[ox + i2], p2y = fp[oy + i2];
-                int direction;
-                if (axis == 0) direction = (p0x < p1x) ? -1 : 1; else direction = (p0x < p1x) ? 1 : -1;  // :559-564
-                const int d0 = band_lo + ld;
-                const float d0f = (float)d0;
-                BandLine r;
-                r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = slot | (i0 << 16) | (i1 << 18);
-                r.cross = r.c0 = r.c1 = 0.0f;
-                r.fn = rfn;
-                const float d1_cross = (p1y - p0y) / (p1x - p0x) * (d0f - p0x) + p0y;                  // :573
-                const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);     // :574
-                const int d1_out = d1_in + direction;                                                 // :575
-                if (!(d1_in < 0 || S <= d1_in) && !(d1_out < 0 || S <= d1_out)) {                     // :578-579
-                    int flags = (0 < direction) ? 8 : 0;
-                    if (p1x != d0f) flags |= 2;
-                    if (p0x != d0f) flags |= 4;
-                    r.c0 = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor x 2 / S
-                    r.c1 = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
-                    if (s_fi[ld * SP + d1_in] == rfn) {  // :604-609
-                        const int lim = (0 < direction) ? S - 1 : 0;
-                        const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
-                        r.out_rng = o_from | (o_to << 16);
-                        flags |= 1;
-                    }
-                    float d0_cross2;                         // :665-672
-                    if ((d0f - p0x) * (d0f - p2x) < 0)
-                        d0_cross2 = (p2y - p0y) / (p2x - p0x) * (d0f - p0x) + p0y;
-                    else
-                        d0_cross2 = (p1y - p2y) / (p1x - p2x) * (d0f - p2x) + p2y;
-                    const int lim2 = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
-                    const int i_from = max(min(d1_in, lim2), 0), i_to = min(max(d1_in, lim2), S - 1);
-                    r.in_rng = i_from | (i_to << 16);
-                    r.geo = d1_in | (ld << 16) | (flags << 24);
-                    r.cross = d1_cross;
-                }
-                s_line[tid] = r;
-            }
-            __syncthreads();
-            NR_PHASE(4);
-
-            // ---- 4. sweeps, one segment per thread (see k_bpm_band)
+            // ---- 3. line setup, one line per thread
             int n_seg = 0;
             if (tid < n_win) {
-                const BandLine &L = s_line[tid];
-                const int il = (L.in_rng >> 16) - (L.in_rng & 0xffff) + 1, ol = (L.out_rng >> 16) - (L.out_rng & 0xffff) + 1;
-                const int full = (il > 0 ? il / SEG : 0) + (ol > 0 ? ol / SEG : 0);
-                const int part = (il > 0 && il % SEG != 0) + (ol > 0 && ol % SEG != 0);
-                n_seg = full | (part << 16);
+                const int rec = s_rec[tid];
+                const int slot_l = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
+                const int rfn = s_recfn[tid];
+                const BandLine r = make_fast_line(faces + ((size_t)b * F + rfn) * 9, e, axis, band_lo + ld, ld, S, rfn,
+                                                  slot_l | (e << 16) | (((e + 1) % 3) << 18),
+                                                  [&](int d1) { return px.fi[ld * SP + d1]; });
+                s_line[tid] = r;
+                n_seg = line_segments(r.in_rng, r.out_rng);
             }
+            NR_PHASE(4);
             int total_seg = 0;
             const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
             if (tid < n_win) s_pref[tid] = seg_off;
             __syncthreads();
             NR_PHASE(5);
-            const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
 #ifndef NR_K6_NO_SWEEPS
-            for (int sid = tid; sid < total_all; sid += BAND_THREADS) {
-                const SegRange sr = decode_segment(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
-                                                   (int)(sizeof(BandLine) / 4));
-                const BandLine *L = &s_line[sr.line];
-                const int4 h = *reinterpret_cast<const int4 *>(L);
-                const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
-                const bool mode_in = sr.mode_in;
-                const int flags = (h.z >> 24) & 0xff;
-                const int base = ((h.z >> 16) & 0xff) * SP;
-                const int d1_in = h.z & 0xffff;
-                // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
-                const int lref = base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
-                float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
-                if (RGB) {
-                    const float4 q = *reinterpret_cast<const float4 *>(s_c + 4 * (size_t)lref);
-                    ra = q.x; rr = q.y; rg = q.z; rb = q.w;
-                } else {
-                    ra = s_c[lref];
-                }
-                float ba = 0.0f, br = 0.0f, bgn = 0.0f, bb = 0.0f;  // colour of an uncovered pixel
-                if (RGB) {
-                    const float4 q = *reinterpret_cast<const float4 *>(s_bg);
-                    ba = q.x; br = q.y; bgn = q.z; bb = q.w;
-                } else {
-                    ba = s_bg[0];
-                }
-                const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;  // (I - ref) of an uncovered pixel
-                const int own_mask = mode_in ? -1 : 0;
-                const float cross = c.x, c0k = c.y, c1k = c.z;
-                const int fnr = __float_as_int(c.w);
-                float f0 = 0.0f, f1 = 0.0f;
-                float d1f = (float)sr.s_from;
-                // One pixel visit.  The face index and the gradients of a pixel are requested together (one LDS round trip);
-                // only a covered pixel pays a second one for its colour.
-                auto visit = [&](int l, int fi, float ga, float gr, float gg, float gb, float d1v) {
-                    // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its
-                    // leading `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the
-                    // background colour, whose difference to the reference colour is a constant of the segment; a covered
-                    // one reads its own colour -- a wave whose 64 pixels are all uncovered skips that block altogether.
-                    float diff;
-                    if (RGB) {
-                        diff = ALPHA ? dba * ga + dbr * gr : dbr * gr;
-                        diff += dbg * gg;
-                        diff += dbb * gb;
-                        if (fi >= 0) {
-                            const float4 c4 = *reinterpret_cast<const float4 *>(s_c + 4 * (size_t)l);
-                            diff = ALPHA ? (c4.x - ra) * ga + (c4.y - rr) * gr : (c4.y - rr) * gr;
-                            diff += (c4.z - rg) * gg;
-                            diff += (c4.w - rb) * gb;
-                        }
-                    } else {
-                        diff = dba * ga;
-                        if (fi >= 0) diff = (s_c[l] - ra) * ga;
-                    }
-                    // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
-                    // control flow on the sweep kind
-                    if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) return;
-                    const float t = d1v - cross;
-                    const float x0 = c0k * t, x1 = c1k * t;                                   // :649 / :654 (2 / S folded into c)
-                    const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                     // :650 / :655
-                    const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
-                    f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y0), f0);                // :651
-                    f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
-                };
-                auto load_g = [&](int l, float &ga, float &gr, float &gg, float &gb) {
-                    if (RGB) {
-                        const float4 g4 = *reinterpret_cast<const float4 *>(s_g + 4 * (size_t)l);
-                        ga = g4.x; gr = g4.y; gg = g4.z; gb = g4.w;
-                    } else {
-                        ga = s_g[l]; gr = gg = gb = 0.0f;
-                    }
-                };
-                int l = base + sr.s_from;
-                const int l_end = base + sr.s_to;
-#if defined(NR_K6_UNROLL) && NR_K6_UNROLL == 3
-                for (; l + 2 <= l_end; l += 3, d1f += 3.0f) {  // three pixels' LDS requests in flight at once
-                    const int fa = s_fi[l], fb = s_fi[l + 1], fc = s_fi[l + 2];
-                    float a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_, c0_, c1_, c2_, c3_;
-                    load_g(l, a0_, a1_, a2_, a3_);
-                    load_g(l + 1, b0_, b1_, b2_, b3_);
-                    load_g(l + 2, c0_, c1_, c2_, c3_);
-                    visit(l, fa, a0_, a1_, a2_, a3_, d1f);
-                    visit(l + 1, fb, b0_, b1_, b2_, b3_, d1f + 1.0f);
-                    visit(l + 2, fc, c0_, c1_, c2_, c3_, d1f + 2.0f);
-                }
-#elif defined(NR_K6_UNROLL) && NR_K6_UNROLL == 2
-                for (; l + 1 <= l_end; l += 2, d1f += 2.0f) {  // two pixels' LDS requests in flight at once
-                    const int fa = s_fi[l], fb = s_fi[l + 1];
-                    float a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_;
-                    load_g(l, a0_, a1_, a2_, a3_);
-                    load_g(l + 1, b0_, b1_, b2_, b3_);
-                    visit(l, fa, a0_, a1_, a2_, a3_, d1f);
-                    visit(l + 1, fb, b0_, b1_, b2_, b3_, d1f + 1.0f);
-                }
-#endif
-                for (; l <= l_end; ++l, d1f += 1.0f) {
-                    const int fi = s_fi[l];
-                    float ga, gr, gg, gb;
-                    load_g(l, ga, gr, gg, gb);
-                    visit(l, fi, ga, gr, gg, gb, d1f);
-                }
-                const double a0 = (flags & 2) ? (double)f0 : 0.0, a1 = (flags & 4) ? (double)f1 : 0.0;  // :648 / :653
-                const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
-                if (slot < ACC_SLOTS) {
-                    if (a0 != 0.0) atomicAdd(&s_acc[3 * slot + v0], a0);
-                    if (a1 != 0.0) atomicAdd(&s_acc[3 * slot + v1], a1);
-                } else if (a0 != 0.0 || a1 != 0.0) {
+            fast_sweeps<RGB, ALPHA>(
+                px, s_line, s_pref, n_win, total_seg, SP, eps_f, s_acc,
+                [](int, int tgt, int k) {
+                    const int sl = tgt & 0xffff;
+                    return sl < ACC_SLOTS ? 3 * sl + ((tgt >> (k ? 18 : 16)) & 3) : -1;
+                },
+                [&](int tgt, int fnr, int k, double a) {  // more faces with lines in this pass than LDS slots
                     const int pos = vis_position(vis_list + (size_t)b * F, n_vis, fnr);
-                    double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
-                    if (a0 != 0.0) atomicAdd(dst + 2 * v0, a0);
-                    if (a1 != 0.0) atomicAdd(dst + 2 * v1, a1);
-                }
-            }
+                    atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * ((tgt >> (k ? 18 : 16)) & 3) + (1 - axis), a);
+                });
 #endif
             __syncthreads();
             NR_PHASE(6);
@@ -1232,9 +1383,14 @@ __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__
 // ====================================================================================================
 
 struct BpmLayout {
-    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, band_off, total;
+    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, band_off, start_off, cursor_off, ok_off,
+        lines_off, total, cap;
     int n_chunks;
 };
+
+// capacity (line records per image) of the band line buffer: a mesh has a few lines per face (teapot 3.8, dense meshes ~2);
+// scenes of few large faces are covered by the S term.  Images beyond it take the scan path of k_bpm_fast.
+size_t line_capacity(int F, int S) { return (size_t)8 * F + (size_t)32 * S; }
 
 BpmLayout bpm_layout(int B, int F, int S)
 {
@@ -1248,8 +1404,14 @@ BpmLayout bpm_layout(int B, int F, int S)
     L.list_off = L.chunk_off + align_up((size_t)B * L.n_chunks * sizeof(int), 256);
     L.rng_off = L.list_off + align_up(n * sizeof(int), 256);
     L.slot_off = L.rng_off + align_up(n * 6 * sizeof(unsigned), 256);  // rng: [B][axis][position][edge]
+    const size_t per_band = align_up((size_t)B * 2 * S * sizeof(int), 256);  // per (image, axis, band): at most S bands (W = 1)
     L.band_off = L.slot_off + align_up(n * sizeof(int), 256);
-    L.total = L.band_off + (size_t)B * 2 * S * sizeof(int);  // lines per (image, axis, band): at most S bands (W = 1)
+    L.start_off = L.band_off + per_band;
+    L.cursor_off = L.start_off + per_band;
+    L.ok_off = L.cursor_off + per_band;
+    L.lines_off = L.ok_off + align_up((size_t)B * sizeof(int), 256);
+    L.cap = line_capacity(F, S);
+    L.total = L.lines_off + (size_t)B * L.cap * sizeof(BandLine);
     return L;
 }
 
@@ -1259,7 +1421,13 @@ BpmLayout bpm_layout(int B, int F, int S)
 constexpr size_t LDS_BUDGET = NR_K6_LDS_BUDGET_KB * 1024 + 512;  // 53 KB: three workgroups per 160 KB CU
 constexpr int FAST_WIN_SMALL = 128;
 
-constexpr size_t band_fixed_lds(int win) { return (sizeof(BandLine) + 12) * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 16 + 10 * 16; }
+// line records + segment prefixes + scan scratch + background colour + the larger of the two paths' private parts
+// (records path: two double sums per line; scan path: compaction records + per-face accumulator slots) + alignment slack
+constexpr size_t band_fixed_lds(int win)
+{
+    const size_t a = 16 * (size_t)win, b = 8 * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS;
+    return (sizeof(BandLine) + 4) * (size_t)win + 64 + 16 + (a > b ? a : b) + 8 * 16;
+}
 
 // band width (lines per workgroup) and line window for the given raster size and modes; 0 = does not fit (global fallback)
 int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *win)
@@ -1269,10 +1437,11 @@ int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *
     // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
     // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
     for (int W = 4; W >= 1; W >>= 1) {
-        // the fast kernel's 40-byte records leave room for 256 line records only in narrow bands; three workgroups per CU
-        // with a 128-line window beat two with 256 (the phases of co-resident workgroups overlap)
+        // three workgroups per CU with a 128-line window beat two with 256 (the phases of co-resident workgroups overlap)
         for (int w = BAND_WIN; w >= (exact ? BAND_WIN : FAST_WIN_SMALL); w >>= 1) {
-            const size_t need = (size_t)W * SP * per_px + band_fixed_lds(w);
+            const size_t fixed = exact ? (sizeof(BandLine) + 12) * (size_t)w + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16
+                                       : band_fixed_lds(w);
+            const size_t need = (size_t)W * SP * per_px + fixed;
             if (need <= LDS_BUDGET || (W == 1 && w == (exact ? BAND_WIN : FAST_WIN_SMALL) && need <= 160 * 1024)) {
                 *lds_bytes = need;
                 *win = w;
@@ -1320,14 +1489,16 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
 template <bool RGB, bool ALPHA, int WIN>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
-                const int *band_lines, int B, int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
+                const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
+                int B, int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
 {
     static LdsLimit limit;
     auto kern = k_bpm_fast<RGB, ALPHA, WIN>;
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
-                       vis_list, vis_count, rng, scratch, band_lines, F, S, W, S + 4, (float)eps, B, min(win_lines, WIN));
+                       vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
+                       (float)eps, B, min(win_lines, WIN));
     return 0;
 }
 
@@ -1397,9 +1568,15 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                            S * S, P);
         vflags = f;
     }
+    int *band_start = (int *)(ws + L.start_off), *band_cursor = (int *)(ws + L.cursor_off), *lines_ok = (int *)(ws + L.ok_off);
+    BandLine *line_buf = (BandLine *)(ws + L.lines_off);
+    // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
+    const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 8192;
+    const size_t cap = use_records ? L.cap : 0;  // capacity 0: every image is told to take the scan path
     if (L.n_chunks <= SMALL_CHUNKS) {
         hipLaunchKernelGGL(k_compact_small, dim3((unsigned)B), dim3(VIS_CHUNK), (size_t)2 * n_bands * sizeof(int), st, vflags,
-                           vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W);
+                           vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W,
+                           band_start, band_cursor, lines_ok, cap);
     } else {
         int *chunk_count = (int *)(ws + L.chunk_off);
         hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
@@ -1407,6 +1584,14 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
                            chunk_count, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines,
                            n_bands, W);
+        if (!exact)
+            hipLaunchKernelGGL(k_band_scan, dim3((unsigned)B), dim3(256), 0, st, band_lines, band_start, band_cursor, lines_ok,
+                               n_bands, cap, 0);
+    }
+    if (use_records) {
+        // a resident grid walks the (image, visible face, axis, edge) items; 8 workgroups per CU
+        hipLaunchKernelGGL(k_line_setup, dim3(2048), dim3(256), (size_t)(B + 1) * sizeof(int), st, faces, face_index_map,
+                           vis_list, vis_count, rng, band_start, band_cursor, lines_ok, line_buf, L.cap, B, F, S, W, n_bands);
     }
     // lines per window: the packed segment scan keeps the count of full segments in 16 bits (<= win * 2 * S / SEG)
     const int win_lines = max(1, min(BAND_WIN, (int)(65535ll * SEG / (2ll * S))));
@@ -1424,9 +1609,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
 #define NR_FAST(R, A)                                                                                                   \
     (win == BAND_WIN                                                                                                    \
          ? launch_fast<R, A, BAND_WIN>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
-                                       vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st)                     \
+                                       vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, \
+                                       eps, win_lines, st)                                                                \
          : launch_fast<R, A, FAST_WIN_SMALL>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,    \
-                                             vis_list, vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st))
+                                             vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf,  \
+                                             L.cap, B, F, S, W, lds, eps, win_lines, st))
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
     }

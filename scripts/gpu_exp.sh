@@ -17,6 +17,10 @@ for v in "" ${VARIANTS}; do
   if [ -z "$v" ]; then unset NR_HIP_LIB; else export NR_HIP_LIB=$PWD/neural_renderer_amd/libnr_hip_$v.so; fi
   TAG=base$v ITERS=20 timeout 200 python scripts/stage_times.py 2>/dev/null | tail -1 >> $OUT/variants.log
 done
+for fl in ${STAGE_FLAGS}; do
+  unset NR_HIP_LIB
+  NR_STAGE_FLAGS=$fl TAG=flags$fl ITERS=20 timeout 200 python scripts/stage_times.py 2>/dev/null | tail -1 >> $OUT/variants.log
+done
 for v in ${VARIANT_TESTS}; do  # parity of a variant build: the forward / K6 suites against the oracle
   export NR_HIP_LIB=$PWD/neural_renderer_amd/libnr_hip_$v.so
   timeout 600 python -m pytest tests/test_hip_parity.py tests/test_fuzz_gpu.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/variant_$v.log 2>&1

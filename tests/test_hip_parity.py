@@ -22,6 +22,7 @@ K6_BOUND_DEFAULT = 1e-4  # the north star's tolerance; measured 1e-6 .. 3e-5 (pr
 K6_BOUND_EXACT = 2e-6
 EXACT = 2  # _lib.NR_FLAG_EXACT_GRADIENT
 K6_GLOBAL = 4  # _lib.NR_FLAG_K6_GLOBAL
+K6_SCAN = 8    # _lib.NR_FLAG_K6_SCAN
 
 
 def report(test, **values):
@@ -220,6 +221,10 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
                                   use_face_inv_map=residual_maps, k6_flags=flags, use_visible=False)
             # same terms either way; only the order of the double atomics (and of K8's float adds) can differ
             assert H.rel_err(abi.host(gf2), gf) <= 1e-6
+            if not flags & EXACT:  # the default kernel's second way to its line records (in-kernel face scan): same terms again
+                gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
+                                      use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
+                assert H.rel_err(abi.host(gf3), gf) <= 1e-6
     if rgb:
         gt = abi.host(gt)
         assert not np.isnan(gt).any(), 'grad_textures has unwritten elements'
