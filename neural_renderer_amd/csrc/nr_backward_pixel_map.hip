@@ -300,7 +300,7 @@ __device__ __forceinline__ unsigned edge_range(float p0x, float p1x, int S)
 // chasing list -> vertices each) and six zeroed double sums.
 __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int S, const float *__restrict__ faces,
                                              int *__restrict__ vis_list, unsigned *__restrict__ rng,
-                                             double *__restrict__ scratch, int *band_count, int n_bands, int W, int nl[2])
+                                             double *__restrict__ scratch, int *band_count, int n_bands, int W)
 {
     vis_list[(size_t)b * F + pos] = fn;
     const float *f = faces + ((size_t)b * F + fn) * 9;
@@ -309,7 +309,6 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
 #pragma unroll
     for (int k = 0; k < 3; k++) { px[k] = to_pixel(f[3 * k], fs); py[k] = to_pixel(f[3 * k + 1], fs); }
     unsigned *r0 = rng + (((size_t)b * 2 + 0) * F + pos) * 3, *r1 = rng + (((size_t)b * 2 + 1) * F + pos) * 3;
-    nl[0] = nl[1] = 0;
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         const unsigned ra = edge_range(px[e], px[(e + 1) % 3], S), rb = edge_range(py[e], py[(e + 1) % 3], S);
@@ -320,7 +319,6 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
         for (int axis = 0; axis < 2; axis++) {
             const unsigned r = axis ? rb : ra;
             const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
-            if (hi >= lo) nl[axis] += hi - lo + 1;
             for (int band = lo / W; band * W <= hi; ++band)  // lo > hi (RNG_EMPTY): no iteration
                 atomicAdd(band_count + axis * n_bands + band, min(hi, band * W + W - 1) - max(lo, band * W) + 1);
         }
@@ -328,6 +326,9 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
     double2 *z = reinterpret_cast<double2 *>(scratch + ((size_t)b * F + pos) * 6);
     z[0] = z[1] = z[2] = make_double2(0.0, 0.0);
 }
+
+__device__ __forceinline__ void band_prefix(const int *cnt, int n2, int *__restrict__ start_out, int *__restrict__ cursor_out,
+                                            int *__restrict__ ok_out, size_t cap);
 
 // Ordered compaction.  Meshes of up to SMALL_CHUNKS * 1024 faces: one workgroup per image walks the chunks in order
 // (one launch).  Larger meshes (config 5: 655 360 faces, B = 1) would be serialised in that one workgroup, so they take two
@@ -342,16 +343,15 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char
                                                              const float *__restrict__ faces, unsigned *__restrict__ rng,
                                                              double *__restrict__ scratch, int S,
                                                              int *__restrict__ band_lines, int n_bands, int W,
-                                                             int *__restrict__ line_start, int *__restrict__ lines_info,
-                                                             size_t cap)
+                                                             int *__restrict__ band_start, int *__restrict__ band_cursor,
+                                                             int *__restrict__ lines_ok, size_t cap)
 {
     extern __shared__ int s_band[];  // [2][n_bands] lines per band of this image
     __shared__ int s_wcnt[VIS_CHUNK / 64];
-    __shared__ int s_wl0[VIS_CHUNK / 64], s_wl1[VIS_CHUNK / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) s_band[i] = 0;
     __syncthreads();
-    int base = 0, base0 = 0, base1 = 0;  // visible faces / their lines along axis 0 / axis 1 before this chunk
+    int base = 0;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const int fn = chunk * VIS_CHUNK + tid;
         const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
@@ -364,44 +364,20 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char
             if (w < wave) off += c;
             tot += c;
         }
-        int nl[2] = {0, 0};
-        int pos = -1;
-        if (fn < F) {
-            pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-            slot_of[(size_t)b * F + fn] = pos;
-            if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W, nl);
-        }
-        // where the face's line records start in the image's buffer: exclusive prefix of the line counts in list order,
-        // per axis (k_line_setup writes them there, the band kernel finds them there: no atomics, no binning)
-        int i0 = nl[0], i1 = nl[1];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t0 = __shfl_up(i0, o, WAVE), t1 = __shfl_up(i1, o, WAVE);
-            if (lane >= o) { i0 += t0; i1 += t1; }
-        }
-        if (lane == 63) { s_wl0[wave] = i0; s_wl1[wave] = i1; }
         __syncthreads();
-        int w0 = 0, w1 = 0, t0 = 0, t1 = 0;
-        for (int w = 0; w < VIS_CHUNK / 64; ++w) {
-            if (w < wave) { w0 += s_wl0[w]; w1 += s_wl1[w]; }
-            t0 += s_wl0[w];
-            t1 += s_wl1[w];
-        }
-        if (v) {
-            line_start[((size_t)b * 2 + 0) * F + pos] = base0 + w0 + i0 - nl[0];
-            line_start[((size_t)b * 2 + 1) * F + pos] = base1 + w1 + i1 - nl[1];
+        if (fn < F) {
+            const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+            slot_of[(size_t)b * F + fn] = pos;
+            if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W);
         }
         base += tot;
-        base0 += t0;
-        base1 += t1;
-        __syncthreads();
     }
+    __syncthreads();
     for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) band_lines[(size_t)b * 2 * n_bands + i] = s_band[i];
-    if (tid == 0) {
-        vis_count[b] = base;
-        lines_info[2 * b] = ((size_t)base0 + (size_t)base1 <= cap) ? 1 : 0;  // the records fit the buffer
-        lines_info[2 * b + 1] = base0;                                       // axis 1 records follow the base0 of axis 0
-    }
+    // where each band's records start in the image's buffer (k_line_setup fills it next), and whether they fit at all
+    band_prefix(s_band, 2 * n_bands, band_start + (size_t)b * 2 * n_bands, band_cursor + (size_t)b * 2 * n_bands, lines_ok + b,
+                cap);
+    if (tid == 0) vis_count[b] = base;
 }
 
 __global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char *__restrict__ flags,
@@ -454,8 +430,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
     if (fn < F) {
         const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
         slot_of[(size_t)b * F + fn] = pos;
-        int nl[2];
-        if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch, band_lines + (size_t)b * 2 * n_bands, n_bands, W, nl);
+        if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch, band_lines + (size_t)b * 2 * n_bands, n_bands, W);
     }
     if (chunk == n_chunks - 1 && tid == 0) {
         int base = 0;
@@ -953,71 +928,105 @@ __device__ __forceinline__ int line_segments(int in_rng, int out_rng)
 }
 
 // --------------------------------------------------------------------------------------------------
-// k_line_setup: the line records of every (visible face, axis, edge, line d0) of every image, so that the band kernel only
-// copies them instead of setting lines up on <= 256 of its 512 threads behind a chain of dependent loads and five IEEE
-// divisions (that phase was ~1/4 of its cycles).  Records lie in list order of the faces, per axis, edge by edge, line by
-// line: record index = (axis ? lines_info[2b + 1] : 0) + line_start[b][axis][pos] + (lines of the face's earlier edges along
-// that axis) + (d0 - first line of the edge) -- fixed by the prefix sums of the compaction: no atomics, no binning.
-//   item = (image b, list position pos, axis, edge): LPI lanes share an item and stride over its lines.
-// Images whose lines exceed the buffer's capacity (lines_info[2b] == 0) are skipped; the band kernel then sets their lines up
-// itself.  `tgt` of a record holds the edge (the band kernel puts its accumulator slot there).
-constexpr int LPI = 4;
+// k_line_setup: the line records of every (visible face, edge, axis, line d0), written band by band into line_buf so that
+// a band workgroup finds its lines as one dense array: no face scan, no record compaction, no line setup inside the band
+// kernel (together ~40 % of its cycles when they ran there, on <= 256 of its 512 threads).
+//   One workgroup takes LS_FACES consecutive list positions of one image.  Binning without a device-wide atomic per line
+//   (1.2 M same-address atomics across the 8 L2s of the chip cost 230 us): (1) the workgroup counts its own lines per band
+//   in LDS, (2) reserves its block of each non-empty band with ONE global atomic (band_cursor), (3) computes the records and
+//   places each at band_start + block base + an LDS cursor.  The order inside a band is irrelevant: every record is
+//   accumulated independently.  tgt = list position | v0 << 28 | v1 << 30.
+// Images whose lines exceed the buffer's capacity (lines_ok[b] == 0) are skipped here and take the scan path of k_bpm_fast.
+constexpr int LPI = 4;        // lanes per (face, axis, edge) item
+constexpr int LS_FACES = 64;  // list positions per workgroup
 
 __global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ faces, const int32_t *__restrict__ fi_map,
                                                     const int *__restrict__ vis_list, const int *__restrict__ vis_count,
-                                                    const unsigned *__restrict__ rng, const int *__restrict__ line_start,
-                                                    const int *__restrict__ lines_info, BandLine *__restrict__ line_buf,
-                                                    size_t cap, int B, int F, int S, int W)
+                                                    const unsigned *__restrict__ rng, const int *__restrict__ band_start,
+                                                    int *__restrict__ band_cursor, const int *__restrict__ lines_ok,
+                                                    BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W,
+                                                    int n_bands)
 {
-    extern __shared__ int s_first[];  // [B + 1] first item of each image
-    if (threadIdx.x < 64) {  // exclusive prefix of 6 * vis_count over the images (first wave, a slice per lane)
-        const int lane = threadIdx.x, per = (B + 63) / 64;
-        int local = 0;
-        for (int i = lane * per; i < min(B, (lane + 1) * per); ++i) local += 6 * vis_count[i];
-        int inc = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, WAVE);
-            if (lane >= o) inc += t;
-        }
-        int run = inc - local;
-        for (int i = lane * per; i < min(B, (lane + 1) * per); ++i) { s_first[i] = run; run += 6 * vis_count[i]; }
-        if (lane == 63) s_first[B] = inc;
+    extern __shared__ int s_cnt[];  // [2 * n_bands] this workgroup's lines per band, then its fill cursors; [2 * n_bands] bases
+    int *s_base = s_cnt + 2 * n_bands;
+    const int b = blockIdx.y, pos0 = blockIdx.x * LS_FACES;
+    const int n_vis = vis_count[b];
+    if (pos0 >= n_vis || !lines_ok[b]) return;
+    const int n_pos = min(LS_FACES, n_vis - pos0);
+    for (int i = threadIdx.x; i < 2 * n_bands; i += blockDim.x) s_cnt[i] = 0;
+    __syncthreads();
+    // (1) lines per band of this workgroup's (face, axis, edge) items
+    for (int it = threadIdx.x; it < 6 * n_pos; it += blockDim.x) {
+        const int p = it / 6, ae = it - 6 * p, axis = ae / 3, e = ae - 3 * axis;
+        const unsigned pr = rng[(((size_t)b * 2 + axis) * F + pos0 + p) * 3 + e];
+        const int lo = (int)(pr & 0xffffu), hi = (int)(pr >> 16);
+        for (int band = lo / W; band * W <= hi; ++band)  // lo > hi (RNG_EMPTY): no iteration
+            atomicAdd(s_cnt + axis * n_bands + band, min(hi, band * W + W - 1) - max(lo, band * W) + 1);
     }
     __syncthreads();
-    const int n_items = s_first[B];
-    const int groups = gridDim.x * (blockDim.x / LPI);
-    for (int item = blockIdx.x * (blockDim.x / LPI) + threadIdx.x / LPI; item < n_items; item += groups) {
-        const int sub = threadIdx.x % LPI;
-        int lo = 0, hi = B - 1;  // image: last b with s_first[b] <= item
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_first[mid] <= item) lo = mid; else hi = mid - 1;
-        }
-        const int b = lo;
-        if (!lines_info[2 * b]) continue;
-        const int r = item - s_first[b];
-        const int pos = r / 6, ae = r - 6 * pos, axis = ae / 3, e = ae - 3 * axis;
-        const unsigned *pr = rng + (((size_t)b * 2 + axis) * F + pos) * 3;
-        int before = 0;  // lines of the face's earlier edges along this axis
-        for (int k = 0; k < e; ++k) {
-            const unsigned q = pr[k];
-            before += max((int)(q >> 16) - (int)(q & 0xffffu) + 1, 0);
-        }
-        const int d_lo = (int)(pr[e] & 0xffffu), d_hi = (int)(pr[e] >> 16);
+    // (2) one reservation per non-empty band
+    for (int i = threadIdx.x; i < 2 * n_bands; i += blockDim.x) {
+        const int c = s_cnt[i];
+        s_base[i] = c > 0 ? atomicAdd(band_cursor + (size_t)b * 2 * n_bands + i, c) : 0;
+        s_cnt[i] = 0;
+    }
+    __syncthreads();
+    // (3) the records: LPI lanes per item stride over its lines
+    const size_t img = (size_t)b * S * S;
+    const int *start_b = band_start + (size_t)b * 2 * n_bands;
+    BandLine *buf_b = line_buf + (size_t)b * cap;
+    for (int t = threadIdx.x; t < 6 * n_pos * LPI; t += blockDim.x) {
+        const int it = t / LPI, sub = t - it * LPI;
+        const int p = it / 6, ae = it - 6 * p, axis = ae / 3, e = ae - 3 * axis;
+        const int pos = pos0 + p;
+        const unsigned pr = rng[(((size_t)b * 2 + axis) * F + pos) * 3 + e];
+        const int d_lo = (int)(pr & 0xffffu), d_hi = (int)(pr >> 16);
         if (d_hi < d_lo) continue;
         const int fn = vis_list[(size_t)b * F + pos];
         const float *fv = faces + ((size_t)b * F + fn) * 9;
-        const size_t img = (size_t)b * S * S;
-        BandLine *dst = line_buf + (size_t)b * cap + (axis ? lines_info[2 * b + 1] : 0) +
-                        line_start[((size_t)b * 2 + axis) * F + pos] + before;
+        const int tgt = pos | (e << 28) | (((e + 1) % 3) << 30);
         for (int d0 = d_lo + sub; d0 <= d_hi; d0 += LPI) {
-            const int ld = d0 % W;
-            dst[d0 - d_lo] = make_fast_line(fv, e, axis, d0, ld, S, fn, e, [&](int d1) {
+            const int band = d0 / W, ld = d0 - band * W;
+            const BandLine rec = make_fast_line(fv, e, axis, d0, ld, S, fn, tgt, [&](int d1) {
                 return fi_map[axis ? img + (size_t)d0 * S + d1 : img + (size_t)d1 * S + d0];
             });
+            const int bi = axis * n_bands + band;
+            buf_b[start_b[bi] + s_base[bi] + atomicAdd(s_cnt + bi, 1)] = rec;
         }
     }
+}
+
+// exclusive prefix of an image's 2 * n_bands line counts (first wave of the block), the image's total and the verdict
+// whether its records fit the buffer; zeroes the fill cursors
+__device__ __forceinline__ void band_prefix(const int *cnt, int n2, int *__restrict__ start_out, int *__restrict__ cursor_out,
+                                            int *__restrict__ ok_out, size_t cap)
+{
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, per = (n2 + 63) / 64;
+    int local = 0;
+    for (int i = lane * per; i < min(n2, (lane + 1) * per); ++i) local += cnt[i];
+    int inc = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    int run = inc - local;
+    for (int i = lane * per; i < min(n2, (lane + 1) * per); ++i) {
+        start_out[i] = run;
+        cursor_out[i] = 0;
+        run += cnt[i];
+    }
+    const int total = __shfl(inc, 63, WAVE);
+    if (lane == 0) *ok_out = ((size_t)total <= cap) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_band_scan(const int *__restrict__ band_lines, int *__restrict__ band_start,
+                                                   int *__restrict__ band_cursor, int *__restrict__ lines_ok, int n_bands,
+                                                   size_t cap, int force_scan)
+{
+    const size_t o = (size_t)blockIdx.x * 2 * n_bands;
+    band_prefix(band_lines + o, 2 * n_bands, band_start + o, band_cursor + o, lines_ok + blockIdx.x, force_scan ? 0 : cap);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1186,8 +1195,8 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
-    double *__restrict__ scratch, const int *__restrict__ band_lines, const int *__restrict__ line_start,
-    const int *__restrict__ lines_info, const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int SP,
+    double *__restrict__ scratch, const int *__restrict__ band_lines, const int *__restrict__ band_start,
+    const int *__restrict__ lines_ok, const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int SP,
     float eps_f, int B, int win_lines)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1199,7 +1208,9 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
-    if (band_lines[((size_t)b * 2 + axis) * n_bands + band] == 0) return;  // step 0: no visible face has a line here
+    const size_t bidx = ((size_t)b * 2 + axis) * n_bands + band;
+    const int n_band_lines = band_lines[bidx];
+    if (n_band_lines == 0) return;  // step 0: no visible face has a line here
     NR_PHASE_BEGIN();
 
     size_t off = 0;
@@ -1211,41 +1222,74 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     px.c = (float *)carve((size_t)W * SP * NC * 4);
     px.bg = (float *)carve(16);
     BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
-    int *s_rec = (int *)carve(4 * WIN);    // slot | edge << 16 | line-in-band << 18
-    int *s_aux = (int *)carve(4 * WIN);    // record index in the image's buffer -- or the face index when there are no records
     int *s_pref = (int *)carve(4 * WIN);
-    double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);
-    int *s_slotpos = (int *)carve(4 * ACC_SLOTS);
     int *s_tmp = (int *)carve(4 * 16);
+    unsigned char *rest = smem + off;  // the two paths below lay out what is left differently
 
     // ---- 1. stage the band
     const size_t img = (size_t)b * S * S;
     fast_stage<RGB, ALPHA>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, img, axis, band_lo, nld, S, SP);
-    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
-    __syncthreads();
     NR_PHASE(1);
 
+    if (lines_ok[b]) {
+        // ================= records path: the band's line records were written by k_line_setup =================
+        double *s_lacc = (double *)rest;  // [WIN][2] sums of each line for its edge's two vertices
+        const BandLine *recs = line_buf + (size_t)b * cap + band_start[bidx];
+        for (int win = 0; win < n_band_lines; win += win_lines) {
+            const int n_win = min(n_band_lines - win, win_lines);
+            int n_seg = 0;
+            if (tid < n_win) {
+                const BandLine r = recs[win + tid];
+                s_line[tid] = r;
+                n_seg = line_segments(r.in_rng, r.out_rng);
+            }
+            if (tid < 2 * n_win) s_lacc[tid] = 0.0;
+            int total_seg = 0;
+            const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);  // (two barriers inside: s_line is visible after)
+            if (tid < n_win) s_pref[tid] = seg_off;
+            __syncthreads();
+            NR_PHASE(5);
+#ifndef NR_K6_NO_SWEEPS
+            fast_sweeps<RGB, ALPHA>(px, s_line, s_pref, n_win, total_seg, SP, eps_f, s_lacc,
+                                    [](int line, int, int k) { return 2 * line + k; }, [](int, int, int, double) {});
+#endif
+            __syncthreads();
+            NR_PHASE(6);
+            if (tid < 2 * n_win) {  // line sums -> global double scratch [list position][vertex][x|y]
+                const double a = s_lacc[tid];
+                if (a != 0.0) {
+                    const int tgt = s_line[tid >> 1].tgt;
+                    const int pos = tgt & 0x0fffffff, v = (tid & 1) ? (tgt >> 30) & 3 : (tgt >> 28) & 3;
+                    atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * v + (1 - axis), a);
+                }
+            }
+            __syncthreads();
+            NR_PHASE(7);
+        }
+        return;
+    }
+
+    // ================= scan path (an image with more lines than the record buffer holds): as k_bpm_band =================
+    int *s_rec = (int *)rest;
+    int *s_recfn = s_rec + WIN;
+    double *s_acc = (double *)(s_recfn + WIN);          // WIN is a multiple of 4: 8-byte aligned
+    int *s_slotpos = (int *)(s_acc + 3 * ACC_SLOTS);
+    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
+    __syncthreads();
     const int n_vis = vis_count[b];
     const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
-    const bool have_records = lines_info[2 * b] != 0;  // k_line_setup wrote this image's line records
-    const int *ls_ba = line_start + ((size_t)b * 2 + axis) * F;
-    const BandLine *recs = line_buf + (size_t)b * cap + (axis ? lines_info[2 * b + 1] : 0);
     for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
         // ---- 2. one visible face per thread: lines of its 3 edges inside the band
-        int fn = -1, nl = 0, rec0 = 0;
-        int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0}, e_rec[3] = {0, 0, 0};
+        int fn = -1, nl = 0;
+        int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
         if (chunk + tid < n_vis) {
             fn = vis_list[(size_t)b * F + chunk + tid];
-            rec0 = ls_ba[chunk + tid];
             const unsigned *r = rng_ba + (size_t)(chunk + tid) * 3;
-            int before = 0;
 #pragma unroll
             for (int e = 0; e < 3; e++) {
                 const unsigned pr = r[e];
-                const int rlo = (int)(pr & 0xffffu), rhi = (int)(pr >> 16);
-                const int lo = max(rlo, band_lo), hi = min(rhi, band_hi);
-                if (hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; e_rec[e] = rec0 + before + (lo - rlo); }
-                before += max(rhi - rlo + 1, 0);
+                const int lo = max((int)(pr & 0xffffu), band_lo), hi = min((int)(pr >> 16), band_hi);
+                if (hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
             }
         }
         int total_packed = 0;
@@ -1263,27 +1307,22 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                     for (int j = 0; j < e_n[e]; j++, k++)
                         if (k >= win && k < win + win_lines) {
                             s_rec[k - win] = slot | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
-                            s_aux[k - win] = have_records ? e_rec[e] + j : fn;
+                            s_recfn[k - win] = fn;
                         }
             }
             __syncthreads();
             const int n_win = min(total_lines - win, win_lines);
             NR_PHASE(3);
 
-            // ---- 3. line records, one per thread: copied from k_line_setup's buffer, or set up here
+            // ---- 3. line setup, one line per thread
             int n_seg = 0;
             if (tid < n_win) {
                 const int rec = s_rec[tid];
                 const int slot_l = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
-                BandLine r;
-                if (have_records) {
-                    r = recs[s_aux[tid]];
-                } else {
-                    const int rfn = s_aux[tid];
-                    r = make_fast_line(faces + ((size_t)b * F + rfn) * 9, e, axis, band_lo + ld, ld, S, rfn, e,
-                                       [&](int d1) { return px.fi[ld * SP + d1]; });
-                }
-                r.tgt = slot_l | (e << 16) | (((e + 1) % 3) << 18);
+                const int rfn = s_recfn[tid];
+                const BandLine r = make_fast_line(faces + ((size_t)b * F + rfn) * 9, e, axis, band_lo + ld, ld, S, rfn,
+                                                  slot_l | (e << 16) | (((e + 1) % 3) << 18),
+                                                  [&](int d1) { return px.fi[ld * SP + d1]; });
                 s_line[tid] = r;
                 n_seg = line_segments(r.in_rng, r.out_rng);
             }
@@ -1309,7 +1348,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             NR_PHASE(6);
         }
 
-        // ---- 5. per-face sums of this chunk -> global double scratch [list position][vertex][x|y]
+        // ---- 5. per-face sums of this chunk -> global double scratch
         {
             const int n_slots = min(total_packed >> 20, ACC_SLOTS);
             if (tid < 3 * n_slots) {
@@ -1348,8 +1387,8 @@ __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__
 // ====================================================================================================
 
 struct BpmLayout {
-    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, band_off, start_off, info_off, lines_off,
-        total, cap;
+    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, band_off, start_off, cursor_off, ok_off,
+        lines_off, total, cap;
     int n_chunks;
 };
 
@@ -1371,9 +1410,10 @@ BpmLayout bpm_layout(int B, int F, int S)
     L.slot_off = L.rng_off + align_up(n * 6 * sizeof(unsigned), 256);  // rng: [B][axis][position][edge]
     const size_t per_band = align_up((size_t)B * 2 * S * sizeof(int), 256);  // per (image, axis, band): at most S bands (W = 1)
     L.band_off = L.slot_off + align_up(n * sizeof(int), 256);
-    L.start_off = L.band_off + per_band;                                  // line_start [B][axis][position]
-    L.info_off = L.start_off + align_up(2 * n * sizeof(int), 256);        // lines_info [B][2]
-    L.lines_off = L.info_off + align_up((size_t)B * 2 * sizeof(int), 256);
+    L.start_off = L.band_off + per_band;
+    L.cursor_off = L.start_off + per_band;
+    L.ok_off = L.cursor_off + per_band;
+    L.lines_off = L.ok_off + align_up((size_t)B * sizeof(int), 256);
     L.cap = line_capacity(F, S);
     L.total = L.lines_off + (size_t)B * L.cap * sizeof(BandLine);
     return L;
@@ -1385,10 +1425,12 @@ BpmLayout bpm_layout(int B, int F, int S)
 constexpr size_t LDS_BUDGET = NR_K6_LDS_BUDGET_KB * 1024 + 512;  // 53 KB: three workgroups per 160 KB CU
 constexpr int FAST_WIN_SMALL = 128;
 
-// line records + three ints per line + per-face accumulator slots + scan scratch + background colour + alignment slack
+// line records + segment prefixes + scan scratch + background colour + the larger of the two paths' private parts
+// (records path: two double sums per line; scan path: compaction records + per-face accumulator slots) + alignment slack
 constexpr size_t band_fixed_lds(int win)
 {
-    return (sizeof(BandLine) + 12) * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 16 + 10 * 16;
+    const size_t a = 16 * (size_t)win, b = 8 * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS;
+    return (sizeof(BandLine) + 4) * (size_t)win + 64 + 16 + (a > b ? a : b) + 8 * 16;
 }
 
 // band width (lines per workgroup) and line window for the given raster size and modes; 0 = does not fit (global fallback)
@@ -1401,7 +1443,9 @@ int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *
     for (int W = 4; W >= 1; W >>= 1) {
         // three workgroups per CU with a 128-line window beat two with 256 (the phases of co-resident workgroups overlap)
         for (int w = BAND_WIN; w >= (exact ? BAND_WIN : FAST_WIN_SMALL); w >>= 1) {
-            const size_t need = (size_t)W * SP * per_px + band_fixed_lds(w);
+            const size_t fixed = exact ? (sizeof(BandLine) + 12) * (size_t)w + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16
+                                       : band_fixed_lds(w);
+            const size_t need = (size_t)W * SP * per_px + fixed;
             if (need <= LDS_BUDGET || (W == 1 && w == (exact ? BAND_WIN : FAST_WIN_SMALL) && need <= 160 * 1024)) {
                 *lds_bytes = need;
                 *win = w;
@@ -1449,7 +1493,7 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
 template <bool RGB, bool ALPHA, int WIN>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
-                const int *band_lines, const int *line_start, const int *lines_info, const BandLine *line_buf, size_t cap,
+                const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
                 int B, int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
 {
     static LdsLimit limit;
@@ -1457,7 +1501,7 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
-                       vis_list, vis_count, rng, scratch, band_lines, line_start, lines_info, line_buf, cap, F, S, W, S + 4,
+                       vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
                        (float)eps, B, min(win_lines, WIN));
     return 0;
 }
@@ -1528,16 +1572,15 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                            S * S, P);
         vflags = f;
     }
-    int *line_start = (int *)(ws + L.start_off), *lines_info = (int *)(ws + L.info_off);
+    int *band_start = (int *)(ws + L.start_off), *band_cursor = (int *)(ws + L.cursor_off), *lines_ok = (int *)(ws + L.ok_off);
     BandLine *line_buf = (BandLine *)(ws + L.lines_off);
-    // Line records (k_line_setup) serve the default kernel on meshes the one-workgroup-per-image compaction handles (it
-    // computes the record positions); the exact kernel, larger meshes and NR_FLAG_K6_SCAN set lines up in the band kernel.
-    const bool small = L.n_chunks <= SMALL_CHUNKS;
-    const bool use_records = !exact && small && !(flags & NR_FLAG_K6_SCAN) && B <= 8192;
-    if (small) {
+    // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
+    const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 3072;  // grid.y and 48 KB of LDS in k_line_setup
+    const size_t cap = use_records ? L.cap : 0;  // capacity 0: every image is told to take the scan path
+    if (L.n_chunks <= SMALL_CHUNKS) {
         hipLaunchKernelGGL(k_compact_small, dim3((unsigned)B), dim3(VIS_CHUNK), (size_t)2 * n_bands * sizeof(int), st, vflags,
                            vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W,
-                           line_start, lines_info, use_records ? L.cap : 0);
+                           band_start, band_cursor, lines_ok, cap);
     } else {
         int *chunk_count = (int *)(ws + L.chunk_off);
         hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
@@ -1545,15 +1588,14 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
                            chunk_count, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines,
                            n_bands, W);
-        if (!exact) {  // no records for these images
-            const hipError_t he = hipMemsetAsync(lines_info, 0, (size_t)B * 2 * sizeof(int), st);
-            if (he != hipSuccess) return (int)he;
-        }
+        if (!exact)
+            hipLaunchKernelGGL(k_band_scan, dim3((unsigned)B), dim3(256), 0, st, band_lines, band_start, band_cursor, lines_ok,
+                               n_bands, cap, 0);
     }
     if (use_records) {
-        // a resident grid walks the (image, visible face, axis, edge) items; 8 workgroups per CU
-        hipLaunchKernelGGL(k_line_setup, dim3(2048), dim3(256), (size_t)(B + 1) * sizeof(int), st, faces, face_index_map,
-                           vis_list, vis_count, rng, line_start, lines_info, line_buf, L.cap, B, F, S, W);
+        hipLaunchKernelGGL(k_line_setup, dim3((unsigned)((F + LS_FACES - 1) / LS_FACES), (unsigned)B), dim3(256),
+                           (size_t)4 * n_bands * sizeof(int), st, faces, face_index_map, vis_list, vis_count, rng, band_start,
+                           band_cursor, lines_ok, line_buf, L.cap, F, S, W, n_bands);
     }
     // lines per window: the packed segment scan keeps the count of full segments in 16 bits (<= win * 2 * S / SEG)
     const int win_lines = max(1, min(BAND_WIN, (int)(65535ll * SEG / (2ll * S))));
@@ -1571,10 +1613,10 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
 #define NR_FAST(R, A)                                                                                                   \
     (win == BAND_WIN                                                                                                    \
          ? launch_fast<R, A, BAND_WIN>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
-                                       vis_count, rng, scratch, band_lines, line_start, lines_info, line_buf, L.cap, B, F, S, W, lds, \
+                                       vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, \
                                        eps, win_lines, st)                                                                \
          : launch_fast<R, A, FAST_WIN_SMALL>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,    \
-                                             vis_list, vis_count, rng, scratch, band_lines, line_start, lines_info, line_buf, \
+                                             vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf,  \
                                              L.cap, B, F, S, W, lds, eps, win_lines, st))
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
