@@ -29,6 +29,18 @@ __device__ __forceinline__ float group_sum(float v, int width)
     return v;
 }
 
+// Sum over a 16-lane group (= one DPP row), delivered in the group's LAST lane (sub == 15): four v_add_f32 with a row_shr
+// DPP operand (lanes shifted in from outside the row read 0) instead of four LDS-crossbar swizzles + adds per value.  The 33
+// sums of a face (24 texel + 9 vertex accumulators) make this the longest instruction run of the gather kernels.
+__device__ __forceinline__ float row16_sum_last(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));  // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));  // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));  // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));  // row_shr:8
+    return v;
+}
+
 // --------------------------------------------------------------------------------------------------
 // B2: one face per group of L lanes (L = 16 | 64 | 256, a power of two; 256 / L faces per workgroup).
 // TS2 = true: texture_size == 2 and eps > 0, so every tap index is static: corner pn -> texel
@@ -149,10 +161,10 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     }
 
     if (TS2) {
-        // L == 16 here: xor-reduce inside the 16-lane row, lane 0 stores the face's 24 floats (96 B)
+        // L == 16 here: reduce inside the 16-lane row, its last lane stores the face's 24 floats (96 B)
 #pragma unroll
-        for (int k = 0; k < 24; k++) acc[k] = group_sum(acc[k], 16);
-        if (face_ok && sub == 0) {
+        for (int k = 0; k < 24; k++) acc[k] = row16_sum_last(acc[k]);
+        if (face_ok && sub == 15) {
             float o[24];
 #pragma unroll
             for (int pn = 0; pn < 8; pn++) {
@@ -175,8 +187,8 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     if (DEPTH) {  // L <= 64 here (the host only fuses when a face group fits in one wave)
         if (__ballot(any_box) == 0ull) return;
 #pragma unroll
-        for (int k = 0; k < 9; k++) dacc[k] = group_sum(dacc[k], L);
-        if (face_ok && any_box && sub == 0) {
+        for (int k = 0; k < 9; k++) dacc[k] = (L == 16) ? row16_sum_last(dacc[k]) : group_sum(dacc[k], L);
+        if (face_ok && any_box && sub == ((L == 16) ? 15 : 0)) {
             float *gf = grad_faces + (size_t)gi * 9;
 #pragma unroll
             for (int k = 0; k < 9; k++) gf[k] += dacc[k];
@@ -454,8 +466,8 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
     }
     if (__ballot(any_box) == 0ull) return;  // whole wave has nothing to add
 #pragma unroll
-    for (int k = 0; k < 9; k++) acc[k] = group_sum(acc[k], L);
-    if (face_ok && any_box && sub == 0) {
+    for (int k = 0; k < 9; k++) acc[k] = row16_sum_last(acc[k]);
+    if (face_ok && any_box && sub == 15) {
         float *gf = grad_faces + (size_t)gi * 9;
 #pragma unroll
         for (int k = 0; k < 9; k++) gf[k] += acc[k];

@@ -230,40 +230,36 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 //          pixel.  A face that owns no pixel contributes nothing to K6 (the out sweep needs face_index[in] == fn,
 //          :604, the in sweep only counts pixels owned by fn, :707), so ~2/3 of the front faces drop out.  The
 //          compaction also stores, per listed face, the line range of each of its 3 edges along both axes, zeroes the
-//          face's six double sums (indexed by list position: no fill launch) and records face -> list position.
+//          face's six double sums (indexed by list position: no fill launch), records face -> list position and counts the
+//          lines of every (axis, band): a band workgroup whose count is zero leaves at once (more than half of the bands
+//          of a teapot view: the object covers 12 % of the image).
+//   k_line_setup (default kernel only)   every line's record (crossing point, in / out pixels, sweep ranges, the two
+//          distance coefficients: rasterize.py:573-579, :606-609, :665-672), written band by band into one buffer.
 //   k_bpm_fast (default) / k_bpm_band (NR_FLAG_EXACT_GRADIENT)   one workgroup per (image, axis, band of W consecutive
 //          lines d0); workgroup ids are mapped so that all bands of an image run on one XCD (xcd_block).  It
-//          0. counts the lines the image's visible faces have in the band and leaves when there are none (more than half
-//             of the bands of a teapot view: the object covers 12 % of the image);
 //          1. stages the band's W x S pixels in LDS, laid out [line][d1] so that a sweep is a contiguous LDS run
 //             whatever the axis;
-//          2. scans the image's visible faces (one per thread, 12 coalesced bytes each): for each of the 3 edges the
-//             precomputed d0 range clipped to the band gives the face's lines; an exclusive scan assigns line slots;
-//          3. sets lines up one per thread (crossing point, in/out pixels, sweep ranges, the two distance
-//             coefficients, rasterize.py:573-579, :606-609, :665-672) into LDS records;
-//          4. sweeps: the in / out sweeps of all lines are cut into segments of <= SEG = 15 pixels; segment ids are
+//          2. gets its line records: k_bpm_fast copies the band's slice of k_line_setup's buffer (256 at a time); k_bpm_band
+//             -- and k_bpm_fast for an image whose records exceed the buffer -- scans the image's visible faces (one per
+//             thread, 12 coalesced bytes each: the precomputed d0 ranges clipped to the band), assigns line slots with an
+//             exclusive scan and sets the lines up one per thread;
+//          3. sweeps: the in / out sweeps of all lines are cut into segments of <= SEG = 15 pixels; segment ids are
 //             dense (one packed scan of the per-line counts) and ordered by class -- all full-length segments first,
 //             the remainders after -- and one thread walks one segment (binary search id -> line), so the lanes of a
 //             wave have equal trip counts whatever the mix of short in-sweeps and border-long out-sweeps; the two
-//             partial sums of a segment are added to per-face LDS accumulators (ds_add_f64);
-//          5. adds the per-face sums to a double scratch array [B][list position][3 vertices][x|y] (global_atomic_add_f64).
+//             partial sums of a segment are added to per-line (k_bpm_fast) or per-face LDS accumulators (ds_add_f64);
+//          4. adds the sums to a double scratch array [B][list position][3 vertices][x|y] (global_atomic_add_f64).
 //   k_bpm_finalize   rounds the scratch sums to float and STORES grad_faces (z = 0; zeros for unlisted faces).
 //
-// Two instantiations of step 1 / 4 (DESIGN.md "K6 numerics"):
+// Two kernels for the sweeps (DESIGN.md "K6 numerics"):
 //   k_bpm_band  EXACT: every per-pixel term is computed with the reference's arithmetic (IEEE division, the double
 //          `dist +- eps`), sums in double: the result is the correctly rounded sum of the reference's terms up to double
 //          round-off (<= 2e-6 against the exactly summed oracle).
-//   k_bpm_fast  the north star's tolerance (1e-4) spent where it buys time: fused multiply-adds for the colour difference,
-//          dist = fma(c * 2/S, t, +-eps) in float and diff * v_rcp_f32(dist) instead of two IEEE divisions and the double
-//          `dist +- eps`, float sums over the <= 15 terms of a segment, double from there on; pixel data as 40-byte records
-//          read with three LDS instructions.  ~24 issue slots per visit instead of ~95; deviation see the kernel's comment.
+//   k_bpm_fast  the north star's tolerance (1e-4) spent where it buys time; see the comment above that kernel.
 constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per pass
 constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
-#ifndef NR_SEG
-#define NR_SEG 15
-#endif
-constexpr int SEG = NR_SEG;      // pixels of a sweep walked by one thread (odd: consecutive segments of a
+constexpr int SEG = 15;          // pixels of a sweep walked by one thread (odd: consecutive segments of a
                                  // sweep start 15 dwords apart, i.e. on different LDS banks)
 
 struct __attribute__((aligned(16))) BandLine {
@@ -937,8 +933,8 @@ __device__ __forceinline__ int line_segments(int in_rng, int out_rng)
 //   places each at band_start + block base + an LDS cursor.  The order inside a band is irrelevant: every record is
 //   accumulated independently.  tgt = list position | v0 << 28 | v1 << 30.
 // Images whose lines exceed the buffer's capacity (lines_ok[b] == 0) are skipped here and take the scan path of k_bpm_fast.
-constexpr int LPI = 4;        // lanes per (face, axis, edge) item
-constexpr int LS_FACES = 64;  // list positions per workgroup
+constexpr int LPI = 2;        // lanes per (face, axis, edge) item (an edge crosses 3-4 lines on a fine mesh)
+constexpr int LS_FACES = 32;  // list positions per workgroup (measured: 64 -> 43 us, 32 -> 29 us, 16 -> 29 us; LPI 2: 27 us)
 
 __global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ faces, const int32_t *__restrict__ fi_map,
                                                     const int *__restrict__ vis_list, const int *__restrict__ vis_count,
@@ -1419,10 +1415,7 @@ BpmLayout bpm_layout(int B, int F, int S)
     return L;
 }
 
-#ifndef NR_K6_LDS_BUDGET_KB
-#define NR_K6_LDS_BUDGET_KB 53
-#endif
-constexpr size_t LDS_BUDGET = NR_K6_LDS_BUDGET_KB * 1024 + 512;  // 53 KB: three workgroups per 160 KB CU
+constexpr size_t LDS_BUDGET = 53 * 1024 + 512;  // three workgroups per 160 KB CU (two with 256-line windows: 367 vs 337 us)
 constexpr int FAST_WIN_SMALL = 128;
 
 // line records + segment prefixes + scan scratch + background colour + the larger of the two paths' private parts
@@ -1577,7 +1570,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
     const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 3072;  // grid.y and 48 KB of LDS in k_line_setup
     const size_t cap = use_records ? L.cap : 0;  // capacity 0: every image is told to take the scan path
-    if (L.n_chunks <= SMALL_CHUNKS) {
+    // (the one-workgroup-per-image compaction keeps the image's 2 * n_bands line counters in LDS: 32 KB at most)
+    if (L.n_chunks <= SMALL_CHUNKS && n_bands <= 4096) {
         hipLaunchKernelGGL(k_compact_small, dim3((unsigned)B), dim3(VIS_CHUNK), (size_t)2 * n_bands * sizeof(int), st, vflags,
                            vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W,
                            band_start, band_cursor, lines_ok, cap);

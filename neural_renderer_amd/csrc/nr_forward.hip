@@ -144,69 +144,6 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     }
 }
 
-#ifdef NR_FWD_TWO_PHASE
-// wave-aggregated append: one atomic per wave and list
-__device__ __forceinline__ void list_append(bool want, int value, int *__restrict__ list, int *__restrict__ counter)
-{
-    const unsigned long long m = __ballot(want);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(m)) + 1;  // the counters start at -1
-    base = __shfl(base, leader, WAVE);
-    if (want) list[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
-}
-
-__global__ __launch_bounds__(256) void k_face_setup(const float *__restrict__ faces, int *__restrict__ small_list,
-                                                    int *__restrict__ large_list, int *__restrict__ counters,
-                                                    unsigned char *__restrict__ visible_faces, int n_faces_total, int S)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool small = false, large = false;
-    if (i < n_faces_total) {
-        if (visible_faces) visible_faces[i] = 0;
-        const float *f = faces + (size_t)i * 9;
-        const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-        if (cd.n > 0) {
-            large = cd.strip || cd.n > SMALL_AREA;
-            small = !large;
-        }
-    }
-    list_append(large, i, large_list, counters);
-    list_append(small, i, small_list, counters + 1);
-}
-
-__global__ __launch_bounds__(256) void k_face_raster_list(const float *__restrict__ faces,
-                                                          unsigned long long *__restrict__ zbuf,
-                                                          const int *__restrict__ small_list,
-                                                          const int *__restrict__ n_small, int F, int S, double near_d,
-                                                          double far_d)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t / LPF, sub = t - j * LPF;
-    if (j > *n_small) return;  // the counter holds (number of entries - 1)
-    const int i = small_list[j];
-    const float *f = faces + (size_t)i * 9;
-    const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-    FaceGeo g;
-    float inv[9];
-    load_face_geo(f, S, g, inv);
-    const int b = i / F;
-    const unsigned fnu = (unsigned)(i - b * F);
-    unsigned long long *zimg = zbuf + (size_t)b * S * S;
-    const bool pow2 = (S & (S - 1)) == 0;
-    const float inv_s = 1.0f / (float)S;
-    const int x_hi = cd.x_lo + cd.bw - 1, y_hi = cd.y_lo + cd.n / cd.bw - 1;
-    for (int py = cd.y_lo + sub; py <= y_hi; py += LPF) {
-        const float yp = pixel_center_p(py, S, inv_s, pow2);
-        unsigned long long *zrow = zimg + (size_t)py * S;
-        for (int px = cd.x_lo; px <= x_hi; ++px)
-            raster_pixel(g, fnu, px, py, pixel_center_p(px, S, inv_s, pow2), yp, near_d, far_d, zrow);
-    }
-}
-#endif
-
 __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces,
                                                       unsigned long long *__restrict__ zbuf,
                                                       const int *__restrict__ large_list,
@@ -390,7 +327,7 @@ FwdLayout fwd_layout(int B, int F, int S)
     L.zbuf_off = 0;
     L.count_off = L.zbuf_off + P * sizeof(unsigned long long);  // the counter sits right behind the z-buffer
     L.list_off = align_up(L.count_off + sizeof(long long), 256);
-    L.total = L.list_off + 2 * n * sizeof(int);  // queue of large faces + (two-phase build) list of small ones
+    L.total = L.list_off + n * sizeof(int);
     return L;
 }
 }  // namespace
@@ -421,16 +358,8 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     // one fill: ZEMPTY words and, right behind them, the large-face counter at -1
     const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
     if (he != hipSuccess) return (int)he;
-#ifdef NR_FWD_TWO_PHASE  // development build: cull / classify first, rasterize the compacted list of small faces
-    int *small_list = large_list + n;
-    hipLaunchKernelGGL(k_face_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, small_list, large_list,
-                       n_large, visible_faces, (int)n, S);
-    hipLaunchKernelGGL(k_face_raster_list, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, zbuf, small_list,
-                       n_large + 1, F, S, near, far);
-#else
     hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
                        n_large, visible_faces, (int)n, F, S, near, far);
-#endif
     // a few workgroups per CU loop over the queue (one per CU left the kernel latency-bound: config 4, 189 -> ~85 us);
     // with an empty queue (any ordinary mesh) they read the counter and leave
     hipLaunchKernelGGL(k_large_raster, dim3(1024), dim3(256), 0, st, faces, zbuf, large_list, n_large, F, S, near, far);

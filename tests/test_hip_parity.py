@@ -318,6 +318,16 @@ def test_band_width_classes(S):
     check_backward(faces, textures, S, 1e-3, (True, True, True), seed=301 + S)
 
 
+@pytest.mark.parametrize('S', [4096, 6000])
+def test_very_large_raster_alpha_only(S):
+    """Raster sizes at which one band line only just fits in LDS (W = 1, alpha only) and the packed segment scan of K6 needs
+    shorter line windows (full-segment counts are kept in 16 bits: 256 lines x 2 S / 15 segments would overflow beyond
+    S = 1919); 6000 is not a power of two and its 2 x 6000 band counters do not fit the compaction's LDS histogram."""
+    rng = np.random.default_rng(4000 + S)
+    faces = H.random_scene(rng, 1, 16, spread=0.5, size=0.35)
+    check_backward(faces, None, S, 1e-4, (False, True, False), seed=4001 + S)
+
+
 def test_known_answer_gradients_through_renderer():
     """The reference's grad_ref constants (tests/test_rasterize_silhouettes.py:37-99) through the full
     PyTorch-facing API: Renderer -> look_at -> vertices_to_faces -> HIP rasterizer -> autograd."""
