@@ -41,6 +41,37 @@ __device__ __forceinline__ float row16_sum_last(float v)
     return v;
 }
 
+// K8's per-face constants (rasterize.py:824-837) when the inverse matrix is recomputed from the vertices: tmp_l = sum_m
+// -face_inv[m][l] / z_m and 1 / z_k^2.  Reciprocals instead of the reference's 21 divisions per PIXEL (4 IEEE divisions per
+// FACE): a term then differs from the reference's by ~1 ulp, far below the float partial sums K8 is accumulated in (both
+// here and, through unordered atomics, in the reference).
+struct DepthConst {
+    float tmp[3], rzz[3];
+};
+__device__ __forceinline__ DepthConst depth_constants(const float f[9], int S)
+{
+    const float fs = (float)S;
+    const float px[3] = {to_pixel(f[0], fs), to_pixel(f[3], fs), to_pixel(f[6], fs)};
+    const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
+    // compute_face_inv (rasterize.py:261-269) with one reciprocal of the determinant
+    float inv[9];
+    inv[0] = py[1] - py[2]; inv[1] = px[2] - px[1]; inv[2] = px[1] * py[2] - px[2] * py[1];
+    inv[3] = py[2] - py[0]; inv[4] = px[0] - px[2]; inv[5] = px[2] * py[0] - px[0] * py[2];
+    inv[6] = py[0] - py[1]; inv[7] = px[1] - px[0]; inv[8] = px[0] * py[1] - px[1] * py[0];
+    const float den = px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]);
+    const float rden = 1.0f / den;
+    const float rz[3] = {1.0f / f[2], 1.0f / f[5], 1.0f / f[8]};
+    DepthConst d;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d.tmp[k] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 3; l++) d.tmp[k] += -(inv[3 * l + k] * rden) * rz[l];
+        d.rzz[k] = rz[k] * rz[k];
+    }
+    return d;
+}
+
 // --------------------------------------------------------------------------------------------------
 // B2: one face per group of L lanes (L = 16 | 64 | 256, a power of two; 256 / L faces per workgroup).
 // TS2 = true: texture_size == 2 and eps > 0, so every tap index is static: corner pn -> texel
@@ -89,14 +120,12 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
         if (cd.n > 0 && (L == 256 || (cd.n <= BIG_PX))) {  // the rest is k_backward_big's
             any_box = true;
-            float inv[9], fv[9];
+            DepthConst dc;
             if (DEPTH) {
+                float fv[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) fv[k] = f[k];
-                const float fs = (float)S;
-                const float px[3] = {to_pixel(fv[0], fs), to_pixel(fv[3], fs), to_pixel(fv[6], fs)};
-                const float py[3] = {to_pixel(fv[1], fs), to_pixel(fv[4], fs), to_pixel(fv[7], fs)};
-                compute_face_inv(px, py, inv);
+                dc = depth_constants(fv, S);
             }
             // z of the three vertices as the forward sampled them: batch 0's geometry (zbase) unless fixed (:389, Q1)
             const float *fz = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fn * 9;
@@ -128,19 +157,11 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                 if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
                     const float depth2 = depth * depth;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        const float z_k = fv[3 * k + 2];
-                        dacc[3 * k + 2] += gd * wk[k] * depth2 / (z_k * z_k);
-                    }
-                    float tmp[3] = {0.0f, 0.0f, 0.0f};
+                    for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 * dc.rzz[k];
 #pragma unroll
                     for (int k = 0; k < 3; k++)
 #pragma unroll
-                        for (int l = 0; l < 3; l++) tmp[k] += -inv[3 * l + k] / fv[3 * l + 2];
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-#pragma unroll
-                        for (int l = 0; l < 2; l++) dacc[3 * k + l] += -gd * tmp[l] * wk[k] * depth2 * (float)S / 2.0f;
+                        for (int l = 0; l < 2; l++) dacc[3 * k + l] += -gd * dc.tmp[l] * wk[k] * depth2 * (float)S / 2.0f;
                 }
 #pragma unroll
                 for (int pn = 0; pn < 8; pn++) {
@@ -246,13 +267,8 @@ __global__ __launch_bounds__(256) void k_backward_big(
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = fp[k];
         const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-        float inv[9];
-        if (DEPTH) {
-            const float fs = (float)S;
-            const float px[3] = {to_pixel(f[0], fs), to_pixel(f[3], fs), to_pixel(f[6], fs)};
-            const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
-            compute_face_inv(px, py, inv);
-        }
+        DepthConst dc;
+        if (DEPTH) dc = depth_constants(f, S);
         const float *fz = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fn * 9;  // :389, Q1
         const float face_z[3] = {fz[2], fz[5], fz[8]};
         for (int k = tid; k < n_lds; k += 256) s_tex[k] = 0.0;
@@ -301,20 +317,17 @@ __global__ __launch_bounds__(256) void k_backward_big(
             }
             if (DEPTH) {  // rasterize.py:824-837, as in k_backward_depth_face
                 const float gd = g_depth[p];
-                float iv[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) iv[k] = face_inv_map ? face_inv_map[9 * p + k] : inv[k];
                 const float depth2 = depth * depth;
+                float tmp[3] = {dc.tmp[0], dc.tmp[1], dc.tmp[2]};
+                if (face_inv_map) {  // the reference's per-pixel residual: its values, its divisions
+                    tmp[0] = tmp[1] = tmp[2] = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float z_k = f[3 * k + 2];
-                    dacc[3 * k + 2] += gd * wk[k] * depth2 / (z_k * z_k);
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int l = 0; l < 3; l++) tmp[k] += -face_inv_map[9 * p + 3 * l + k] / f[3 * l + 2];
                 }
-                float tmp[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int l = 0; l < 3; l++) tmp[k] += -iv[3 * l + k] / f[3 * l + 2];
+                for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 * dc.rzz[k];
 #pragma unroll
                 for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -425,11 +438,7 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
         const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
         if (cd.n > 0 && cd.n <= BIG_PX) {  // the rest is k_backward_big's
             any_box = true;
-            float inv[9];
-            const float fs = (float)S;
-            const float px[3] = {to_pixel(f[0], fs), to_pixel(f[3], fs), to_pixel(f[6], fs)};
-            const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
-            compute_face_inv(px, py, inv);
+            const DepthConst dc = depth_constants(f, S);
             const size_t img = (size_t)b * S * S;
             for (int i = sub; i < cd.n; i += L) {
                 int x, y;
@@ -440,23 +449,19 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
                 const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
                 const float gd = g_depth[p];
                 if (fi_p != fn) continue;
-                if (face_inv_map) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) inv[k] = face_inv_map[9 * p + k];
-                }
                 const float depth2 = depth * depth;
                 // :824-827
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float z_k = f[3 * k + 2];
-                    acc[3 * k + 2] += gd * w[k] * depth2 / (z_k * z_k);
-                }
+                for (int k = 0; k < 3; k++) acc[3 * k + 2] += gd * w[k] * depth2 * dc.rzz[k];
                 // :830-837
-                float tmp[3] = {0.0f, 0.0f, 0.0f};
+                float tmp[3] = {dc.tmp[0], dc.tmp[1], dc.tmp[2]};
+                if (face_inv_map) {  // the reference's per-pixel residual: its values, its divisions
+                    tmp[0] = tmp[1] = tmp[2] = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 3; k++)
+                    for (int k = 0; k < 3; k++)
 #pragma unroll
-                    for (int l = 0; l < 3; l++) tmp[k] += -inv[3 * l + k] / f[3 * l + 2];
+                        for (int l = 0; l < 3; l++) tmp[k] += -face_inv_map[9 * p + 3 * l + k] / f[3 * l + 2];
+                }
 #pragma unroll
                 for (int k = 0; k < 3; k++)
 #pragma unroll
