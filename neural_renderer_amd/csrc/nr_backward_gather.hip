@@ -41,33 +41,26 @@ __device__ __forceinline__ float row16_sum_last(float v)
     return v;
 }
 
-// K8's per-face constants (rasterize.py:824-837) when the inverse matrix is recomputed from the vertices: tmp_l = sum_m
-// -face_inv[m][l] / z_m and 1 / z_k^2.  Reciprocals instead of the reference's 21 divisions per PIXEL (4 IEEE divisions per
-// FACE): a term then differs from the reference's by ~1 ulp, far below the float partial sums K8 is accumulated in (both
-// here and, through unordered atomics, in the reference).
+// K8's per-face constants (rasterize.py:830-833) when the inverse matrix is recomputed from the vertices: tmp_l = sum_m
+// -face_inv[m][l] / z_m, evaluated ONCE per face with the reference's own operations (the three terms cancel: reciprocal
+// shortcuts here showed up as 5e-4 in grad_faces), instead of once per pixel.  zz[k] = z_k * z_k (:826).
 struct DepthConst {
-    float tmp[3], rzz[3];
+    float tmp[3], zz[3];
 };
 __device__ __forceinline__ DepthConst depth_constants(const float f[9], int S)
 {
     const float fs = (float)S;
     const float px[3] = {to_pixel(f[0], fs), to_pixel(f[3], fs), to_pixel(f[6], fs)};
     const float py[3] = {to_pixel(f[1], fs), to_pixel(f[4], fs), to_pixel(f[7], fs)};
-    // compute_face_inv (rasterize.py:261-269) with one reciprocal of the determinant
     float inv[9];
-    inv[0] = py[1] - py[2]; inv[1] = px[2] - px[1]; inv[2] = px[1] * py[2] - px[2] * py[1];
-    inv[3] = py[2] - py[0]; inv[4] = px[0] - px[2]; inv[5] = px[2] * py[0] - px[0] * py[2];
-    inv[6] = py[0] - py[1]; inv[7] = px[1] - px[0]; inv[8] = px[0] * py[1] - px[1] * py[0];
-    const float den = px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]);
-    const float rden = 1.0f / den;
-    const float rz[3] = {1.0f / f[2], 1.0f / f[5], 1.0f / f[8]};
+    compute_face_inv(px, py, inv);
     DepthConst d;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         d.tmp[k] = 0.0f;
 #pragma unroll
-        for (int l = 0; l < 3; l++) d.tmp[k] += -(inv[3 * l + k] * rden) * rz[l];
-        d.rzz[k] = rz[k] * rz[k];
+        for (int l = 0; l < 3; l++) d.tmp[k] += -inv[3 * l + k] / f[3 * l + 2];
+        d.zz[k] = f[3 * k + 2] * f[3 * k + 2];
     }
     return d;
 }
@@ -157,7 +150,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                 if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
                     const float depth2 = depth * depth;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 * dc.rzz[k];
+                    for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 / dc.zz[k];
 #pragma unroll
                     for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -327,7 +320,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
                         for (int l = 0; l < 3; l++) tmp[k] += -face_inv_map[9 * p + 3 * l + k] / f[3 * l + 2];
                 }
 #pragma unroll
-                for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 * dc.rzz[k];
+                for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 / dc.zz[k];
 #pragma unroll
                 for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -452,7 +445,7 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
                 const float depth2 = depth * depth;
                 // :824-827
 #pragma unroll
-                for (int k = 0; k < 3; k++) acc[3 * k + 2] += gd * w[k] * depth2 * dc.rzz[k];
+                for (int k = 0; k < 3; k++) acc[3 * k + 2] += gd * w[k] * depth2 / dc.zz[k];
                 // :830-837
                 float tmp[3] = {dc.tmp[0], dc.tmp[1], dc.tmp[2]};
                 if (face_inv_map) {  // the reference's per-pixel residual: its values, its divisions
