@@ -473,6 +473,13 @@ def main():
             ms3 = time_step(make_step(faces, textures, S, ones), dev, args.steps, 2)
             extra_rows.append({'row': 'all-ones upstream gradient (reference misc/measure_time.py:60)', 'ms_per_step': ms3,
                                'mpixel_per_s_raster': B * S * S / (ms3 * 1e-3) / 1e6})
+            try:  # the same step replayed from a captured HIP graph: what the ~15 launches and allocations cost the host
+                from neural_renderer_amd.graph import capture
+                ms4 = time_step(capture(local_step, dev), dev, args.steps, 2)
+                extra_rows.append({'row': 'headline step replayed from a captured HIP graph (neural_renderer_amd.graph)',
+                                   'ms_per_step': ms4, 'mpixel_per_s_raster': B * S * S / (ms4 * 1e-3) / 1e6})
+            except Exception as ex:  # pragma: no cover
+                extra_rows.append({'row': 'hip graph capture failed: %s' % ex, 'ms_per_step': float('nan')})
             e2e = renderer_end_to_end(dev, B, rank * B, world * B, S, ts)
         cpu = None
         if args.cpu_sample_views > 0 and world == 1:

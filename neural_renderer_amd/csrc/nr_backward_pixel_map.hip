@@ -1053,7 +1053,41 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
             if (fi < 0) px.bg[0] = al;
         }
     };
-    if (axis) {  // a band line is an image row: thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
+    // four adjacent pixels of a map row with one 16-byte load per field: the 4 columns of a vertical band (one thread per
+    // row) or 4 consecutive pixels of a horizontal band's line (one thread per quad); `l0 + j * lstep` is pixel j's LDS slot
+    auto put_quad = [&](size_t g, int l0, int lstep) {
+        const int4 vf = *reinterpret_cast<const int4 *>(fi_map + g);
+        float4 va = make_float4(0, 0, 0, 0), vg = va;
+        if (ALPHA) {
+            va = *reinterpret_cast<const float4 *>(alpha_map + g);
+            vg = *reinterpret_cast<const float4 *>(g_alpha + g);
+        }
+        float rr[12], qq[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) rr[k] = qq[k] = 0.0f;
+        if (RGB) {
+            const float4 *pr = reinterpret_cast<const float4 *>(rgb_map + 3 * g);
+            const float4 *pg = reinterpret_cast<const float4 *>(g_rgb + 3 * g);
+            const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], q0 = pg[0], q1 = pg[1], q2 = pg[2];
+            rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+            rr[8] = r2.x; rr[9] = r2.y; rr[10] = r2.z; rr[11] = r2.w;
+            qq[0] = q0.x; qq[1] = q0.y; qq[2] = q0.z; qq[3] = q0.w; qq[4] = q1.x; qq[5] = q1.y; qq[6] = q1.z; qq[7] = q1.w;
+            qq[8] = q2.x; qq[9] = q2.y; qq[10] = q2.z; qq[11] = q2.w;
+        }
+        const int fis[4] = {vf.x, vf.y, vf.z, vf.w};
+        const float als[4] = {va.x, va.y, va.z, va.w}, gas[4] = {vg.x, vg.y, vg.z, vg.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            put(l0 + j * lstep, fis[j], als[j], gas[j], rr[3 * j], rr[3 * j + 1], rr[3 * j + 2], qq[3 * j], qq[3 * j + 1],
+                qq[3 * j + 2]);
+    };
+    if (axis && (S & 3) == 0) {  // a band line is an image row: thread -> (line, quad of 4 consecutive pixels)
+        const int quads = S >> 2;
+        for (int i = tid; i < nld * quads; i += BAND_THREADS) {
+            const int ld = i / quads, x = (i - ld * quads) << 2;
+            put_quad(img + (size_t)(band_lo + ld) * S + x, ld * SP + x, 1);
+        }
+    } else if (axis) {  // thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
         for (int i = tid; i < nld * S; i += BAND_THREADS) {
             const int ld = i / S, x = i - ld * S;
             const size_t g = img + (size_t)(band_lo + ld) * S + x;
@@ -1065,34 +1099,8 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
             }
             put(ld * SP + x, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
         }
-    } else if (nld == 4 && (S & 3) == 0) {  // 4 adjacent columns: one 16-byte load per (row, field)
-        for (int y = tid; y < S; y += BAND_THREADS) {
-            const size_t g = img + (size_t)y * S + band_lo;
-            const int4 vf = *reinterpret_cast<const int4 *>(fi_map + g);
-            float4 va = make_float4(0, 0, 0, 0), vg = va;
-            if (ALPHA) {
-                va = *reinterpret_cast<const float4 *>(alpha_map + g);
-                vg = *reinterpret_cast<const float4 *>(g_alpha + g);
-            }
-            float rr[12], qq[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) rr[k] = qq[k] = 0.0f;
-            if (RGB) {
-                const float4 *pr = reinterpret_cast<const float4 *>(rgb_map + 3 * g);
-                const float4 *pg = reinterpret_cast<const float4 *>(g_rgb + 3 * g);
-                const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], q0 = pg[0], q1 = pg[1], q2 = pg[2];
-                rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
-                rr[8] = r2.x; rr[9] = r2.y; rr[10] = r2.z; rr[11] = r2.w;
-                qq[0] = q0.x; qq[1] = q0.y; qq[2] = q0.z; qq[3] = q0.w; qq[4] = q1.x; qq[5] = q1.y; qq[6] = q1.z; qq[7] = q1.w;
-                qq[8] = q2.x; qq[9] = q2.y; qq[10] = q2.z; qq[11] = q2.w;
-            }
-            const int fis[4] = {vf.x, vf.y, vf.z, vf.w};
-            const float als[4] = {va.x, va.y, va.z, va.w}, gas[4] = {vg.x, vg.y, vg.z, vg.w};
-#pragma unroll
-            for (int ld = 0; ld < 4; ++ld)
-                put(ld * SP + y, fis[ld], als[ld], gas[ld], rr[3 * ld], rr[3 * ld + 1], rr[3 * ld + 2], qq[3 * ld],
-                    qq[3 * ld + 1], qq[3 * ld + 2]);
-        }
+    } else if (nld == 4 && (S & 3) == 0) {  // 4 adjacent columns: one thread per row
+        for (int y = tid; y < S; y += BAND_THREADS) put_quad(img + (size_t)y * S + band_lo, y, SP);
     } else {  // generic columns: thread -> (row d1, line ld) with ld fastest
         for (int i = tid; i < nld * S; i += BAND_THREADS) {
             const int d1 = i / nld, ld = i - d1 * nld;

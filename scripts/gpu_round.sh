@@ -12,13 +12,14 @@ for f in tests/test_hip_parity.py tests/test_fuzz_gpu.py tests/test_full_size_gp
          tests/test_sharding_gpu.py tests/test_frontend_gpu.py tests/test_texture_io.py tests/test_optimizer.py \
          tests/test_examples_gpu.py tests/test_bench_contract.py tests/test_multi_rank_gpu.py tests/test_abi.py; do
   echo "=== $f" >> $OUT/pytest.log
-  timeout ${TEST_TIMEOUT:-600} python -m pytest $f -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -${TAIL:-40} >> $OUT/pytest.log
+  timeout ${TEST_TIMEOUT:-600} python -m pytest $f -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -${TAIL:-200} >> $OUT/pytest.log
 done
-cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
+cp gpurun_out/parity_errors.jsonl gpurun_out/two_ranks_one_gpu*.log $OUT/ 2>/dev/null
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 TAG=default timeout 300 python scripts/stage_times.py > $OUT/stages.log 2>&1
 NR_STAGE_FLAGS=2 TAG=exact timeout 300 python scripts/stage_times.py >> $OUT/stages.log 2>&1
+NR_STAGE_FLAGS=8 TAG=scan_path timeout 300 python scripts/stage_times.py >> $OUT/stages.log 2>&1
 timeout 300 python scripts/k6_modes.py >> $OUT/stages.log 2>&1
 timeout 900 python scripts/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -38,7 +38,7 @@ def test_bench_json_line():
     w = r['whole_step']
     assert w['algorithmic_bytes'] == 92 * 4 * 256 * 256 + (108 + 24 * 8) * 4 * d['config']['num_faces']
     assert r['traffic'] is None and 'traffic_from_profiles' in r
-    assert len(d['extra_rows']) == 2 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
+    assert len(d['extra_rows']) == 3 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
     assert d['renderer_end_to_end']['frontend'] == 'fused'
 
 
