@@ -34,7 +34,8 @@ namespace {
 // scans faces in ascending order with a strict `<`, rasterize.py:300,334): zp > near > 0, so the float bit
 // pattern is order-preserving as an unsigned integer.  The result does not depend on the order of the
 // atomics: face_index_map is bit-reproducible.
-constexpr int SMALL_AREA = 256;
+constexpr int SMALL_AREA = 64;    // boxes up to this many pixels: rasterized on the spot by the face's LPF lanes
+constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (k_wave_raster); beyond, and strips: one workgroup (k_large_raster)
 constexpr unsigned long long ZEMPTY = ~0ull;
 
 struct FaceGeo {
@@ -112,7 +113,8 @@ constexpr int LPF = 4;
 
 __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces,
                                                      unsigned long long *__restrict__ zbuf,
-                                                     int *__restrict__ large_list, int *__restrict__ n_large,
+                                                     int *__restrict__ large_list, int *__restrict__ wave_list,
+                                                     int *__restrict__ n_large,
                                                      unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
                                                      int S, double near_d, double far_d)
 {
@@ -123,8 +125,13 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     const float *f = faces + (size_t)i * 9;
     const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
     if (cd.n == 0) return;  // back faces, off-screen faces, coincident vertices
-    if (cd.strip || cd.n > SMALL_AREA) {  // strips (needles) and large boxes: a whole workgroup each, k_large_raster
-        if (sub == 0) large_list[atomicAdd(n_large, 1) + 1] = i;  // the counter starts at -1 (one fill with the z-buffer)
+    if (cd.strip || cd.n > SMALL_AREA) {
+        // medium boxes: a wave each (k_wave_raster); strips (needles) and large boxes: a whole workgroup each (k_large_raster).
+        // Both counters start at -1 (one fill with the z-buffer).
+        if (sub == 0) {
+            if (!cd.strip && cd.n <= WAVE_AREA) wave_list[atomicAdd(n_large + 1, 1) + 1] = i;
+            else large_list[atomicAdd(n_large, 1) + 1] = i;
+        }
         return;
     }
     FaceGeo g;
@@ -144,9 +151,40 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     }
 }
 
+// Faces whose box is too large for LPF lanes and too small for a workgroup (a mesh of spiky or close-up triangles: config 4
+// queued 1/5 of its faces for k_large_raster, 256 threads on a 300-pixel box): one wave per face, lanes stride over the box.
+__device__ __forceinline__ void wave_raster(const float *__restrict__ faces, unsigned long long *__restrict__ zbuf,
+                                            const int *__restrict__ wave_list, const int *__restrict__ n_wave, int F, int S,
+                                            double near_d, double far_d)
+{
+    const int n = *n_wave + 1;  // the counter starts at -1
+    const int lane = threadIdx.x & 63;
+    const int waves = gridDim.x * (blockDim.x >> 6);
+    const bool pow2 = (S & (S - 1)) == 0;
+    const float inv_s = 1.0f / (float)S;
+    for (int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < n; j += waves) {
+        const int i = wave_list[j];
+        const float *f = faces + (size_t)i * 9;
+        FaceGeo g;
+        float inv[9];
+        load_face_geo(f, S, g, inv);
+        const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
+        const int b = i / F;
+        const unsigned fnu = (unsigned)(i - b * F);
+        unsigned long long *zimg = zbuf + (size_t)b * S * S;
+        for (int k = lane; k < cd.n; k += 64) {
+            const int yy = k / cd.bw, x = cd.x_lo + (k - yy * cd.bw), y = cd.y_lo + yy;
+            raster_pixel(g, fnu, x, y, pixel_center_p(x, S, inv_s, pow2), pixel_center_p(y, S, inv_s, pow2), near_d, far_d,
+                         zimg + (size_t)y * S);
+        }
+    }
+}
+
+// The two queues share one launch: a workgroup first takes large faces (all 256 threads on one face), then its four waves
+// take medium ones.
 __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces,
                                                       unsigned long long *__restrict__ zbuf,
-                                                      const int *__restrict__ large_list,
+                                                      const int *__restrict__ large_list, const int *__restrict__ wave_list,
                                                       const int *__restrict__ n_large, int F, int S, double near_d,
                                                       double far_d)
 {
@@ -167,6 +205,7 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
             raster_pixel(g, fnu, x, y, pixel_center_f(x, S), pixel_center_f(y, S), near_d, far_d, zimg + (size_t)y * S);
         }
     }
+    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -327,7 +366,7 @@ FwdLayout fwd_layout(int B, int F, int S)
     L.zbuf_off = 0;
     L.count_off = L.zbuf_off + P * sizeof(unsigned long long);  // the counter sits right behind the z-buffer
     L.list_off = align_up(L.count_off + sizeof(long long), 256);
-    L.total = L.list_off + n * sizeof(int);
+    L.total = L.list_off + 2 * n * sizeof(int);  // the queue of large faces, then the queue of medium ones
     return L;
 }
 }  // namespace
@@ -358,11 +397,12 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     // one fill: ZEMPTY words and, right behind them, the large-face counter at -1
     const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
     if (he != hipSuccess) return (int)he;
+    int *wave_list = large_list + n;
     hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
-                       n_large, visible_faces, (int)n, F, S, near, far);
-    // a few workgroups per CU loop over the queue (one per CU left the kernel latency-bound: config 4, 189 -> ~85 us);
-    // with an empty queue (any ordinary mesh) they read the counter and leave
-    hipLaunchKernelGGL(k_large_raster, dim3(1024), dim3(256), 0, st, faces, zbuf, large_list, n_large, F, S, near, far);
+                       wave_list, n_large, visible_faces, (int)n, F, S, near, far);
+    // a resident grid loops over the two queues; with empty queues (a fine mesh) its workgroups read two counters and leave
+    hipLaunchKernelGGL(k_large_raster, dim3(2048), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
+                       far);
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, zbuf, face_index_map,
                        weight_map, depth_map, face_inv_map, visible_faces, F, S, near, far, P,
                        faces_z_ref ? faces_z_ref : faces, textures, rgb_map, background, bg_per_batch, alpha_map, ts, eps,
