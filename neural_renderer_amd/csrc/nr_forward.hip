@@ -34,7 +34,8 @@ namespace {
 // scans faces in ascending order with a strict `<`, rasterize.py:300,334): zp > near > 0, so the float bit
 // pattern is order-preserving as an unsigned integer.  The result does not depend on the order of the
 // atomics: face_index_map is bit-reproducible.
-constexpr int SMALL_AREA = 64;    // boxes up to this many pixels: rasterized on the spot by the face's LPF lanes
+constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized on the spot by the face's LPF lanes (a queue
+                                  // entry costs a device-wide same-address atomic: 64 here made the headline forward 2.2x slower)
 constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (k_wave_raster); beyond, and strips: one workgroup (k_large_raster)
 constexpr unsigned long long ZEMPTY = ~0ull;
 
@@ -120,20 +121,36 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = t / LPF, sub = t - i * LPF;
-    if (i >= n_faces_total) return;
-    if (visible_faces && sub == 0) visible_faces[i] = 0;  // k_resolve raises the flags of the faces that win a pixel
-    const float *f = faces + (size_t)i * 9;
-    const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-    if (cd.n == 0) return;  // back faces, off-screen faces, coincident vertices
-    if (cd.strip || cd.n > SMALL_AREA) {
-        // medium boxes: a wave each (k_wave_raster); strips (needles) and large boxes: a whole workgroup each (k_large_raster).
-        // Both counters start at -1 (one fill with the z-buffer).
-        if (sub == 0) {
-            if (!cd.strip && cd.n <= WAVE_AREA) wave_list[atomicAdd(n_large + 1, 1) + 1] = i;
-            else large_list[atomicAdd(n_large, 1) + 1] = i;
+    const bool live = i < n_faces_total;
+    if (live && visible_faces && sub == 0) visible_faces[i] = 0;  // k_resolve raises the flags of the faces that win a pixel
+    const float *f = faces + (size_t)(live ? i : 0) * 9;
+    Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+    if (!live) cd.n = 0;
+    // Boxes too large for LPF lanes are queued: medium ones for a wave each, strips (needles) and large ones for a whole
+    // workgroup each (k_large_raster).  One atomic per wave and queue (a same-address atomic per face from all over the chip
+    // serialises at the memory side); both counters start at -1 (one fill with the z-buffer).
+    const bool queued = cd.n > 0 && (cd.strip || cd.n > SMALL_AREA);
+    const bool to_wave = queued && sub == 0 && !cd.strip && cd.n <= WAVE_AREA;
+    const bool to_large = queued && sub == 0 && !to_wave;
+    {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long mw = __ballot(to_wave), ml = __ballot(to_large);
+        if (mw) {
+            const int leader = __ffsll((long long)mw) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(n_large + 1, __popcll(mw)) + 1;
+            base = __shfl(base, leader, WAVE);
+            if (to_wave) wave_list[base + __popcll(mw & ((1ull << lane) - 1ull))] = i;
         }
-        return;
+        if (ml) {
+            const int leader = __ffsll((long long)ml) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(n_large, __popcll(ml)) + 1;
+            base = __shfl(base, leader, WAVE);
+            if (to_large) large_list[base + __popcll(ml & ((1ull << lane) - 1ull))] = i;
+        }
     }
+    if (cd.n == 0 || queued) return;  // back faces, off-screen faces, coincident vertices; queued faces
     FaceGeo g;
     float inv[9];
     load_face_geo(f, S, g, inv);
