@@ -34,8 +34,8 @@ namespace {
 // scans faces in ascending order with a strict `<`, rasterize.py:300,334): zp > near > 0, so the float bit
 // pattern is order-preserving as an unsigned integer.  The result does not depend on the order of the
 // atomics: face_index_map is bit-reproducible.
-constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized on the spot by the face's LPF lanes (a queue
-                                  // entry costs a device-wide same-address atomic: 64 here made the headline forward 2.2x slower)
+constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized on the spot by the face's LPF lanes (measured with
+                                  // the wave tier behind it: 128 / 64 make config 4 15 % / 28 % slower, the headline +0 / +11 %)
 constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (k_wave_raster); beyond, and strips: one workgroup (k_large_raster)
 constexpr unsigned long long ZEMPTY = ~0ull;
 
