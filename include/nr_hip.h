@@ -56,7 +56,7 @@ extern "C" {
 
 /* argument errors */
 #define NR_E_NULL (-1)      /* a required pointer is NULL */
-#define NR_E_SIZE (-2)      /* a size is out of range (B,F,S < 1, S > 16384, ts < 2, index overflow) */
+#define NR_E_SIZE (-2)      /* a size is out of range (B,F,S < 1, B > 65535, S > 16384, ts < 2, index overflow) */
 #define NR_E_WORKSPACE (-3) /* workspace missing or too small */
 #define NR_E_MODE (-4)      /* nothing to do / inconsistent optional arguments */
 #define NR_E_NEAR (-5)      /* near <= 0: the z-buffer packs positive depths (reference default 0.1; the reference itself accepts

@@ -224,7 +224,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 inline int check_sizes(int B, int F, int S)
 {
-    if (B < 1 || F < 1 || S < 1 || S > 16384) return NR_E_SIZE;
+    if (B < 1 || B > 65535 || F < 1 || S < 1 || S > 16384) return NR_E_SIZE;  // B: several kernels put the image on grid.y
     if ((size_t)B * (size_t)F > 0x7fffffffull / 9) return NR_E_SIZE;  // int32 face indexing inside kernels
     return 0;
 }
