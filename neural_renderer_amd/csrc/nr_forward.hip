@@ -43,15 +43,20 @@ struct FaceGeo {
     float x0, y0, z0, x1, y1, z1, x2, y2, z2, i0, i1, i2, i3, i4, i5, i6, i7, i8;
 };
 
-// One (face, pixel) evaluation of the reference's K2 body.  Returns false when the pixel is rejected.
-__device__ __forceinline__ bool eval_pixel(const FaceGeo &q, float xp, float yp, float xif, float yif, double near_d,
-                                           double far_d, float &zp, float &w0, float &w1, float &w2)
+// The reference's K2 body in two parts, so that a raster loop can run the cheap half-plane tests over the pixels of a box and
+// spend the expensive part (seven IEEE divisions) only on pixels inside the triangle -- with all lanes that found one.
+// rasterize.py:310-312 (back faces never reach here: their box is empty)
+__device__ __forceinline__ bool inside_edges(const FaceGeo &q, float xp, float yp)
 {
-    // rasterize.py:310-312 (back faces never reach here: their box is empty)
-    if (((yp - q.y0) * (q.x1 - q.x0) < (xp - q.x0) * (q.y1 - q.y0)) ||
-        ((yp - q.y1) * (q.x2 - q.x1) < (xp - q.x1) * (q.y2 - q.y1)) ||
-        ((yp - q.y2) * (q.x0 - q.x2) < (xp - q.x2) * (q.y0 - q.y2)))
-        return false;
+    return !(((yp - q.y0) * (q.x1 - q.x0) < (xp - q.x0) * (q.y1 - q.y0)) ||
+             ((yp - q.y1) * (q.x2 - q.x1) < (xp - q.x1) * (q.y2 - q.y1)) ||
+             ((yp - q.y2) * (q.x0 - q.x2) < (xp - q.x2) * (q.y0 - q.y2)));
+}
+
+// weights and depth of a pixel inside the triangle; false when the depth test rejects it
+__device__ __forceinline__ bool eval_inside(const FaceGeo &q, float xif, float yif, double near_d, double far_d, float &zp,
+                                            float &w0, float &w1, float &w2)
+{
     // :317-327
     w0 = q.i0 * xif + q.i1 * yif + q.i2;
     w1 = q.i3 * xif + q.i4 * yif + q.i5;
@@ -69,6 +74,13 @@ __device__ __forceinline__ bool eval_pixel(const FaceGeo &q, float xp, float yp,
     // :334 `zp < depth_min` with depth_min starting at (float)far: implied by :331 for ordinary numbers, but a NaN zp (NaN /
     // Inf vertices, zero depth) passes :331 and must never win a pixel
     return zp < (float)far_d;
+}
+
+// One (face, pixel) evaluation.  Returns false when the pixel is rejected.
+__device__ __forceinline__ bool eval_pixel(const FaceGeo &q, float xp, float yp, float xif, float yif, double near_d,
+                                           double far_d, float &zp, float &w0, float &w1, float &w2)
+{
+    return inside_edges(q, xp, yp) && eval_inside(q, xif, yif, near_d, far_d, zp, w0, w1, w2);
 }
 
 // pixel centre (2. * i + 1 - is) / is (rasterize.py:291-292, evaluated in double there).  Both operands are
@@ -106,12 +118,105 @@ __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S
     g.i6 = inv[6]; g.i7 = inv[7]; g.i8 = inv[8];
 }
 
-// LPF lanes share one face (they split the rows of its box): 4x more waves than a thread-per-face launch,
-// each with 4x shorter serial loops.  The kernel is bound by the dependent-instruction latency of the IEEE
-// divisions in the K2 body (measured: 13 cycles per VALU instruction at 1.2 waves/SIMD), which more resident
-// waves hide.
-constexpr int LPF = 4;
+// --------------------------------------------------------------------------------------------------
+// k_face_raster: one lane per face for the per-face work, then the *wave* re-distributes the work of its 64 faces twice so that
+// the expensive part runs with full lanes (a thread-per-face or 4-lanes-per-face loop over the box pays the seven IEEE divisions
+// of the K2 body max-over-lanes of the box sizes with ~30 % of the lanes active: half of the faces are culled, boxes differ, and
+// half of a box lies outside its triangle):
+//   1. lane = face: cull, screen box, inverse matrix; faces with a small box ("kept") put their constants into the wave's LDS;
+//   2. lane = (kept face, row of its box): the inside pixels of a row are one interval (each half-plane test is monotonic in xp
+//      for a fixed yp, rounding included) -- found with the reference's tests alone (:310-312), a few cheap steps per lane;
+//   3. lane = inside pixel: weights, depth, depth test, 64-bit atomicMin.
+// Rows and pixels are handed over through small LDS lists, written by their producers at wave-prefix positions, a window of
+// the list at a time (any box shape fits).  The waves of a workgroup are independent: no barrier, only wave-scope fences.
+#ifndef FR_ROWS
+#define FR_ROWS 128  // row items per window
+#endif
+#ifndef FR_PIX
+#define FR_PIX 256  // pixel items per window (7.4 KB of LDS per wave: five workgroups per CU)
+#endif
+#ifndef FR_GROUP
+#define FR_GROUP 16  // consecutive faces per lane group (power of two <= 64), see the face -> lane mapping below
+#endif
+#ifdef NR_FWD_NO_ATOMIC  // development: what the z-buffer atomics cost (results are wrong)
+#define FR_PUBLISH(at, key) do { if ((key) == 12345ull) *(at) = (key); } while (0)
+#else
+#define FR_PUBLISH(at, key) atomicMin(at, key)
+#endif
+#ifndef FR_SEARCH4
+#define FR_SEARCH4 1
+#endif
+#ifndef FR_EVAL2
+#define FR_EVAL2 0  // two pixels per lane and step: measured neutral (84.7 vs 85.1 us), more code
+#endif
+static_assert(SMALL_AREA <= 256, "rows and columns of a kept box are packed into 8 bits each");
 
+struct FaceWaveLds {
+    float g[18][64];  // x0 y0 x1 y1 x2 y2 | z0 z1 z2 | inv[9], component-major: lanes with different faces hit different banks
+    int x_lo[64], y_lo[64], bw[64], img[64], fn[64];
+    int rows[FR_ROWS];
+    int pix[FR_PIX];
+};
+
+// inclusive prefix sum over the 64 lanes with DPP moves only (no LDS crossbar round trips): Hillis-Steele inside each row of 16
+// lanes, then the row totals are passed on (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+}
+
+// LDS hand-over between the lanes of one wave: the wave's LDS operations execute in order; the fence keeps the compiler from
+// moving accesses across and waits for the writes
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// pixel item (slot << 16 | row << 8 | column) -> z-buffer word and key; false when the depth test rejects the pixel
+__device__ __forceinline__ bool slot_pixel(const FaceWaveLds &L, int e, int S, double near_d, double far_d,
+                                           unsigned long long *__restrict__ zbuf, unsigned long long &key,
+                                           unsigned long long *&at)
+{
+    const int s = e >> 16;
+    FaceGeo q;
+    q.z0 = L.g[6][s]; q.z1 = L.g[7][s]; q.z2 = L.g[8][s];
+    q.i0 = L.g[9][s]; q.i1 = L.g[10][s]; q.i2 = L.g[11][s]; q.i3 = L.g[12][s]; q.i4 = L.g[13][s];
+    q.i5 = L.g[14][s]; q.i6 = L.g[15][s]; q.i7 = L.g[16][s]; q.i8 = L.g[17][s];
+    const int x = L.x_lo[s] + (e & 255), y = L.y_lo[s] + ((e >> 8) & 255);
+    float zp, w0, w1, w2;
+    const bool ok = eval_inside(q, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2);
+    key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)L.fn[s];
+    at = zbuf + ((size_t)L.img[s] * S + y) * S + x;
+    return ok;
+}
+
+#ifdef NR_FWD_PHASES  // development build: cycles per phase of k_face_raster summed over waves (scripts/fwd_phases.py)
+__device__ unsigned long long g_fwd_phase[8];
+#define FWD_PH_BEGIN() unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_t = clock64(), ph_w = wall_clock64()
+#define FWD_PH(k) do { const unsigned long long ph_n = clock64(); ph_acc[k] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#define FWD_PH_END()                                                                                  \
+    do {                                                                                              \
+        if (lane == 0) {                                                                              \
+            for (int k = 0; k < 6; k++) atomicAdd(&g_fwd_phase[k], ph_acc[k]);                        \
+            atomicAdd(&g_fwd_phase[6], wall_clock64() - ph_w);                                        \
+            atomicAdd(&g_fwd_phase[7], 1ull);                                                         \
+        }                                                                                             \
+    } while (0)
+#else
+#define FWD_PH_BEGIN()
+#define FWD_PH(k)
+#define FWD_PH_END()
+#endif
+
+template <bool POW2>
 __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces,
                                                      unsigned long long *__restrict__ zbuf,
                                                      int *__restrict__ large_list, int *__restrict__ wave_list,
@@ -119,21 +224,45 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                                                      unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
                                                      int S, double near_d, double far_d)
 {
+    __shared__ FaceWaveLds lds[4];
+    FaceWaveLds &L = lds[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    FWD_PH_BEGIN();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = t / LPF, sub = t - i * LPF;
-    const bool live = i < n_faces_total;
-    if (live && visible_faces && sub == 0) visible_faces[i] = 0;  // k_resolve raises the flags of the faces that win a pixel
-    const float *f = faces + (size_t)(live ? i : 0) * 9;
+    if (t < n_faces_total && visible_faces) visible_faces[t] = 0;  // k_resolve raises the flags of the faces that win a pixel
+    // A wave takes 64 / FR_GROUP groups of FR_GROUP consecutive faces, the groups W apart (W = number of waves): faces that are
+    // neighbours in the mesh are neighbours on screen and of similar size, and a wave of 64 consecutive large ones has ten
+    // times the average work -- the kernel then waits for a few waves (teapot view: 2566 inside pixels in the heaviest wave
+    // against a mean of 233; fully interleaved: 280).
+    const int n_waves = (n_faces_total + 63) >> 6;
+    const int i = ((lane / FR_GROUP) * n_waves + (t >> 6)) * FR_GROUP + (lane % FR_GROUP);
+    const bool live = (t >> 6) < n_waves && i < n_faces_total;
+    // the wave's faces: 64 / FR_GROUP runs of FR_GROUP * 9 floats, fetched with consecutive lanes on consecutive words (a lane
+    // fetching its own 36 bytes makes 64 requests per load instruction) and handed to their lanes through LDS
+    float f[9];
+    {
+        float *stage = &L.g[0][0];  // 576 of its 1152 floats; the slot constants move in after the hand-over
+        const size_t n_words = (size_t)n_faces_total * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int d = k * 64 + lane, run = d / (9 * FR_GROUP), off = d - run * (9 * FR_GROUP);
+            const size_t src = ((size_t)run * n_waves + (t >> 6)) * (9 * FR_GROUP) + off;
+            stage[d] = src < n_words ? faces[src] : 0.0f;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 9; k++) f[k] = stage[lane * 9 + k];
+        wave_lds_sync();
+    }
     Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
     if (!live) cd.n = 0;
-    // Boxes too large for LPF lanes are queued: medium ones for a wave each, strips (needles) and large ones for a whole
+    // Boxes too large for this kernel are queued: medium ones for a wave each, strips (needles) and large ones for a whole
     // workgroup each (k_large_raster).  One atomic per wave and queue (a same-address atomic per face from all over the chip
     // serialises at the memory side); both counters start at -1 (one fill with the z-buffer).
     const bool queued = cd.n > 0 && (cd.strip || cd.n > SMALL_AREA);
-    const bool to_wave = queued && sub == 0 && !cd.strip && cd.n <= WAVE_AREA;
-    const bool to_large = queued && sub == 0 && !to_wave;
+    const bool to_wave = queued && !cd.strip && cd.n <= WAVE_AREA;
+    const bool to_large = queued && !to_wave;
     {
-        const int lane = threadIdx.x & 63;
         const unsigned long long mw = __ballot(to_wave), ml = __ballot(to_large);
         if (mw) {
             const int leader = __ffsll((long long)mw) - 1;
@@ -150,22 +279,107 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
             if (to_large) large_list[base + __popcll(ml & ((1ull << lane) - 1ull))] = i;
         }
     }
-    if (cd.n == 0 || queued) return;  // back faces, off-screen faces, coincident vertices; queued faces
-    FaceGeo g;
-    float inv[9];
-    load_face_geo(f, S, g, inv);
-    const int b = i / F;
-    const unsigned fnu = (unsigned)(i - b * F);
-    unsigned long long *zimg = zbuf + (size_t)b * S * S;
-    const bool pow2 = (S & (S - 1)) == 0;
-    const float inv_s = 1.0f / (float)S;
-    const int x_hi = cd.x_lo + cd.bw - 1, y_hi = cd.y_lo + cd.n / cd.bw - 1;
-    for (int py = cd.y_lo + sub; py <= y_hi; py += LPF) {
-        const float yp = pixel_center_p(py, S, inv_s, pow2);
-        unsigned long long *zrow = zimg + (size_t)py * S;
-        for (int px = cd.x_lo; px <= x_hi; ++px)
-            raster_pixel(g, fnu, px, py, pixel_center_p(px, S, inv_s, pow2), yp, near_d, far_d, zrow);
+    // 1. kept faces -> slots (lane order), their constants -> LDS
+    const bool keep = cd.n > 0 && !queued;  // not: back faces, off-screen faces, coincident vertices; queued faces
+    const unsigned long long mk = __ballot(keep);
+    FWD_PH(0);
+    if (mk == 0) {
+        FWD_PH_END();
+        return;
     }
+    const int slot = __popcll(mk & ((1ull << lane) - 1ull));
+    const int bh = keep ? cd.n / cd.bw : 0;
+    if (keep) {
+        FaceGeo g;
+        float inv[9];
+        load_face_geo(f, S, g, inv);
+        L.g[0][slot] = g.x0; L.g[1][slot] = g.y0; L.g[2][slot] = g.x1; L.g[3][slot] = g.y1; L.g[4][slot] = g.x2; L.g[5][slot] = g.y2;
+        L.g[6][slot] = g.z0; L.g[7][slot] = g.z1; L.g[8][slot] = g.z2;
+#pragma unroll
+        for (int k = 0; k < 9; k++) L.g[9 + k][slot] = inv[k];
+        const int b = i / F;
+        L.x_lo[slot] = cd.x_lo; L.y_lo[slot] = cd.y_lo; L.bw[slot] = cd.bw; L.img[slot] = b; L.fn[slot] = i - b * F;
+    }
+    const int row_end = wave_inclusive_sum(bh), row0 = row_end - bh;
+    const int n_rows = __builtin_amdgcn_readlane(row_end, 63);
+    constexpr bool pow2 = POW2;  // (S & (S - 1)) == 0: pixel centres with one multiply, no division in the search loop
+    const float inv_s = 1.0f / (float)S;
+    FWD_PH(1);
+    for (int rbase = 0; rbase < n_rows; rbase += FR_ROWS) {
+        wave_lds_sync();  // (the previous window's readers are done)
+        for (int r = max(rbase - row0, 0), r_hi = min(rbase + FR_ROWS - row0, bh); r < r_hi; ++r)
+            L.rows[row0 + r - rbase] = (slot << 8) | r;
+        wave_lds_sync();
+        const int rows_here = min(FR_ROWS, n_rows - rbase);
+        FWD_PH(2);
+        for (int rp = 0; rp < rows_here; rp += 64) {
+            // 2. the inside interval [xa, xa + cnt) of this lane's row
+            int item = 0, xa = 0, cnt = 0;
+            if (rp + lane < rows_here) {
+                item = L.rows[rp + lane];
+                const int s = item >> 8;
+                FaceGeo q;
+                q.x0 = L.g[0][s]; q.y0 = L.g[1][s]; q.x1 = L.g[2][s]; q.y1 = L.g[3][s]; q.x2 = L.g[4][s]; q.y2 = L.g[5][s];
+                const int x_lo = L.x_lo[s], x_end = x_lo + L.bw[s];
+                const float yp = pixel_center_p(L.y_lo[s] + (item & 255), S, inv_s, pow2);
+#if FR_SEARCH4
+                // four pixels per step (independent tests overlap their latencies); the interval ends at the first outside
+                // pixel behind an inside one
+                bool started = false;
+                for (int px = x_lo; px < x_end; px += 4) {
+                    bool in[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        in[k] = inside_edges(q, pixel_center_p(px + k, S, inv_s, pow2), yp) && px + k < x_end;
+                    const int m = (int)in[0] | ((int)in[1] << 1) | ((int)in[2] << 2) | ((int)in[3] << 3);
+                    if (m && !started) {
+                        xa = px + __ffs(m) - 1;
+                        started = true;
+                    }
+                    cnt += __popc(m);
+                    if (started && !in[3]) break;
+                }
+#else
+                int px = x_lo;
+                while (px < x_end && !inside_edges(q, pixel_center_p(px, S, inv_s, pow2), yp)) ++px;
+                xa = px;
+                while (px < x_end && inside_edges(q, pixel_center_p(px, S, inv_s, pow2), yp)) ++px;
+                cnt = px - xa;
+#endif
+                xa -= x_lo;
+            }
+            FWD_PH(3);
+            const int pix_end = wave_inclusive_sum(cnt), pix0 = pix_end - cnt;
+            const int n_pix = __builtin_amdgcn_readlane(pix_end, 63);
+            for (int pbase = 0; pbase < n_pix; pbase += FR_PIX) {
+                wave_lds_sync();
+                for (int k = max(pbase - pix0, 0), k_hi = min(pbase + FR_PIX - pix0, cnt); k < k_hi; ++k)
+                    L.pix[pix0 + k - pbase] = (item << 8) | (xa + k);  // slot, row, column
+                wave_lds_sync();
+                FWD_PH(4);
+                // 3. one inside pixel per lane
+                const int pix_here = min(FR_PIX, n_pix - pbase);
+#if FR_EVAL2
+                // two pixels per lane and step: the two division chains overlap
+                for (int pp = lane; pp < pix_here; pp += 128) {
+                    const bool two = pp + 64 < pix_here;
+                    unsigned long long key0, key1, *at0, *at1;
+                    const bool ok0 = slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key0, at0);
+                    const bool ok1 = slot_pixel(L, L.pix[two ? pp + 64 : pp], S, near_d, far_d, zbuf, key1, at1);
+                    if (ok0) FR_PUBLISH(at0, key0);
+                    if (ok1 && two) FR_PUBLISH(at1, key1);
+                }
+#else
+                for (int pp = lane; pp < pix_here; pp += 64) {
+                    unsigned long long key, *at;
+                    if (slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key, at)) FR_PUBLISH(at, key);
+                }
+#endif
+                FWD_PH(5);
+            }
+        }
+    }
+    FWD_PH_END();
 }
 
 // Faces whose box is too large for LPF lanes and too small for a workgroup (a mesh of spiky or close-up triangles: config 4
@@ -415,7 +629,11 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
     if (he != hipSuccess) return (int)he;
     int *wave_list = large_list + n;
-    hipLaunchKernelGGL(k_face_raster, dim3((unsigned)((n * LPF + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
+    if ((S & (S - 1)) == 0)
+        hipLaunchKernelGGL(k_face_raster<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
+                       wave_list, n_large, visible_faces, (int)n, F, S, near, far);
+    else
+        hipLaunchKernelGGL(k_face_raster<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
                        wave_list, n_large, visible_faces, (int)n, F, S, near, far);
     // a resident grid loops over the two queues; with empty queues (a fine mesh) its workgroups read two counters and leave
     hipLaunchKernelGGL(k_large_raster, dim3(2048), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
@@ -475,3 +693,16 @@ NR_API int nr_forward_texture_sampling(const float *faces, const float *faces_z_
                        (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, n);
     return launch_status();
 }
+
+#ifdef NR_FWD_PHASES
+// development build only (not declared in include/nr_hip.h)
+NR_API int nr_debug_fwd_phases(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fwd_phase), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

@@ -70,78 +70,85 @@ def run(name, faces, textures, S, modes, eps, iters=10, graph=False):
 
 
 def main():
-    # headline scene, per mode, AA off (S 256) and AA on (S 512)
-    for S in (256, 512):
-        faces, textures = bench.build_scene(dev, 64, 0, 64, S, 2)
-        for name, modes, eps in (('H silhouette', (False, True, False), 1e-4), ('H rgb', (True, False, False), 1e-3),
-                                 ('H depth', (False, False, True), 1e-4), ('H rgb+alpha+depth', (True, True, True), 1e-3)):
-            run('%s S%d' % (name, S), faces, textures, S, modes, eps)
-    # config 2: 16 azimuth views, RGB + depth + silhouette
-    faces, textures = bench.build_scene(dev, 16, 0, 16, 256, 2)
-    run('C2 teapot 16 views', faces, textures, 256, (True, True, True), 1e-3, iters=30, graph=True)
-    # config 3: example2, teapot -> rectangle silhouette loss through the public Renderer (256x256, anti-aliasing on), 300 Adam steps
-    sys.path.insert(0, os.path.join(ROOT, 'examples'))
-    import make_data
-    import example2
-    make_data.main()
-    data = os.path.join(ROOT, 'examples', 'data')
-    model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    losses = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(300):
-        opt.zero_grad()
-        loss = model()
-        loss.backward()
-        opt.step()
-        losses.append(loss.detach())
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 300 * 1e3
-    print(json.dumps({'config': 'C3 example2 vertex optimisation, 300 Adam steps', 'B': 1, 'S': 512, 'ms_per_step': round(ms, 4),
-                      'loss_first': round(float(losses[0]), 2), 'loss_last': round(float(losses[-1]), 2)}), flush=True)
-    # the same loop with the whole step (render, loss, backward, Adam) captured once in a HIP graph
-    model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
-    loss_buf = torch.zeros((), device=dev)
-
-    def train_step():
-        opt.zero_grad(set_to_none=False)
-        loss = model()
-        loss.backward()
-        opt.step()
-        loss_buf.copy_(loss.detach())
-
-    replay = nr.graph.capture(train_step, dev, warmup=3)  # 3 warm-up + 1 captured step are real Adam steps
-    first = float(loss_buf)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(296):
-        replay()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 296 * 1e3
-    print(json.dumps({'config': 'C3 example2, whole step replayed from a HIP graph (Adam capturable)', 'B': 1, 'S': 512,
-                      'ms_per_step': round(ms, 4), 'loss_after_4_steps': round(first, 2),
-                      'loss_last': round(float(loss_buf), 2)}), flush=True)
-    # config 4 (per-GPU share): 64 distinct ~5k-face meshes (10 240 with fill_back), ts 4 random textures, 256x256 RGB
-    from test_hip_parity import icosphere, project_mesh
+    only = [k for k in os.environ.get('ONLY', '').split(',') if k]  # e.g. ONLY=C2,C4
     rng = np.random.default_rng(1234)
-    v0, f0 = icosphere(4)
-    batch = []
-    for _ in range(64):
-        v = v0 * (0.55 + 0.12 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
-        q = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
-        batch.append(project_mesh((v @ q).astype(np.float32), f0, [0.3, 0.4, -2.6]))
-    faces = torch.from_numpy(np.stack(batch)).to(dev)
-    textures = torch.rand((64, faces.shape[1], 4, 4, 4, 3), device=dev)
-    run('C4 64 random meshes x 10240 faces ts4', faces, textures, 256, (True, False, False), 1e-3)
-    del faces, textures
-    # config 5: one 327 680-face icosphere (655 360 with fill_back), 1024x1024, ts 8
-    v0, f0 = icosphere(7)
-    v = v0 * (0.6 + 0.02 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
-    faces = torch.from_numpy(project_mesh(v.astype(np.float32), f0, [0.0, 0.0, -2.4])[None]).to(dev)
-    textures = torch.rand((1, faces.shape[1], 8, 8, 8, 3), device=dev)
-    run('C5 655k-face mesh 1024x1024 ts8', faces, textures, 1024, (True, True, True), 1e-3, iters=5)
+    if not only or 'H' in only:
+        # headline scene, per mode, AA off (S 256) and AA on (S 512)
+        for S in (256, 512):
+            faces, textures = bench.build_scene(dev, 64, 0, 64, S, 2)
+            for name, modes, eps in (('H silhouette', (False, True, False), 1e-4), ('H rgb', (True, False, False), 1e-3),
+                                     ('H depth', (False, False, True), 1e-4), ('H rgb+alpha+depth', (True, True, True), 1e-3)):
+                run('%s S%d' % (name, S), faces, textures, S, modes, eps)
+    if not only or 'C2' in only:
+        # config 2: 16 azimuth views, RGB + depth + silhouette
+        faces, textures = bench.build_scene(dev, 16, 0, 16, 256, 2)
+        run('C2 teapot 16 views', faces, textures, 256, (True, True, True), 1e-3, iters=30, graph=True)
+    if not only or 'C3' in only:
+        # config 3: example2, teapot -> rectangle silhouette loss through the public Renderer (256x256, anti-aliasing on), 300 Adam steps
+        sys.path.insert(0, os.path.join(ROOT, 'examples'))
+        import make_data
+        import example2
+        make_data.main()
+        data = os.path.join(ROOT, 'examples', 'data')
+        model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            opt.zero_grad()
+            loss = model()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 300 * 1e3
+        print(json.dumps({'config': 'C3 example2 vertex optimisation, 300 Adam steps', 'B': 1, 'S': 512, 'ms_per_step': round(ms, 4),
+                          'loss_first': round(float(losses[0]), 2), 'loss_last': round(float(losses[-1]), 2)}), flush=True)
+        # the same loop with the whole step (render, loss, backward, Adam) captured once in a HIP graph
+        model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        loss_buf = torch.zeros((), device=dev)
+
+        def train_step():
+            opt.zero_grad(set_to_none=False)
+            loss = model()
+            loss.backward()
+            opt.step()
+            loss_buf.copy_(loss.detach())
+
+        replay = nr.graph.capture(train_step, dev, warmup=3)  # 3 warm-up + 1 captured step are real Adam steps
+        first = float(loss_buf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(296):
+            replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 296 * 1e3
+        print(json.dumps({'config': 'C3 example2, whole step replayed from a HIP graph (Adam capturable)', 'B': 1, 'S': 512,
+                          'ms_per_step': round(ms, 4), 'loss_after_4_steps': round(first, 2),
+                          'loss_last': round(float(loss_buf), 2)}), flush=True)
+    from test_hip_parity import icosphere, project_mesh
+    if not only or 'C4' in only or 'C5' in only:  # (C5's mesh continues C4's random stream: same scenes whatever is selected)
+        # config 4 (per-GPU share): 64 distinct ~5k-face meshes (10 240 with fill_back), ts 4 random textures, 256x256 RGB
+        v0, f0 = icosphere(4)
+        batch = []
+        for _ in range(64):
+            v = v0 * (0.55 + 0.12 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+            q = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+            batch.append(project_mesh((v @ q).astype(np.float32), f0, [0.3, 0.4, -2.6]))
+    if not only or 'C4' in only:
+        faces = torch.from_numpy(np.stack(batch)).to(dev)
+        textures = torch.rand((64, faces.shape[1], 4, 4, 4, 3), device=dev)
+        run('C4 64 random meshes x 10240 faces ts4', faces, textures, 256, (True, False, False), 1e-3)
+        del faces, textures
+    if not only or 'C5' in only:
+        # config 5: one 327 680-face icosphere (655 360 with fill_back), 1024x1024, ts 8
+        v0, f0 = icosphere(7)
+        v = v0 * (0.6 + 0.02 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+        faces = torch.from_numpy(project_mesh(v.astype(np.float32), f0, [0.0, 0.0, -2.4])[None]).to(dev)
+        textures = torch.rand((1, faces.shape[1], 8, 8, 8, 3), device=dev)
+        run('C5 655k-face mesh 1024x1024 ts8', faces, textures, 1024, (True, True, True), 1e-3, iters=5)
 
 
 if __name__ == '__main__':
