@@ -2,7 +2,7 @@
 //
 //   k_face_raster   F1+F2  per face: back-face cull, inverse matrix, screen box (ref K1, :240-277) and
 //                          rasterization of the face's pixels into a packed 64-bit z-buffer (ref K2, :279-359)
-//   k_large_raster  F2'    faces with a large screen box, one workgroup per face
+//   k_large_raster  F2'    faces with a large screen box: one wave or one workgroup per face
 //   k_resolve       F2''   per pixel: decode the winner, write face_index / weight / depth / face_inv maps
 //   k_shade         F3  per pixel: trilinear texture sampling + background + alpha        (ref K4+K5, :361-465)
 #include "nr_device.h"
@@ -19,12 +19,13 @@ namespace {
 // faces in a few tiles (185 candidate faces over one 16x4 pixel block) and every candidate costs a
 // wave-wide test; a tile-local face-parallel variant still left 4/5 of the chip idle (only ~18 of 64
 // tiles per view contain geometry).  Faces, not pixels, are the balanced unit of work of a fine mesh:
-//   k_face_raster    one thread per face: back-face cull, inverse matrix, screen box (K1); small boxes
-//                    (<= SMALL_AREA pixels, i.e. practically every face of a mesh) are rasterized on the spot:
-//                    the thread walks the box, evaluates the reference's inside / barycentric / depth test
-//                    (K2 body) and publishes (depth bits << 32 | face index) with a 64-bit atomicMin on the
-//                    pixel's z-buffer word; faces with a large box are queued;
-//   k_large_raster   queued faces are rasterized by a whole workgroup each (threads stride over the box);
+//   k_face_raster    a wave takes 64 faces: back-face cull, inverse matrix, screen box (K1) one face per lane; the faces with
+//                    a small box (<= SMALL_AREA pixels, i.e. practically every face of a mesh) are then rasterized by the
+//                    wave together -- their rows, then their inside pixels are dealt to the lanes (see the kernel) -- each
+//                    inside pixel evaluating the reference's barycentric / depth test (K2 body) and publishing
+//                    (depth bits << 32 | face index) with a 64-bit atomicMin on the pixel's z-buffer word; faces with a
+//                    larger box are queued;
+//   k_large_raster   queued faces: a wave each up to WAVE_AREA pixels, a whole workgroup beyond (and for needle strips);
 //   k_resolve        one thread per pixel decodes the winner, re-evaluates its inverse matrix and weights (same
 //                    functions, same inputs -> same bits: the per-face inverses are never stored, which saves
 //                    36 B per face written + 36 B per covered pixel re-read) and writes face_index / weight / depth /
@@ -34,9 +35,9 @@ namespace {
 // scans faces in ascending order with a strict `<`, rasterize.py:300,334): zp > near > 0, so the float bit
 // pattern is order-preserving as an unsigned integer.  The result does not depend on the order of the
 // atomics: face_index_map is bit-reproducible.
-constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized on the spot by the face's LPF lanes (measured with
-                                  // the wave tier behind it: 128 / 64 make config 4 15 % / 28 % slower, the headline +0 / +11 %)
-constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (k_wave_raster); beyond, and strips: one workgroup (k_large_raster)
+constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized by k_face_raster (measured with the round-2 form of
+                                  // the kernel: 128 / 64 make config 4 15 % / 28 % slower, the headline +0 / +11 %)
+constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (wave_raster); beyond, and strips: one workgroup (k_large_raster)
 constexpr unsigned long long ZEMPTY = ~0ull;
 
 struct FaceGeo {
@@ -93,14 +94,6 @@ __device__ __forceinline__ float pixel_center_p(int i, int S, float inv_s, bool 
     return pow2 ? (float)(2 * i + 1 - S) * inv_s : (float)(2 * i + 1 - S) / (float)S;
 }
 
-__device__ __forceinline__ void raster_pixel(const FaceGeo &g, unsigned fnu, int px, int py, float xp, float yp,
-                                             double near_d, double far_d, unsigned long long *__restrict__ zrow)
-{
-    float zp, w0, w1, w2;
-    if (eval_pixel(g, xp, yp, (float)px, (float)py, near_d, far_d, zp, w0, w1, w2))
-        atomicMin(zrow + px, ((unsigned long long)__float_as_uint(zp) << 32) | fnu);
-}
-
 // vertices -> FaceGeo with the inverse barycentric matrix of K1 (rasterize.py:240-277); zeros for back faces (:240, :253)
 __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S, FaceGeo &g, float inv[9])
 {
@@ -144,8 +137,8 @@ __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S
 #define FR_PUBLISH(at, key) atomicMin(at, key)
 #endif
 #ifndef FR_SEARCH4
-#define FR_SEARCH4 1
-#endif
+#define FR_SEARCH4 1  // four pixels per search step.  (Estimating the interval from the edge equations and pinning it down with
+#endif                // ~4 exact tests, one per step of a small state machine, was slower: 89 vs 81 us, config 4 0.274 vs 0.264 ms)
 #ifndef FR_EVAL2
 #define FR_EVAL2 0  // two pixels per lane and step: measured neutral (84.7 vs 85.1 us), more code
 #endif
@@ -382,17 +375,58 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     FWD_PH_END();
 }
 
-// Faces whose box is too large for LPF lanes and too small for a workgroup (a mesh of spiky or close-up triangles: config 4
-// queued 1/5 of its faces for k_large_raster, 256 threads on a 300-pixel box): one wave per face, lanes stride over the box.
-__device__ __forceinline__ void wave_raster(const float *__restrict__ faces, unsigned long long *__restrict__ zbuf,
-                                            const int *__restrict__ wave_list, const int *__restrict__ n_wave, int F, int S,
-                                            double near_d, double far_d)
+// Candidate pixels first + step * j (j = 0, 1, ...) of one face for the calling wave, lane by lane: the half-plane tests run on
+// every candidate, the pixels that pass are collected (ballot-compacted) in the wave's LDS queue, and whenever 64 are waiting
+// all lanes evaluate one each -- the divisions of the K2 body run with full lanes although only a fraction of a box (a few
+// percent for a needle) lies inside its triangle.
+constexpr int CQ = 128;  // queue words per wave: < 64 waiting + <= 64 new
+template <class PixelOf>
+__device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu, int n_cand, int first, int step,
+                                                  PixelOf pixel_of, int *__restrict__ queue, int S, double near_d,
+                                                  double far_d, unsigned long long *__restrict__ zimg)
 {
-    const int n = *n_wave + 1;  // the counter starts at -1
     const int lane = threadIdx.x & 63;
-    const int waves = gridDim.x * (blockDim.x >> 6);
+    const unsigned long long below = (1ull << lane) - 1ull;
     const bool pow2 = (S & (S - 1)) == 0;
     const float inv_s = 1.0f / (float)S;
+    int waiting = 0;
+    auto evaluate = [&](int e) {
+        const int x = e & 0xffff, y = e >> 16;
+        float zp, w0, w1, w2;
+        if (eval_inside(g, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2))
+            atomicMin(zimg + (size_t)y * S + x, ((unsigned long long)__float_as_uint(zp) << 32) | fnu);
+    };
+    for (int base = first; base < n_cand; base += step) {  // (wave-uniform trip count)
+        const int k = base + lane;
+        int x = 0, y = 0;
+        const bool in = k < n_cand && pixel_of(k, x, y) &&
+                        inside_edges(g, pixel_center_p(x, S, inv_s, pow2), pixel_center_p(y, S, inv_s, pow2));
+        const unsigned long long m = __ballot(in);
+        if (in) queue[waiting + __popcll(m & below)] = (y << 16) | x;
+        waiting += __popcll(m);
+        if (waiting >= 64) {
+            wave_lds_sync();
+            const int e = queue[lane];
+            const int rest = lane + 64 < waiting ? queue[lane + 64] : 0;
+            wave_lds_sync();
+            waiting -= 64;
+            if (lane < waiting) queue[lane] = rest;
+            evaluate(e);
+        }
+    }
+    wave_lds_sync();
+    if (lane < waiting) evaluate(queue[lane]);
+    wave_lds_sync();  // (the queue is reused for the next face)
+}
+
+// Faces whose box is too large for k_face_raster and too small for a workgroup (a mesh of spiky or close-up triangles: config 4
+// queues 1/5 of its faces): one wave per face, lanes stride over the box.
+__device__ __forceinline__ void wave_raster(const float *__restrict__ faces, unsigned long long *__restrict__ zbuf,
+                                            const int *__restrict__ wave_list, const int *__restrict__ n_wave, int F, int S,
+                                            double near_d, double far_d, int *__restrict__ queue)
+{
+    const int n = *n_wave + 1;  // the counter starts at -1
+    const int waves = gridDim.x * (blockDim.x >> 6);
     for (int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < n; j += waves) {
         const int i = wave_list[j];
         const float *f = faces + (size_t)i * 9;
@@ -401,24 +435,28 @@ __device__ __forceinline__ void wave_raster(const float *__restrict__ faces, uns
         load_face_geo(f, S, g, inv);
         const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
         const int b = i / F;
-        const unsigned fnu = (unsigned)(i - b * F);
-        unsigned long long *zimg = zbuf + (size_t)b * S * S;
-        for (int k = lane; k < cd.n; k += 64) {
-            const int yy = k / cd.bw, x = cd.x_lo + (k - yy * cd.bw), y = cd.y_lo + yy;
-            raster_pixel(g, fnu, x, y, pixel_center_p(x, S, inv_s, pow2), pixel_center_p(y, S, inv_s, pow2), near_d, far_d,
-                         zimg + (size_t)y * S);
-        }
+        raster_candidates(
+            g, (unsigned)(i - b * F), cd.n, 0, 64,
+            [&](int k, int &x, int &y) {
+                const int yy = k / cd.bw;
+                x = cd.x_lo + (k - yy * cd.bw);
+                y = cd.y_lo + yy;
+                return true;
+            },
+            queue, S, near_d, far_d, zbuf + (size_t)b * S * S);
     }
 }
 
-// The two queues share one launch: a workgroup first takes large faces (all 256 threads on one face), then its four waves
-// take medium ones.
+// The two queues share one launch: a workgroup first takes large faces (its four waves on one face, 256 candidates per step),
+// then its waves take medium ones.
 __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces,
                                                       unsigned long long *__restrict__ zbuf,
                                                       const int *__restrict__ large_list, const int *__restrict__ wave_list,
                                                       const int *__restrict__ n_large, int F, int S, double near_d,
                                                       double far_d)
 {
+    __shared__ int s_queue[4][CQ];
+    int *queue = s_queue[threadIdx.x >> 6];
     const int n = *n_large + 1;  // the counter starts at -1
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
         const int i = large_list[j];
@@ -428,15 +466,12 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
         load_face_geo(f, S, g, inv);
         const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
         const int b = i / F;
-        const unsigned fnu = (unsigned)(i - b * F);
-        unsigned long long *zimg = zbuf + (size_t)b * S * S;
-        for (int k = threadIdx.x; k < cd.n; k += blockDim.x) {
-            int x, y;
-            if (!cand_pixel(cd, k, S, x, y)) continue;
-            raster_pixel(g, fnu, x, y, pixel_center_f(x, S), pixel_center_f(y, S), near_d, far_d, zimg + (size_t)y * S);
-        }
+        raster_candidates(
+            g, (unsigned)(i - b * F), cd.n, (int)(threadIdx.x >> 6) * 64, 256,
+            [&](int k, int &x, int &y) { return cand_pixel(cd, k, S, x, y); }, queue, S, near_d, far_d,
+            zbuf + (size_t)b * S * S);
     }
-    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d);
+    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d, queue);
 }
 
 // --------------------------------------------------------------------------------------------------
