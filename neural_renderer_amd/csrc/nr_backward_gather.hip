@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 
     const int tid = threadIdx.x;
     const int grp = tid / L, sub = tid - grp * L;
+    // The grid covers F list slots per image, the list holds the ~1/6 of them that own a pixel: the other workgroups leave
+    // here (they used to run the 24-sum reduction below on zeros -- 40 % of the kernel's instructions at the headline size).
+    if (vis_list && (int)blockIdx.x * (256 / L) >= vis_count[blockIdx.y]) return;
     int gi = blockIdx.x * (256 / L) + grp;  // global face index b * F + fn
     bool face_ok = gi < n_faces_total;
     if (vis_list) {  // blockIdx.y = image, slot -> face through the image's visible list
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
     constexpr int L = 16;
     const int tid = threadIdx.x;
     const int grp = tid / L, sub = tid - grp * L;
+    if (vis_list && (int)blockIdx.x * (256 / L) >= vis_count[blockIdx.y]) return;  // slots behind the image's list
     int gi = blockIdx.x * (256 / L) + grp;
     bool face_ok = gi < n_faces_total;
     if (vis_list) {
