@@ -233,29 +233,39 @@ __global__ __launch_bounds__(256) void k_backward_big(
 {
     extern __shared__ __attribute__((aligned(16))) double s_tex[];  // [ts^3 * 3] texel sums of the face being walked
     __shared__ int s_list[256];
-    __shared__ int s_n;
+    __shared__ int s_wave_n[4];
     __shared__ float s_red[33];  // 9 depth sums + 24 texel sums (TEX == 2)
     const int tid = threadIdx.x;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    {   // one face per thread: is its candidate set this kernel's business?
+    if (vis_list && (int)blockIdx.x * 256 >= vis_count[blockIdx.y]) return;  // slots behind the image's list
+    int n_big;
+    {   // one face per thread: is its candidate set this kernel's business?  The list is built in thread order, so that the
+        // gridDim.z workgroups that scan the same range agree on it and can share it out (entry q -> workgroup q % gridDim.z:
+        // with one workgroup per range a 2048 x 2048 view, whose faces are all "big", kept 20 workgroups busy for 5 ms).
         int gi = blockIdx.x * 256 + tid;
         bool ok = gi < n_faces_total;
         if (vis_list) {
             ok = gi < vis_count[blockIdx.y];
             gi = ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + gi] : 0;
         }
+        bool big = false;
         if (ok) {
             const float *f = faces + (size_t)gi * 9;
             const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
-            if (cd.n > BIG_PX) s_list[atomicAdd(&s_n, 1)] = gi;
+            big = cd.n > BIG_PX;
         }
+        const unsigned long long m = __ballot(big);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0) s_wave_n[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += s_wave_n[w];
+        if (big) s_list[before + __popcll(m & ((1ull << lane) - 1ull))] = gi;
+        n_big = s_wave_n[0] + s_wave_n[1] + s_wave_n[2] + s_wave_n[3];
+        __syncthreads();
     }
-    __syncthreads();
-    const int n_big = s_n;
     const int n_tex = TEX ? ts * ts * ts * 3 : 0;
     const int n_lds = TEX == 1 ? n_tex : 0;
-    for (int q = 0; q < n_big; ++q) {
+    for (int q = blockIdx.z; q < n_big; q += gridDim.z) {
         const int gi = s_list[q];
         const int b = gi / F, fn = gi - b * F;
         const float *fp = faces + (size_t)gi * 9;
@@ -476,6 +486,17 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
     }
 }
 
+// k_backward_big's grid: one workgroup per range of 256 faces (or list slots), times as many workgroups per range (z) as it
+// takes to put ~4096 workgroups on the chip -- they share out the range's big faces
+inline dim3 big_grid(bool listed, int B, int F)
+{
+    const size_t n = (size_t)B * F;
+    const dim3 g = listed ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
+    const size_t ranges = (size_t)g.x * g.y;
+    const size_t z = 4096 / ranges;
+    return dim3(g.x, g.y, (unsigned)(z < 1 ? 1 : (z > 64 ? 64 : z)));
+}
+
 }  // namespace
 
 // ====================================================================================================
@@ -534,7 +555,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     }
     if (ts <= 8) {
         // faces the gathers above left out (more than BIG_PX candidates): a workgroup each
-        const dim3 grid = vis_list ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
+        const dim3 grid = big_grid(vis_list != nullptr, B, F);
         const bool st2 = ts2_static && !sampling_weight_map;
         const size_t lds = st2 ? 0 : n_tex * sizeof(double);
 #define NR_BIG(T, D)                                                                                                    \
@@ -569,7 +590,7 @@ int nr::run_backward_depth_map(const float *faces, const float *depth_map, const
     const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
     hipLaunchKernelGGL(k_backward_depth_face, grid, dim3(256), 0, st, faces, depth_map, face_index_map, face_inv_map,
                        weight_map, grad_depth_map, grad_faces, n, F, S, vis_list, vis_count);
-    const dim3 grid_big = vis_list ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
+    const dim3 grid_big = big_grid(vis_list != nullptr, B, F);
     hipLaunchKernelGGL((k_backward_big<0, true>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
                        (const int32_t *)nullptr, face_inv_map, faces, faces, weight_map, depth_map, (const float *)nullptr,
                        (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces);

@@ -128,6 +128,12 @@ def main():
         print(json.dumps({'config': 'C3 example2, whole step replayed from a HIP graph (Adam capturable)', 'B': 1, 'S': 512,
                           'ms_per_step': round(ms, 4), 'loss_after_4_steps': round(first, 2),
                           'loss_last': round(float(loss_buf), 2)}), flush=True)
+    # extreme shapes with the headline's pixel count: one 2048 x 2048 view, 1024 views of 32 x 32 (only on request)
+    for key, (xb, xs) in (('X1', (1, 2048)), ('X2', (1024, 32)), ('X3', (4, 1024)), ('X4', (256, 128))):
+        if key in only:
+            faces, textures = bench.build_scene(dev, xb, 0, xb, xs, 2)
+            run('%s teapot %d views %dx%d' % (key, xb, xs, xs), faces, textures, xs, (True, True, True), 1e-3)
+            del faces, textures
     from test_hip_parity import icosphere, project_mesh
     if not only or 'C4' in only or 'C5' in only:  # (C5's mesh continues C4's random stream: same scenes whatever is selected)
         # config 4 (per-GPU share): 64 distinct ~5k-face meshes (10 240 with fill_back), ts 4 random textures, 256x256 RGB
