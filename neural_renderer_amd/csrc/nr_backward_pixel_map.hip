@@ -226,7 +226,7 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 // cache-line amplification.  The band pipeline makes every sweep an LDS access:
 //
 //   [k_mark_visible]   only when the forward did not hand over its per-face "owns a pixel" flags (visible_faces)
-//   k_compact_small | k_count_visible + k_compact_visible   per image, the sorted list of faces that own at least one
+//   k_compact_par | k_count_visible + k_compact_visible   per image, the sorted list of faces that own at least one
 //          pixel.  A face that owns no pixel contributes nothing to K6 (the out sweep needs face_index[in] == fn,
 //          :604, the in sweep only counts pixels owned by fn, :707), so ~2/3 of the front faces drop out.  The
 //          compaction also stores, per listed face, the line range of each of its 3 edges along both axes, zeroes the
@@ -323,57 +323,60 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
     z[0] = z[1] = z[2] = make_double2(0.0, 0.0);
 }
 
-__device__ __forceinline__ void band_prefix(const int *cnt, int n2, int *__restrict__ start_out, int *__restrict__ cursor_out,
-                                            int *__restrict__ ok_out, size_t cap);
-
-// Ordered compaction.  Meshes of up to SMALL_CHUNKS * 1024 faces: one workgroup per image walks the chunks in order
-// (one launch).  Larger meshes (config 5: 655 360 faces, B = 1) would be serialised in that one workgroup, so they take two
-// launches: k_count_visible counts the flags of each 1024-face chunk, k_compact_visible turns the counts of the preceding
-// chunks into the chunk's offset.  Either way every face gets slot_of = its list position or -1.
+// Ordered compaction: every face gets slot_of = its position in the image's sorted list of visible faces, or -1.  One
+// workgroup per chunk of 1024 faces.
+//   Meshes of up to SMALL_CHUNKS chunks, one launch (k_compact_par): a workgroup counts the flags of the chunks in front of
+//   its own (<= 15 coalesced bytes per thread) and leaves its lines-per-band counts as a dense row chunk_band[b][chunk][.];
+//   the consumer (k_line_setup, or k_band_total when there is none) adds the rows up and takes the prefix.  (One workgroup
+//   per image walking the chunks in order took 16 us for 5 chunks, 99 us for a 2048 x 2048 view with its 2 x 2048 bands.)
+//   Larger meshes (config 5: 655 360 faces, B = 1), two launches + k_band_scan: k_count_visible counts the flags of each
+//   chunk, k_compact_visible turns the counts of the preceding chunks into the chunk's offset and adds its band counts to
+//   the image's global counters.
 constexpr int VIS_CHUNK = 1024;
 constexpr int SMALL_CHUNKS = 16;
 
-__global__ __launch_bounds__(VIS_CHUNK) void k_compact_small(const unsigned char *__restrict__ flags,
-                                                             int *__restrict__ vis_list, int *__restrict__ vis_count,
-                                                             int *__restrict__ slot_of, int F, int n_chunks,
-                                                             const float *__restrict__ faces, unsigned *__restrict__ rng,
-                                                             double *__restrict__ scratch, int S,
-                                                             int *__restrict__ band_lines, int n_bands, int W,
-                                                             int *__restrict__ band_start, int *__restrict__ band_cursor,
-                                                             int *__restrict__ lines_ok, size_t cap)
+__global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *__restrict__ flags,
+                                                           int *__restrict__ vis_list, int *__restrict__ vis_count,
+                                                           int *__restrict__ slot_of, int F, int n_chunks,
+                                                           const float *__restrict__ faces, unsigned *__restrict__ rng,
+                                                           double *__restrict__ scratch, int S,
+                                                           int *__restrict__ chunk_band, int n_bands, int W,
+                                                           int *__restrict__ band_cursor)
 {
-    extern __shared__ int s_band[];  // [2][n_bands] lines per band of this image
+    extern __shared__ int s_band[];  // [2][n_bands] lines per band of this chunk's faces
     __shared__ int s_wcnt[VIS_CHUNK / 64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_part[VIS_CHUNK / 64];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) s_band[i] = 0;
+    int part = 0;  // (per wave) visible faces of this wave's columns of the preceding chunks
+    for (int c = 0; c < chunk; ++c) part += __popcll(__ballot(flags[(size_t)b * F + c * VIS_CHUNK + tid] != 0));
+    const int fn = chunk * VIS_CHUNK + tid;
+    const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
+    const unsigned long long m = __ballot(v);
+    if (lane == 0) { s_part[wave] = part; s_wcnt[wave] = __popcll(m); }
     __syncthreads();
-    int base = 0;
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int fn = chunk * VIS_CHUNK + tid;
-        const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
-        const unsigned long long m = __ballot(v);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = base, tot = 0;
-        for (int w = 0; w < VIS_CHUNK / 64; ++w) {
-            const int c = s_wcnt[w];
-            if (w < wave) off += c;
-            tot += c;
-        }
-        __syncthreads();
-        if (fn < F) {
-            const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-            slot_of[(size_t)b * F + fn] = pos;
-            if (v) emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W);
-        }
-        base += tot;
+    int off = 0, own = 0;
+    for (int w = 0; w < VIS_CHUNK / 64; ++w) {
+        off += s_part[w];
+        if (w < wave) off += s_wcnt[w];
+        own += s_wcnt[w];
+    }
+    if (fn < F) {
+        const int before = off + __popcll(m & ((1ull << lane) - 1ull));  // visible faces in front of fn
+        slot_of[(size_t)b * F + fn] = v ? before : -1;
+        if (v) emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W);
+        else vis_list[(size_t)b * F + F - 1 - (fn - before)] = fn;  // the others fill the list from its end
     }
     __syncthreads();
-    for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) band_lines[(size_t)b * 2 * n_bands + i] = s_band[i];
-    // where each band's records start in the image's buffer (k_line_setup fills it next), and whether they fit at all
-    band_prefix(s_band, 2 * n_bands, band_start + (size_t)b * 2 * n_bands, band_cursor + (size_t)b * 2 * n_bands, lines_ok + b,
-                cap);
-    if (tid == 0) vis_count[b] = base;
+    int *row = chunk_band + ((size_t)b * n_chunks + chunk) * 2 * n_bands;
+    for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) row[i] = s_band[i];
+    if (chunk == 0)  // the fill cursors of k_line_setup (it runs after this kernel)
+        for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) band_cursor[(size_t)b * 2 * n_bands + i] = 0;
+    if (chunk == n_chunks - 1 && tid == 0) {
+        int base = 0;
+        for (int w = 0; w < VIS_CHUNK / 64; ++w) base += s_part[w];
+        vis_count[b] = base + own;
+    }
 }
 
 __global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char *__restrict__ flags,
@@ -430,11 +433,13 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
         own += s_wcnt[w];
     }
     if (fn < F) {
-        const int pos = v ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-        slot_of[(size_t)b * F + fn] = pos;
+        const int before = off + __popcll(m & ((1ull << lane) - 1ull));  // visible faces in front of fn
+        slot_of[(size_t)b * F + fn] = v ? before : -1;
         if (v)
-            emit_visible(b, fn, pos, F, S, faces, vis_list, rng, scratch,
+            emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch,
                          lds_counters ? s_band : band_lines + (size_t)b * 2 * n_bands, n_bands, W);
+        else
+            vis_list[(size_t)b * F + F - 1 - (fn - before)] = fn;  // the others fill the list from its end
     }
     if (lds_counters) {
         __syncthreads();
@@ -951,18 +956,75 @@ __device__ __forceinline__ int line_segments(int in_rng, int out_rng)
 constexpr int LPI = 2;        // lanes per (face, axis, edge) item (an edge crosses 3-4 lines on a fine mesh)
 constexpr int LS_FACES = 32;  // list positions per workgroup (measured: 64 -> 43 us, 32 -> 29 us, 16 -> 29 us; LPI 2: 27 us)
 
+// Adds up the n_sum rows chunk_band[b][.][i] of an image (k_compact_par) into tot[i], i < n2, and takes the exclusive prefix
+// start[i]; returns the image's total.  All 256 threads of the workgroup; tot / start are LDS arrays.
+__device__ __forceinline__ int band_sum_prefix(const int *__restrict__ rows, int n_sum, int n2, int *tot, int *start,
+                                               int *s_tmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n2; i += 256) {
+        int t = 0;
+        for (int c = 0; c < n_sum; ++c) t += rows[(size_t)c * n2 + i];
+        tot[i] = t;
+    }
+    __syncthreads();
+    // thread t owns the entries [t * per, (t + 1) * per)
+    const int per = (n2 + 255) / 256, i0 = tid * per, i1 = min(n2, i0 + per);
+    int local = 0;
+    for (int i = i0; i < i1; ++i) local += tot[i];
+    int inc = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    int run = inc - local;
+    for (int w = 0; w < wave; ++w) run += s_tmp[w];
+    for (int i = i0; i < i1; ++i) {
+        start[i] = run;
+        run += tot[i];
+    }
+    const int total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    __syncthreads();
+    return total;
+}
+
 __global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ faces, const int32_t *__restrict__ fi_map,
                                                     const int *__restrict__ vis_list, const int *__restrict__ vis_count,
-                                                    const unsigned *__restrict__ rng, const int *__restrict__ band_start,
-                                                    int *__restrict__ band_cursor, const int *__restrict__ lines_ok,
+                                                    const unsigned *__restrict__ rng, const int *__restrict__ chunk_band,
+                                                    int n_sum, int *__restrict__ band_lines, int *__restrict__ band_start,
+                                                    int *__restrict__ band_cursor, int *__restrict__ lines_ok,
                                                     BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W,
                                                     int n_bands)
 {
-    extern __shared__ int s_cnt[];  // [2 * n_bands] this workgroup's lines per band, then its fill cursors; [2 * n_bands] bases
-    int *s_base = s_cnt + 2 * n_bands;
+    extern __shared__ int s_cnt[];  // [2 * n_bands] this workgroup's lines per band, then its fill cursors; [2 * n_bands] bases;
+    int *s_base = s_cnt + 2 * n_bands;  // [2 * n_bands] where the image's bands start in its buffer
+    int *s_start = s_base + 2 * n_bands;
+    __shared__ int s_tmp[4];
     const int b = blockIdx.y, pos0 = blockIdx.x * LS_FACES;
     const int n_vis = vis_count[b];
-    if (pos0 >= n_vis || !lines_ok[b]) return;
+    const bool first = blockIdx.x == 0;  // publishes the image's band table for the band kernel
+    if (pos0 >= n_vis && !first) return;
+    int ok;
+    if (n_sum > 0) {
+        // the image's lines per band = the sum of its chunk rows; every workgroup derives the band starts itself
+        const int total = band_sum_prefix(chunk_band + (size_t)b * n_sum * 2 * n_bands, n_sum, 2 * n_bands, s_cnt, s_start, s_tmp);
+        ok = (size_t)total <= cap ? 1 : 0;
+        if (first) {
+            for (int i = threadIdx.x; i < 2 * n_bands; i += blockDim.x) {
+                band_lines[(size_t)b * 2 * n_bands + i] = s_cnt[i];
+                band_start[(size_t)b * 2 * n_bands + i] = s_start[i];
+            }
+            if (threadIdx.x == 0) lines_ok[b] = ok;
+        }
+    } else {  // k_band_scan has prepared the table (large meshes)
+        ok = lines_ok[b];
+        for (int i = threadIdx.x; i < 2 * n_bands; i += blockDim.x) s_start[i] = band_start[(size_t)b * 2 * n_bands + i];
+    }
+    if (pos0 >= n_vis || !ok) return;
+    __syncthreads();
     const int n_pos = min(LS_FACES, n_vis - pos0);
     for (int i = threadIdx.x; i < 2 * n_bands; i += blockDim.x) s_cnt[i] = 0;
     __syncthreads();
@@ -984,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ fa
     __syncthreads();
     // (3) the records: LPI lanes per item stride over its lines
     const size_t img = (size_t)b * S * S;
-    const int *start_b = band_start + (size_t)b * 2 * n_bands;
+    const int *start_b = s_start;
     BandLine *buf_b = line_buf + (size_t)b * cap;
     for (int t = threadIdx.x; t < 6 * n_pos * LPI; t += blockDim.x) {
         const int it = t / LPI, sub = t - it * LPI;
@@ -1038,6 +1100,22 @@ __global__ __launch_bounds__(256) void k_band_scan(const int *__restrict__ band_
 {
     const size_t o = (size_t)blockIdx.x * 2 * n_bands;
     band_prefix(band_lines + o, 2 * n_bands, band_start + o, band_cursor + o, lines_ok + blockIdx.x, force_scan ? 0 : cap);
+}
+
+// the same table from the chunk rows of k_compact_par when no k_line_setup follows (exact kernel, NR_FLAG_K6_SCAN): every
+// image is told to take the scan path
+__global__ __launch_bounds__(256) void k_band_total(const int *__restrict__ chunk_band, int n_sum, int *__restrict__ band_lines,
+                                                    int *__restrict__ band_start, int *__restrict__ lines_ok, int n_bands)
+{
+    const int b = blockIdx.x, n2 = 2 * n_bands;
+    const int *rows = chunk_band + (size_t)b * n_sum * n2;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        int t = 0;
+        for (int c = 0; c < n_sum; ++c) t += rows[(size_t)c * n2 + i];
+        band_lines[(size_t)b * n2 + i] = t;
+        band_start[(size_t)b * n2 + i] = 0;
+    }
+    if (threadIdx.x == 0) lines_ok[b] = 0;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1406,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__
 // ====================================================================================================
 
 struct BpmLayout {
-    size_t flags_off, scratch_off, count_off, chunk_off, list_off, rng_off, slot_off, band_off, start_off, cursor_off, ok_off,
+    size_t flags_off, scratch_off, count_off, chunk_off, cband_off, list_off, rng_off, slot_off, band_off, start_off, cursor_off, ok_off,
         lines_off, total, cap;
     int n_chunks;
 };
@@ -1424,7 +1502,9 @@ BpmLayout bpm_layout(int B, int F, int S)
     L.count_off = align_up(L.scratch_off + n * 6 * sizeof(double), 256);
     L.n_chunks = (F + VIS_CHUNK - 1) / VIS_CHUNK;
     L.chunk_off = L.count_off + align_up((size_t)B * sizeof(int), 256);
-    L.list_off = L.chunk_off + align_up((size_t)B * L.n_chunks * sizeof(int), 256);
+    // rows of k_compact_par: [B][n_chunks][2 * n_bands], n_bands <= S
+    L.cband_off = L.chunk_off + align_up((size_t)B * L.n_chunks * sizeof(int), 256);
+    L.list_off = L.cband_off + (L.n_chunks <= SMALL_CHUNKS ? align_up((size_t)B * L.n_chunks * 2 * S * sizeof(int), 256) : 0);
     L.rng_off = L.list_off + align_up(n * sizeof(int), 256);
     L.slot_off = L.rng_off + align_up(n * 6 * sizeof(unsigned), 256);  // rng: [B][axis][position][edge]
     const size_t per_band = align_up((size_t)B * 2 * S * sizeof(int), 256);  // per (image, axis, band): at most S bands (W = 1)
@@ -1591,13 +1671,20 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     int *band_start = (int *)(ws + L.start_off), *band_cursor = (int *)(ws + L.cursor_off), *lines_ok = (int *)(ws + L.ok_off);
     BandLine *line_buf = (BandLine *)(ws + L.lines_off);
     // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
-    const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 3072;  // grid.y and 48 KB of LDS in k_line_setup
+    // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
+    const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 2048;  // grid.y and 48 KB of LDS in k_line_setup
     const size_t cap = use_records ? L.cap : 0;  // capacity 0: every image is told to take the scan path
-    // (the one-workgroup-per-image compaction keeps the image's 2 * n_bands line counters in LDS: 32 KB at most)
+    int n_sum = 0;  // chunk rows per image that the consumer adds up (0: the band table is ready)
+    // (k_compact_par keeps its chunk's 2 * n_bands line counters in LDS: 32 KB at most)
     if (L.n_chunks <= SMALL_CHUNKS && n_bands <= 4096) {
-        hipLaunchKernelGGL(k_compact_small, dim3((unsigned)B), dim3(VIS_CHUNK), (size_t)2 * n_bands * sizeof(int), st, vflags,
-                           vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W,
-                           band_start, band_cursor, lines_ok, cap);
+        int *chunk_band = (int *)(ws + L.cband_off);
+        n_sum = L.n_chunks;
+        hipLaunchKernelGGL(k_compact_par, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK),
+                           (size_t)2 * n_bands * sizeof(int), st, vflags, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng,
+                           scratch, S, chunk_band, n_bands, W, band_cursor);
+        if (!use_records)
+            hipLaunchKernelGGL(k_band_total, dim3((unsigned)B), dim3(256), 0, st, chunk_band, n_sum, band_lines, band_start,
+                               lines_ok, n_bands);
     } else {
         int *chunk_count = (int *)(ws + L.chunk_off);
         hipLaunchKernelGGL(k_count_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, vflags,
@@ -1612,8 +1699,9 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     }
     if (use_records) {
         hipLaunchKernelGGL(k_line_setup, dim3((unsigned)((F + LS_FACES - 1) / LS_FACES), (unsigned)B), dim3(256),
-                           (size_t)4 * n_bands * sizeof(int), st, faces, face_index_map, vis_list, vis_count, rng, band_start,
-                           band_cursor, lines_ok, line_buf, L.cap, F, S, W, n_bands);
+                           (size_t)6 * n_bands * sizeof(int), st, faces, face_index_map, vis_list, vis_count, rng,
+                           (const int *)(ws + L.cband_off), n_sum, band_lines, band_start, band_cursor, lines_ok, line_buf, L.cap, F,
+                           S, W, n_bands);
     }
     // lines per window: the packed segment scan keeps the count of full segments in 16 bits (<= win * 2 * S / SEG)
     const int win_lines = max(1, min(BAND_WIN, (int)(65535ll * SEG / (2ll * S))));
