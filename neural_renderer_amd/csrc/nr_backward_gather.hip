@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     const float *__restrict__ g_rgb, float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts,
     double eps, int fix_batch_z, int L,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces, int store_zeros)
+    float *__restrict__ grad_faces)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
 
@@ -88,18 +88,14 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     const int n_tex = ts * ts * ts * 3;
     int gi = blockIdx.x * (256 / L) + grp;  // global face index b * F + fn
     bool face_ok = gi < n_faces_total;
-    if (vis_list) {  // blockIdx.y = image, slot -> face through the image's list
-        // The grid covers the F list slots of the image; its first vis_count slots hold the faces that own a pixel (~1/6 of
-        // them), the slots behind hold the others: their gradient is zero, stored here when store_zeros is set (no fill
-        // launch in front of the kernel; the host prefers the fill for large cubes: 4 GB of zeros on config 5).  A workgroup of such slots leaves before the reductions below (run on zeros they were 40 % of the kernel's
-        // instructions at the headline size).
+    if (vis_list) {  // blockIdx.y = image, slot -> face through the image's visible list
+        // The grid covers F list slots per image, the list holds the ~1/6 of them that own a pixel: the other workgroups
+        // leave here (they used to run the 24-sum reduction below on zeros -- 40 % of the kernel's instructions at the
+        // headline size).  Their faces' zeros come from the fill in front of the kernel (storing them from here, through a
+        // list of the invisible faces, cost 9 us to save a 6 us fill).
         const int slot = gi, n_vis = vis_count[blockIdx.y];
-        face_ok = slot < n_vis;
-        if (store_zeros && !face_ok && slot < F) {
-            float *dst = grad_textures + ((size_t)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + slot]) * n_tex;
-            for (int k = sub; k < n_tex; k += L) dst[k] = 0.0f;
-        }
         if ((int)blockIdx.x * (256 / L) >= n_vis) return;
+        face_ok = slot < n_vis;
         gi = face_ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + slot] : 0;
     }
     double *acc_l = s_acc + (size_t)grp * n_tex;
@@ -530,10 +526,8 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     const bool ts2_static = ts == 2 && (float)(1.0 - eps) < 1.0f;
     if (ts == 2 && !ts2_static) g_depth = nullptr;
     if (g_depth && depth_done) *depth_done = 1;
-    // with a list only its visible faces are visited; the zeros of the others (listed behind them) are stored by the gather
-    // itself up to 64 MB, by a fill beyond
-    const int store_zeros = vis_list && (size_t)n * n_tex * sizeof(float) <= ((size_t)64 << 20);
-    if (vis_list && !store_zeros) {
+    if (vis_list) {
+        // only visible faces are visited: everything else is zero
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
@@ -542,11 +536,11 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         if (g_depth)
             hipLaunchKernelGGL((k_backward_textures_face<true, true>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces, store_zeros);
+                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces);
         else
             hipLaunchKernelGGL((k_backward_textures_face<true, false>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, nullptr, nullptr, store_zeros);
+                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, nullptr, nullptr);
     } else if (ts <= 13) {
         const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
         const int per = 256 / L;
@@ -555,11 +549,11 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         if (g_depth && L <= 64)
             hipLaunchKernelGGL((k_backward_textures_face<false, true>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces, store_zeros);
+                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces);
         else
             hipLaunchKernelGGL((k_backward_textures_face<false, false>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, nullptr, nullptr, store_zeros);
+                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, nullptr, nullptr);
     }
     if (ts <= 8) {
         // faces the gathers above left out (more than BIG_PX candidates): a workgroup each
