@@ -65,6 +65,58 @@ __device__ __forceinline__ DepthConst depth_constants(const float f[9], int S)
     return d;
 }
 
+// Walk of a face's candidate pixels by its group of L lanes, the lanes of a wave in step, in two passes.  Ownership pass: one
+// lane per candidate, only face_index_map is read; the owned pixels (a quarter of a typical box) are ballot-compacted into
+// the group's LDS queue.  Evaluation pass: whenever a group has QL pixels waiting -- and once at the end, for all groups of the
+// wave together -- each lane takes one owned pixel and calls eval(pixel offset in the image).  (With the ownership test in
+// front of the evaluation in one loop, the evaluation ran in every candidate step in which *any* lane of the wave owned its
+// pixel: three to four times per wave instead of once or twice.)  The order in which a lane meets its pixels, and therefore
+// the rounding of its float sums, is fixed by the candidate order: results are reproducible and identical between the
+// kernels that use this walk.
+//   n_mine: candidates of this lane's face (0: none, the lane only keeps step); queue: 2 * QL words of LDS per queue group
+//   (QL = min(L, 64) lanes: the face's group, or one wave of it when L == 256).
+template <class Eval>
+__device__ __forceinline__ void walk_owned_pixels(const Cand &cd, int n_mine, int fn, const int32_t *__restrict__ fi_img,
+                                                  int S, int sub, int L, int *__restrict__ queue_base, Eval eval)
+{
+    const int tid = threadIdx.x;
+    const int QL = L < 64 ? L : 64;
+    int *queue = queue_base + (tid / QL) * (2 * QL);
+    const int qsub = tid & (QL - 1);
+    const int qshift = (tid & 63) & ~(QL - 1);
+    const unsigned long long qmask = QL == 64 ? ~0ull : ((1ull << QL) - 1ull);
+    int waiting = 0;
+    for (int i = sub;; i += L) {
+        const bool more = i < n_mine;
+        const bool any_more = __ballot(more) != 0ull;
+        int x = 0, y = 0, off = 0;
+        bool owned = false;
+        if (more && cand_pixel(cd, i, S, x, y)) {
+            off = y * S + x;
+            owned = fi_img[off] == fn;
+        }
+        const unsigned long long m = (__ballot(owned) >> qshift) & qmask;
+        if (owned) queue[waiting + __popcll(m & ((1ull << qsub) - 1ull))] = off;
+        waiting += __popcll(m);
+        const bool ready = waiting >= QL || (!any_more && waiting > 0);
+        if (__ballot(ready) != 0ull) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int take = ready ? (waiting < QL ? waiting : QL) : 0;
+            const int e = qsub < take ? queue[qsub] : 0;
+            const int rest = (ready && qsub + QL < waiting) ? queue[qsub + QL] : 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            waiting -= take;
+            if (ready && qsub < waiting) queue[qsub] = rest;
+            if (qsub < take) eval(e);
+        }
+        if (!any_more) break;  // (the evaluation above took everything that was waiting)
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // B2: one face per group of L lanes (L = 16 | 64 | 256, a power of two; 256 / L faces per workgroup).
 // TS2 = true: texture_size == 2 and eps > 0, so every tap index is static: corner pn -> texel
@@ -82,6 +134,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     float *__restrict__ grad_faces)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
+    __shared__ int s_queue[512];  // owned pixels waiting for their evaluation (walk_owned_pixels)
 
     const int tid = threadIdx.x;
     const int grp = tid / L, sub = tid - grp * L;
@@ -112,13 +165,21 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         __syncthreads();
     }
 
+    Cand cd;
+    cd.n = 0;
+    int fn = 0;
+    size_t img = 0;
+    DepthConst dc;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dc.tmp[k] = dc.zz[k] = 0.0f;
+    float face_z[3] = {1.0f, 1.0f, 1.0f};
     if (face_ok) {
-        const int b = gi / F, fn = gi - b * F;
+        const int b = gi / F;
+        fn = gi - b * F;
         const float *f = faces + (size_t)gi * 9;
-        const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+        cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
         if (cd.n > 0 && (L == 256 || (cd.n <= BIG_PX))) {  // the rest is k_backward_big's
             any_box = true;
-            DepthConst dc;
             if (DEPTH) {
                 float fv[9];
 #pragma unroll
@@ -127,57 +188,51 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
             }
             // z of the three vertices as the forward sampled them: batch 0's geometry (zbase) unless fixed (:389, Q1)
             const float *fz = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fn * 9;
-            const float face_z[3] = {fz[2], fz[5], fz[8]};
-            const size_t img = (size_t)b * S * S;
-            for (int i = sub; i < cd.n; i += L) {
-                int x, y;
-                if (!cand_pixel(cd, i, S, x, y)) continue;
-                const size_t p = img + (size_t)y * S + x;
-                // every operand of the pixel is requested before the ownership test: one memory round trip per
-                // box pixel instead of two dependent ones (the kernel is bound by that latency, not by bandwidth)
-                const int fi_p = face_index_map[p];
-                float wk[3] = {0.0f, 0.0f, 0.0f}, depth = 0.0f, gd = 0.0f;
-                if (weight_map) { wk[0] = weight_map[3 * p]; wk[1] = weight_map[3 * p + 1]; wk[2] = weight_map[3 * p + 2]; }
-                if (depth_map) depth = depth_map[p];
-                if (DEPTH) gd = g_depth[p];
-                const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
-                if (fi_p != fn) continue;
-                Taps t;
-                if (sampling_weight_map) {
-#pragma unroll
-                    for (int pn = 0; pn < 8; pn++) {
-                        t.w[pn] = sampling_weight_map[8 * p + pn];
-                        t.isc[pn] = sampling_index_map[8 * p + pn];
-                    }
-                } else {
-                    compute_taps(face_z, wk, depth, ts, eps, t);
-                }
-                if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
-                    const float depth2 = depth * depth;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 / dc.zz[k];
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-#pragma unroll
-                        for (int l = 0; l < 2; l++) dacc[3 * k + l] += -gd * dc.tmp[l] * wk[k] * depth2 * (float)S / 2.0f;
-                }
-#pragma unroll
-                for (int pn = 0; pn < 8; pn++) {
-                    if (TS2) {
-                        acc[3 * pn + 0] += t.w[pn] * g[0];  // :780
-                        acc[3 * pn + 1] += t.w[pn] * g[1];
-                        acc[3 * pn + 2] += t.w[pn] * g[2];
-                    } else {
-                        if (t.isc[pn] * 3 >= n_tex) continue;  // outside the cube: weight 0 (compute_taps)
-                        double *q = acc_l + t.isc[pn] * 3;
-                        atomicAdd(q + 0, (double)(t.w[pn] * g[0]));
-                        atomicAdd(q + 1, (double)(t.w[pn] * g[1]));
-                        atomicAdd(q + 2, (double)(t.w[pn] * g[2]));
-                    }
-                }
-            }
+            face_z[0] = fz[2]; face_z[1] = fz[5]; face_z[2] = fz[8];
+            img = (size_t)b * S * S;
         }
     }
+    walk_owned_pixels(cd, any_box ? cd.n : 0, fn, face_index_map + img, S, sub, L, s_queue, [&](int off) {
+        const size_t p = img + (size_t)off;
+        float wk[3] = {0.0f, 0.0f, 0.0f}, depth = 0.0f, gd = 0.0f;
+        if (weight_map) { wk[0] = weight_map[3 * p]; wk[1] = weight_map[3 * p + 1]; wk[2] = weight_map[3 * p + 2]; }
+        if (depth_map) depth = depth_map[p];
+        if (DEPTH) gd = g_depth[p];
+        const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
+        Taps t;
+        if (sampling_weight_map) {
+#pragma unroll
+            for (int pn = 0; pn < 8; pn++) {
+                t.w[pn] = sampling_weight_map[8 * p + pn];
+                t.isc[pn] = sampling_index_map[8 * p + pn];
+            }
+        } else {
+            compute_taps(face_z, wk, depth, ts, eps, t);
+        }
+        if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
+            const float depth2 = depth * depth;
+#pragma unroll
+            for (int k = 0; k < 3; k++) dacc[3 * k + 2] += gd * wk[k] * depth2 / dc.zz[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int l = 0; l < 2; l++) dacc[3 * k + l] += -gd * dc.tmp[l] * wk[k] * depth2 * (float)S / 2.0f;
+        }
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            if (TS2) {
+                acc[3 * pn + 0] += t.w[pn] * g[0];  // :780
+                acc[3 * pn + 1] += t.w[pn] * g[1];
+                acc[3 * pn + 2] += t.w[pn] * g[2];
+            } else {
+                if (t.isc[pn] * 3 >= n_tex) continue;  // outside the cube: weight 0 (compute_taps)
+                double *q = acc_l + t.isc[pn] * 3;
+                atomicAdd(q + 0, (double)(t.w[pn] * g[0]));
+                atomicAdd(q + 1, (double)(t.w[pn] * g[1]));
+                atomicAdd(q + 2, (double)(t.w[pn] * g[2]));
+            }
+        }
+    });
 
     if (TS2) {
         // L == 16 here: reduce inside the 16-lane row, its last lane stores the face's 24 floats (96 B)
@@ -438,46 +493,53 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
 #pragma unroll
     for (int k = 0; k < 9; k++) acc[k] = 0.0f;
     bool any_box = false;
+    __shared__ int s_queue[512];
+    Cand cd;
+    cd.n = 0;
+    int fn = 0;
+    size_t img = 0;
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = 1.0f;
+    DepthConst dc;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dc.tmp[k] = dc.zz[k] = 0.0f;
     if (face_ok) {
-        const int b = gi / F, fn = gi - b * F;
+        const int b = gi / F;
+        fn = gi - b * F;
         const float *fp = faces + (size_t)gi * 9;
-        float f[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) f[k] = fp[k];
-        const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
+        cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
         if (cd.n > 0 && cd.n <= BIG_PX) {  // the rest is k_backward_big's
             any_box = true;
-            const DepthConst dc = depth_constants(f, S);
-            const size_t img = (size_t)b * S * S;
-            for (int i = sub; i < cd.n; i += L) {
-                int x, y;
-                if (!cand_pixel(cd, i, S, x, y)) continue;
-                const size_t p = img + (size_t)y * S + x;
-                const int fi_p = face_index_map[p];  // operands requested before the ownership test (see K7)
-                const float depth = depth_map[p];
-                const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
-                const float gd = g_depth[p];
-                if (fi_p != fn) continue;
-                const float depth2 = depth * depth;
-                // :824-827
-#pragma unroll
-                for (int k = 0; k < 3; k++) acc[3 * k + 2] += gd * w[k] * depth2 / dc.zz[k];
-                // :830-837
-                float tmp[3] = {dc.tmp[0], dc.tmp[1], dc.tmp[2]};
-                if (face_inv_map) {  // the reference's per-pixel residual: its values, its divisions
-                    tmp[0] = tmp[1] = tmp[2] = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-#pragma unroll
-                        for (int l = 0; l < 3; l++) tmp[k] += -face_inv_map[9 * p + 3 * l + k] / f[3 * l + 2];
-                }
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int l = 0; l < 2; l++) acc[3 * k + l] += -gd * tmp[l] * w[k] * depth2 * (float)S / 2.0f;
-            }
+            dc = depth_constants(f, S);
+            img = (size_t)b * S * S;
         }
     }
+    walk_owned_pixels(cd, any_box ? cd.n : 0, fn, face_index_map + img, S, sub, L, s_queue, [&](int off) {
+        const size_t p = img + (size_t)off;
+        const float depth = depth_map[p];
+        const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+        const float gd = g_depth[p];
+        const float depth2 = depth * depth;
+        // :824-827
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[3 * k + 2] += gd * w[k] * depth2 / dc.zz[k];
+        // :830-837
+        float tmp[3] = {dc.tmp[0], dc.tmp[1], dc.tmp[2]};
+        if (face_inv_map) {  // the reference's per-pixel residual: its values, its divisions
+            tmp[0] = tmp[1] = tmp[2] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int l = 0; l < 3; l++) tmp[k] += -face_inv_map[9 * p + 3 * l + k] / f[3 * l + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int l = 0; l < 2; l++) acc[3 * k + l] += -gd * tmp[l] * w[k] * depth2 * (float)S / 2.0f;
+    });
     if (__ballot(any_box) == 0ull) return;  // whole wave has nothing to add
 #pragma unroll
     for (int k = 0; k < 9; k++) acc[k] = row16_sum_last(acc[k]);

@@ -22,6 +22,7 @@ NR_STAGE_FLAGS=2 TAG=exact timeout 300 python scripts/stage_times.py >> $OUT/sta
 NR_STAGE_FLAGS=8 TAG=scan_path timeout 300 python scripts/stage_times.py >> $OUT/stages.log 2>&1
 timeout 300 python scripts/k6_modes.py >> $OUT/stages.log 2>&1
 timeout 900 python scripts/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
+ONLY=X1,X2,X3,X4 timeout 600 python scripts/bench_configs.py >> $OUT/configs.jsonl 2>> $OUT/configs.err  # extreme shapes
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o stats -- python bench.py --steps 10 --warmup 2 --cpu-sample-views 0 --light > $OUT/bench_prof.log 2>&1
 python scripts/rocpd_stats.py $OUT/stats_results.db $OUT/kernel_stats.csv > /dev/null 2>&1
@@ -34,6 +35,10 @@ if [ -n "$PMC" ]; then
   ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT -o sq2 -- python scripts/stage_times.py > $OUT/sq2.log 2>&1
   python scripts/rocpd_pmc.py $OUT/sq_results.db k_bpm > $OUT/pmc_k6.txt 2>&1
   python scripts/rocpd_pmc.py $OUT/sq2_results.db k_bpm >> $OUT/pmc_k6.txt 2>&1
+  for k in k_face_raster k_line_setup "k_backward_textures_face<true, true>"; do
+    python scripts/rocpd_pmc.py $OUT/sq_results.db "$k" >> $OUT/pmc_other.txt 2>&1
+    python scripts/rocpd_pmc.py $OUT/sq2_results.db "$k" >> $OUT/pmc_other.txt 2>&1
+  done
 fi
 rm -f $OUT/*_results.db
 grep -E "===|passed|failed|error" $OUT/pytest.log | head -40
