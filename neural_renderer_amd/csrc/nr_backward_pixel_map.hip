@@ -1615,13 +1615,13 @@ constexpr size_t band_fixed_lds(int win)
 }
 
 // band width (lines per workgroup) and line window for the given raster size and modes; 0 = does not fit (global fallback)
-int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *win)
+int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *win, int w_max = 4)
 {
     const size_t per_px = exact ? 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0) : (rgb ? 36 : 12);
     const size_t SP = (size_t)S + 4;
     // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
     // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
-    for (int W = 4; W >= 1; W >>= 1) {
+    for (int W = w_max; W >= 1; W >>= 1) {
         // three workgroups per CU with a 128-line window beat two with 256 (the phases of co-resident workgroups overlap)
         for (int w = BAND_WIN; w >= (exact ? BAND_WIN : FAST_WIN_SMALL); w >>= 1) {
             const size_t fixed = exact ? (sizeof(BandLine) + 12) * (size_t)w + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16
@@ -1716,7 +1716,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
 
     size_t lds = 0;
     int win = BAND_WIN;
-    const int W = band_width(S, rgb, alpha, exact, &lds, &win);
+    // Narrower bands when the launch would have few band workgroups (small batches): the chip holds 768 of them at a time and
+    // half of a teapot view's bands are empty; 16 views: stage 113 -> 104 us with W = 2, 4 views 70 -> 50, 1 view 66 -> 40 (W = 1).
+    int w_max = 4;
+    while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
+    const int W = band_width(S, rgb, alpha, exact, &lds, &win, w_max);
     if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
         const dim3 grid((unsigned)n), block(WAVE);
         if (rgb && alpha)

@@ -128,9 +128,10 @@ __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S
 #ifndef FR_PIX
 #define FR_PIX 256  // pixel items per window (7.4 KB of LDS per wave: five workgroups per CU)
 #endif
-#ifndef FR_GROUP
-#define FR_GROUP 16  // consecutive faces per lane group (power of two <= 64), see the face -> lane mapping below
-#endif
+// FACES: faces per wave (its first FACES lanes take one each) and GROUP: consecutive faces per run of the face -> lane mapping
+// are template parameters: 64 / 16 in general, 32 / 8 for launches of fewer than 2048 such waves (less than two per SIMD: the
+// kernel is then one round of waves and as long as a wave lives -- 16 teapot views: 25 -> 17 us; at 64 views and on config 4
+// the halves cost 0-12 %).
 #ifdef NR_FWD_NO_ATOMIC  // development: what the z-buffer atomics cost (results are wrong)
 #define FR_PUBLISH(at, key) do { if ((key) == 12345ull) *(at) = (key); } while (0)
 #else
@@ -144,9 +145,10 @@ __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S
 #endif
 static_assert(SMALL_AREA <= 256, "rows and columns of a kept box are packed into 8 bits each");
 
+template <int FACES>
 struct FaceWaveLds {
-    float g[18][64];  // x0 y0 x1 y1 x2 y2 | z0 z1 z2 | inv[9], component-major: lanes with different faces hit different banks
-    int x_lo[64], y_lo[64], bw[64], img[64], fn[64];
+    float g[18][FACES];  // x0 y0 x1 y1 x2 y2 | z0 z1 z2 | inv[9], component-major: lanes with different faces hit different banks
+    int x_lo[FACES], y_lo[FACES], bw[FACES], img[FACES], fn[FACES];
     int rows[FR_ROWS];
     int pix[FR_PIX];
 };
@@ -174,7 +176,8 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // pixel item (slot << 16 | row << 8 | column) -> z-buffer word and key; false when the depth test rejects the pixel
-__device__ __forceinline__ bool slot_pixel(const FaceWaveLds &L, int e, int S, double near_d, double far_d,
+template <int FACES>
+__device__ __forceinline__ bool slot_pixel(const FaceWaveLds<FACES> &L, int e, int S, double near_d, double far_d,
                                            unsigned long long *__restrict__ zbuf, unsigned long long &key,
                                            unsigned long long *&at)
 {
@@ -209,7 +212,7 @@ __device__ unsigned long long g_fwd_phase[8];
 #define FWD_PH_END()
 #endif
 
-template <bool POW2>
+template <bool POW2, int FACES, int GROUP>
 __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces,
                                                      unsigned long long *__restrict__ zbuf,
                                                      int *__restrict__ large_list, int *__restrict__ wave_list,
@@ -217,34 +220,34 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                                                      unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
                                                      int S, double near_d, double far_d)
 {
-    __shared__ FaceWaveLds lds[4];
-    FaceWaveLds &L = lds[threadIdx.x >> 6];
+    __shared__ FaceWaveLds<FACES> lds[4];
+    FaceWaveLds<FACES> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     FWD_PH_BEGIN();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_faces_total && visible_faces) visible_faces[t] = 0;  // k_resolve raises the flags of the faces that win a pixel
-    // A wave takes 64 / FR_GROUP groups of FR_GROUP consecutive faces, the groups W apart (W = number of waves): faces that are
+    // A wave takes 64 / GROUP groups of GROUP consecutive faces, the groups W apart (W = number of waves): faces that are
     // neighbours in the mesh are neighbours on screen and of similar size, and a wave of 64 consecutive large ones has ten
     // times the average work -- the kernel then waits for a few waves (teapot view: 2566 inside pixels in the heaviest wave
     // against a mean of 233; fully interleaved: 280).
-    const int n_waves = (n_faces_total + 63) >> 6;
-    const int i = ((lane / FR_GROUP) * n_waves + (t >> 6)) * FR_GROUP + (lane % FR_GROUP);
-    const bool live = (t >> 6) < n_waves && i < n_faces_total;
-    // the wave's faces: 64 / FR_GROUP runs of FR_GROUP * 9 floats, fetched with consecutive lanes on consecutive words (a lane
-    // fetching its own 36 bytes makes 64 requests per load instruction) and handed to their lanes through LDS
+    const int n_waves = (n_faces_total + FACES - 1) / FACES;
+    const int i = ((lane / GROUP) * n_waves + (t >> 6)) * GROUP + (lane % GROUP);
+    const bool live = lane < FACES && (t >> 6) < n_waves && i < n_faces_total;
+    // the wave's faces: FACES / GROUP runs of GROUP * 9 floats, fetched with consecutive lanes on consecutive words (a
+    // lane fetching its own 36 bytes makes 64 requests per load instruction) and handed to their lanes through LDS
     float f[9];
     {
-        float *stage = &L.g[0][0];  // 576 of its 1152 floats; the slot constants move in after the hand-over
+        float *stage = &L.g[0][0];  // half of its floats; the slot constants move in after the hand-over
         const size_t n_words = (size_t)n_faces_total * 9;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int d = k * 64 + lane, run = d / (9 * FR_GROUP), off = d - run * (9 * FR_GROUP);
-            const size_t src = ((size_t)run * n_waves + (t >> 6)) * (9 * FR_GROUP) + off;
-            stage[d] = src < n_words ? faces[src] : 0.0f;
+        for (int k = 0; k < (9 * FACES + 63) / 64; k++) {
+            const int d = k * 64 + lane, run = d / (9 * GROUP), off = d - run * (9 * GROUP);
+            const size_t src = ((size_t)run * n_waves + (t >> 6)) * (9 * GROUP) + off;
+            if (d < 9 * FACES) stage[d] = src < n_words ? faces[src] : 0.0f;
         }
         wave_lds_sync();
 #pragma unroll
-        for (int k = 0; k < 9; k++) f[k] = stage[lane * 9 + k];
+        for (int k = 0; k < 9; k++) f[k] = stage[(lane & (FACES - 1)) * 9 + k];
         wave_lds_sync();
     }
     Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
@@ -664,12 +667,15 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
     if (he != hipSuccess) return (int)he;
     int *wave_list = large_list + n;
-    if ((S & (S - 1)) == 0)
-        hipLaunchKernelGGL(k_face_raster<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
-                       wave_list, n_large, visible_faces, (int)n, F, S, near, far);
-    else
-        hipLaunchKernelGGL(k_face_raster<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, zbuf, large_list,
-                       wave_list, n_large, visible_faces, (int)n, F, S, near, far);
+    {
+        const bool pow2 = (S & (S - 1)) == 0, few = n < 2048 * 64;
+#define NR_FACE_RASTER(P, FC, G)                                                                                           \
+    hipLaunchKernelGGL((k_face_raster<P, FC, G>), dim3((unsigned)((n + 4 * FC - 1) / (4 * FC))), dim3(256), 0, st, faces, zbuf, \
+                       large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far)
+        if (few) { if (pow2) NR_FACE_RASTER(true, 32, 8); else NR_FACE_RASTER(false, 32, 8); }
+        else { if (pow2) NR_FACE_RASTER(true, 64, 16); else NR_FACE_RASTER(false, 64, 16); }
+#undef NR_FACE_RASTER
+    }
     // a resident grid loops over the two queues; with empty queues (a fine mesh) its workgroups read two counters and leave
     hipLaunchKernelGGL(k_large_raster, dim3(2048), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
                        far);

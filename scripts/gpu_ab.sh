@@ -20,4 +20,10 @@ for v in "" ${VARIANTS}; do
     timeout 900 python scripts/bench_configs.py 2>$OUT/configs.err | cut -c1-400 | tee -a $OUT/configs.log
   fi
 done
+for v in ${VARIANT_TESTS}; do  # parity of a variant build: the forward / K6 suites against the oracle
+  export NR_HIP_LIB=$PWD/neural_renderer_amd/libnr_hip_$v.so
+  timeout 600 python -m pytest tests/test_hip_parity.py tests/test_fuzz_gpu.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/variant_$v.log 2>&1
+  echo "=== variant $v: $(tail -1 $OUT/variant_$v.log)"
+done
+unset NR_HIP_LIB
 grep -E "^FAILED|^ERROR" $OUT/*.log | cut -c1-200 | head -40
