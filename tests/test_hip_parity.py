@@ -156,6 +156,27 @@ def test_thin_face_with_far_offscreen_vertices():
     check_backward(faces, textures, 256, 1e-3, (True, True, True), seed=18)
 
 
+@pytest.mark.parametrize('F,S', [(1, 64), (33, 100), (4096, 256), (40000, 96)])
+def test_forward_wave_redistribution(F, S):
+    """k_face_raster deals a wave's rows, then its inside pixels, to the lanes through LDS lists of 128 / 256 entries: faces of
+    ~15 x 15 pixels fill several windows of both lists per wave (64 kept faces -> ~900 rows, ~6000 inside pixels).  The face
+    counts cover both wave sizes of the kernel (32 faces below 131 072 faces per launch, 64 above: B * F = 160 000), a launch
+    that is not a multiple of either, and a raster that is not a power of two."""
+    rng = np.random.default_rng(1000 + F)
+    B = 4
+    size = 15.0 * 2.0 / S                                     # NDC extent of ~15 pixels
+    c = rng.uniform(-0.9, 0.9, (B, F, 1, 2)).astype(np.float32)
+    faces = np.zeros((B, F, 3, 3), np.float32)
+    faces[..., :2] = c + rng.uniform(-0.5, 0.5, (B, F, 3, 2)).astype(np.float32) * size
+    faces[..., 2] = rng.uniform(1.0, 3.0, (B, F, 3)).astype(np.float32)
+    flip = ((faces[:, :, 2, 1] - faces[:, :, 0, 1]) * (faces[:, :, 1, 0] - faces[:, :, 0, 0]) <
+            (faces[:, :, 1, 1] - faces[:, :, 0, 1]) * (faces[:, :, 2, 0] - faces[:, :, 0, 0]))
+    faces[flip] = faces[flip][:, ::-1]                         # all front-facing: every face is kept
+    fn = oracle_forward(faces, None, S, 0.1, 100, 1e-4, None, False, True, True)
+    fw = abi.forward(faces, None, S, return_alpha=True, return_depth=True, want_face_inv=True)
+    check_forward(fw, fn)
+
+
 def test_many_faces_more_than_one_round():
     """F > 1024 exercises several scan rounds of the tile kernel; dense overlap exercises the tie rule."""
     rng = np.random.default_rng(4)
