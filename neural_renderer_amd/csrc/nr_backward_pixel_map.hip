@@ -1761,7 +1761,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     BandLine *line_buf = (BandLine *)(ws + L.lines_off);
     // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
     // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
-    const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 2048;  // grid.y and 48 KB of LDS in k_line_setup
+    const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 3072;  // grid.y and 72 KB of LDS in k_line_setup
     const size_t cap = use_records ? L.cap : 0;  // capacity 0: every image is told to take the scan path
     int n_sum = 0;  // chunk rows per image that the consumer adds up (0: the band table is ready)
     // (k_compact_par keeps its chunk's 2 * n_bands line counters in LDS: 32 KB at most)
@@ -1787,6 +1787,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                                n_bands, cap, 0);
     }
     if (use_records) {
+        static LdsLimit ls_limit;
+        if (int rc = ls_limit.ensure((const void *)k_line_setup, (size_t)6 * n_bands * sizeof(int))) return rc;
         hipLaunchKernelGGL(k_line_setup, dim3((unsigned)((F + LS_FACES - 1) / LS_FACES), (unsigned)B), dim3(256),
                            (size_t)6 * n_bands * sizeof(int), st, faces, face_index_map, vis_list, vis_count, rng,
                            (const int *)(ws + L.cband_off), n_sum, band_lines, band_start, band_cursor, lines_ok, line_buf, L.cap, F,

@@ -349,6 +349,16 @@ def test_very_large_raster_alpha_only(S):
     check_backward(faces, None, S, 1e-4, (False, True, False), seed=4001 + S)
 
 
+@pytest.mark.parametrize('S', [2048, 2600])
+def test_large_raster_rgb_one_line_bands(S):
+    """RGB + alpha at raster sizes whose bands are one line wide (W = 1 from S ~ 1500): 2 x 2048 bands are the most whose
+    table k_line_setup keeps in 48 KB of LDS, 2 x 2600 need the raised limit (up to 3072; beyond, the in-kernel line setup)."""
+    rng = np.random.default_rng(7000 + S)
+    faces = H.random_scene(rng, 1, 24, spread=0.5, size=0.3)
+    textures = rng.uniform(0, 1, (1, 24, 2, 2, 2, 3)).astype(np.float32)
+    check_backward(faces, textures, S, 1e-3, (True, True, False), seed=7001 + S)
+
+
 def test_known_answer_gradients_through_renderer():
     """The reference's grad_ref constants (tests/test_rasterize_silhouettes.py:37-99) through the full
     PyTorch-facing API: Renderer -> look_at -> vertices_to_faces -> HIP rasterizer -> autograd."""
