@@ -132,17 +132,8 @@ __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S
 // are template parameters: 64 / 16 in general, 32 / 8 for launches of fewer than 2048 such waves (less than two per SIMD: the
 // kernel is then one round of waves and as long as a wave lives -- 16 teapot views: 25 -> 17 us; at 64 views and on config 4
 // the halves cost 0-12 %).
-#ifdef NR_FWD_NO_ATOMIC  // development: what the z-buffer atomics cost (results are wrong)
-#define FR_PUBLISH(at, key) do { if ((key) == 12345ull) *(at) = (key); } while (0)
-#else
-#define FR_PUBLISH(at, key) atomicMin(at, key)
-#endif
-#ifndef FR_SEARCH4
-#define FR_SEARCH4 1  // four pixels per search step.  (Estimating the interval from the edge equations and pinning it down with
-#endif                // ~4 exact tests, one per step of a small state machine, was slower: 89 vs 81 us, config 4 0.274 vs 0.264 ms)
-#ifndef FR_EVAL2
-#define FR_EVAL2 0  // two pixels per lane and step: measured neutral (84.7 vs 85.1 us), more code
-#endif
+// Measured and dropped: two pixels per lane and evaluation step (neutral, more code); the row interval estimated from the edge
+// equations and pinned down with ~4 exact tests by a one-test-per-step state machine (89 vs 81 us fused forward).
 static_assert(SMALL_AREA <= 256, "rows and columns of a kept box are packed into 8 bits each");
 
 template <int FACES>
@@ -318,7 +309,6 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                 q.x0 = L.g[0][s]; q.y0 = L.g[1][s]; q.x1 = L.g[2][s]; q.y1 = L.g[3][s]; q.x2 = L.g[4][s]; q.y2 = L.g[5][s];
                 const int x_lo = L.x_lo[s], x_end = x_lo + L.bw[s];
                 const float yp = pixel_center_p(L.y_lo[s] + (item & 255), S, inv_s, pow2);
-#if FR_SEARCH4
                 // four pixels per step (independent tests overlap their latencies); the interval ends at the first outside
                 // pixel behind an inside one
                 bool started = false;
@@ -335,13 +325,6 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                     cnt += __popc(m);
                     if (started && !in[3]) break;
                 }
-#else
-                int px = x_lo;
-                while (px < x_end && !inside_edges(q, pixel_center_p(px, S, inv_s, pow2), yp)) ++px;
-                xa = px;
-                while (px < x_end && inside_edges(q, pixel_center_p(px, S, inv_s, pow2), yp)) ++px;
-                cnt = px - xa;
-#endif
                 xa -= x_lo;
             }
             FWD_PH(3);
@@ -355,22 +338,10 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                 FWD_PH(4);
                 // 3. one inside pixel per lane
                 const int pix_here = min(FR_PIX, n_pix - pbase);
-#if FR_EVAL2
-                // two pixels per lane and step: the two division chains overlap
-                for (int pp = lane; pp < pix_here; pp += 128) {
-                    const bool two = pp + 64 < pix_here;
-                    unsigned long long key0, key1, *at0, *at1;
-                    const bool ok0 = slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key0, at0);
-                    const bool ok1 = slot_pixel(L, L.pix[two ? pp + 64 : pp], S, near_d, far_d, zbuf, key1, at1);
-                    if (ok0) FR_PUBLISH(at0, key0);
-                    if (ok1 && two) FR_PUBLISH(at1, key1);
-                }
-#else
                 for (int pp = lane; pp < pix_here; pp += 64) {
                     unsigned long long key, *at;
-                    if (slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key, at)) FR_PUBLISH(at, key);
+                    if (slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key, at)) atomicMin(at, key);
                 }
-#endif
                 FWD_PH(5);
             }
         }
