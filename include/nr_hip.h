@@ -180,7 +180,8 @@ int nr_forward_rasterize(const float *faces, const float *faces_z_ref, const flo
  * (the reference substitutes zeros, :858-878): the corresponding terms are skipped.  STORES every element of
  * grad_faces and, when grad_rgb_map and grad_textures are given, of grad_textures.  Needs weight_map / depth_map
  * when grad_rgb_map or grad_depth_map is given, rgb_map / alpha_map for their gradients; workspace as for
- * nr_backward_pixel_map.
+ * nr_backward_pixel_map.  visible_faces (optional): the forward's per-face flags; K6 builds its lists from them, and with
+ * only grad_depth_map given (no K6, no lists) the depth gather skips the faces they mark as owning no pixel.
  */
 int nr_backward_rasterize(const float *faces, const float *faces_z_ref, const int32_t *face_index_map,
                           const float *weight_map, const float *depth_map, const float *rgb_map, const float *alpha_map,

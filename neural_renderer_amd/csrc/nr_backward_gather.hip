@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
     const float *__restrict__ zbase, const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
     float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces)
+    float *__restrict__ grad_faces, const unsigned char *__restrict__ visible)
 {
     extern __shared__ __attribute__((aligned(16))) double s_tex[];  // [ts^3 * 3] texel sums of the face being walked
     __shared__ int s_list[256];
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
             gi = ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + gi] : 0;
         }
         bool big = false;
+        if (ok && !vis_list && visible && !visible[gi]) ok = false;
         if (ok) {
             const float *f = faces + (size_t)gi * 9;
             const Cand cd = face_candidates(f[0], f[1], f[3], f[4], f[6], f[7], S);
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
     const float *__restrict__ faces, const float *__restrict__ depth_map, const int32_t *__restrict__ face_index_map,
     const float *__restrict__ face_inv_map, const float *__restrict__ weight_map, const float *__restrict__ g_depth,
     float *__restrict__ grad_faces, int n_faces_total, int F, int S, const int *__restrict__ vis_list,
-    const int *__restrict__ vis_count)
+    const int *__restrict__ vis_count, const unsigned char *__restrict__ visible)
 {
     constexpr int L = 16;
     const int tid = threadIdx.x;
@@ -488,6 +489,8 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
         const int slot = gi;
         face_ok = slot < vis_count[blockIdx.y];
         gi = face_ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + slot] : 0;
+    } else if (visible && face_ok && !visible[gi]) {
+        face_ok = false;  // the forward's flags (depth-only rendering has no K6 lists): 5/6 of a mesh's faces own no pixel
     }
     float acc[9];
 #pragma unroll
@@ -626,7 +629,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     hipLaunchKernelGGL((k_backward_big<T, D>), grid, dim3(256), lds, st, face_index_map, sampling_weight_map,          \
                        sampling_index_map, (const float *)nullptr, faces, zbase, weight_map, depth_map, grad_rgb_map, \
                        grad_textures, n, F, S, ts, eps, fix, vis_list, vis_count, D ? g_depth : (const float *)nullptr, \
-                       D ? grad_faces : (float *)nullptr)
+                       D ? grad_faces : (float *)nullptr, (const unsigned char *)nullptr)
         if (st2) { if (g_depth) NR_BIG(2, true); else NR_BIG(2, false); }
         else { if (g_depth) NR_BIG(1, true); else NR_BIG(1, false); }
 #undef NR_BIG
@@ -646,18 +649,18 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
 int nr::run_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                                const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
                                float *grad_faces, int B, int F, int S, const int *vis_list, const int *vis_count,
-                               hipStream_t st)
+                               hipStream_t st, const unsigned char *visible)
 {
     if (!faces || !depth_map || !face_index_map || !weight_map || !grad_depth_map || !grad_faces) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
     const int n = B * F;
     const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
     hipLaunchKernelGGL(k_backward_depth_face, grid, dim3(256), 0, st, faces, depth_map, face_index_map, face_inv_map,
-                       weight_map, grad_depth_map, grad_faces, n, F, S, vis_list, vis_count);
+                       weight_map, grad_depth_map, grad_faces, n, F, S, vis_list, vis_count, visible);
     const dim3 grid_big = big_grid(vis_list != nullptr, B, F);
     hipLaunchKernelGGL((k_backward_big<0, true>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
                        (const int32_t *)nullptr, face_inv_map, faces, faces, weight_map, depth_map, (const float *)nullptr,
-                       (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces);
+                       (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces, visible);
     return launch_status();
 }
 
@@ -677,5 +680,5 @@ NR_API int nr_backward_depth_map(const float *faces, const float *depth_map, con
                                  float *grad_faces, int32_t B, int32_t F, int32_t S, void *stream)
 {
     return run_backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map,
-                                  grad_faces, B, F, S, nullptr, nullptr, (hipStream_t)stream);
+                                  grad_faces, B, F, S, nullptr, nullptr, (hipStream_t)stream, nullptr);
 }

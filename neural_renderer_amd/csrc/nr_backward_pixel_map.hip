@@ -1870,7 +1870,7 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
     }
     if (use_depth && !depth_done) {
         if (int rc = run_backward_depth_map(faces, depth_map, face_index_map, nullptr, weight_map, grad_depth_map,
-                                            grad_faces, B, F, S, vis_list, vis_count, st))
+                                            grad_faces, B, F, S, vis_list, vis_count, st, visible_faces))
             return rc;
     }
     return 0;

@@ -254,6 +254,6 @@ int run_backward_textures(const int32_t *face_index_map, const float *sampling_w
 int run_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                            const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
                            float *grad_faces, int B, int F, int S, const int *vis_list, const int *vis_count,
-                           hipStream_t st);
+                           hipStream_t st, const unsigned char *visible);  // visible: the forward's per-face flags or NULL
 
 }  // namespace nr

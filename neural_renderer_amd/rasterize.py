@@ -123,8 +123,9 @@ class _RasterizeFunction(torch.autograd.Function):
                 z_ref = z_ref.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if tuple(z_ref.shape) != (F, 3, 3):
                     raise ValueError('faces_z_ref must have shape (num of faces, 3, 3), got %s' % (tuple(z_ref.shape),))
-            # per-face "owns a pixel" flags: a residual the K6 pipeline of the backward starts from
-            visible = torch.empty((B, F), dtype=torch.uint8, device=dev) if (return_rgb or return_alpha) else None
+            # per-face "owns a pixel" flags: a residual the backward starts from (K6's lists; the depth-only gather skips the
+            # faces without a pixel)
+            visible = torch.empty((B, F), dtype=torch.uint8, device=dev)
             # visibility + shading behind one call (rasterize.py:499-502)
             _lib.check(lib.nr_forward_rasterize(
                 faces_c.data_ptr(), _lib.ptr(z_ref), _lib.ptr(textures_c), face_index_map.data_ptr(),
