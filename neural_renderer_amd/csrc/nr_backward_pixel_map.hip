@@ -378,6 +378,35 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *
     }
 }
 
+// the lists alone (depth-only backward: no K6, but the K8 gather still wants to visit only the faces that own a pixel)
+__global__ __launch_bounds__(VIS_CHUNK) void k_list_visible(const unsigned char *__restrict__ flags,
+                                                            int *__restrict__ vis_list, int *__restrict__ vis_count, int F,
+                                                            int n_chunks)
+{
+    __shared__ int s_wcnt[VIS_CHUNK / 64];
+    __shared__ int s_part[VIS_CHUNK / 64];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int part = 0;
+    for (int c = 0; c < chunk; ++c) part += __popcll(__ballot(flags[(size_t)b * F + c * VIS_CHUNK + tid] != 0));
+    const int fn = chunk * VIS_CHUNK + tid;
+    const bool v = fn < F && flags[(size_t)b * F + fn] != 0;
+    const unsigned long long m = __ballot(v);
+    if (lane == 0) { s_part[wave] = part; s_wcnt[wave] = __popcll(m); }
+    __syncthreads();
+    int off = 0, own = 0;
+    for (int w = 0; w < VIS_CHUNK / 64; ++w) {
+        off += s_part[w];
+        if (w < wave) off += s_wcnt[w];
+        own += s_wcnt[w];
+    }
+    if (v) vis_list[(size_t)b * F + off + __popcll(m & ((1ull << lane) - 1ull))] = fn;
+    if (chunk == n_chunks - 1 && tid == 0) {
+        int base = 0;
+        for (int w = 0; w < VIS_CHUNK / 64; ++w) base += s_part[w];
+        vis_count[b] = base + own;
+    }
+}
+
 __global__ __launch_bounds__(VIS_CHUNK) void k_count_visible(const unsigned char *__restrict__ flags,
                                                              int *__restrict__ chunk_count, int F, int n_chunks,
                                                              int *__restrict__ band_lines, int n_bands)
@@ -1859,6 +1888,17 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
     } else {
         const hipError_t e = hipMemsetAsync(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
         if (e != hipSuccess) return (int)e;
+        // depth only: no K6 and therefore no lists -- built from the forward's flags when there are any (one launch), so that
+        // the K8 gather visits the ~1/6 of the faces that own a pixel
+        const BpmLayout L = bpm_layout(B, F, S);
+        if (use_depth && visible_faces && workspace && workspace_bytes >= L.total && L.n_chunks <= SMALL_CHUNKS) {
+            unsigned char *ws = (unsigned char *)workspace;
+            int *list = (int *)(ws + L.list_off), *count = (int *)(ws + L.count_off);
+            hipLaunchKernelGGL(k_list_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, visible_faces,
+                               list, count, F, L.n_chunks);
+            vis_list = list;
+            vis_count = count;
+        }
     }
     int depth_done = 0;
     if (use_rgb && grad_textures) {
