@@ -52,23 +52,23 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 200 /* 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
+#define NR_VERSION 300 /* 0.3.0: any `near` (NR_E_NEAR removed); 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
 
 /* argument errors */
 #define NR_E_NULL (-1)      /* a required pointer is NULL */
 #define NR_E_SIZE (-2)      /* a size is out of range (B,F,S < 1, B > 65535, S > 16384, ts < 2, index overflow) */
 #define NR_E_WORKSPACE (-3) /* workspace missing or too small */
 #define NR_E_MODE (-4)      /* nothing to do / inconsistent optional arguments */
-#define NR_E_NEAR (-5)      /* near <= 0: the z-buffer packs positive depths (reference default 0.1; the reference itself accepts
-                               any near, rasterize.py:331 -- rescale the scene or pass a small positive near) */
+/* (-5 was NR_E_NEAR up to 0.2.0: `near` may be any number now, as in the reference, rasterize.py:331) */
 #define NR_E_INDEX (-6)     /* a vertex index outside [0, num_vertices) */
 
 /* flags */
 #define NR_FLAG_FIX_TEXTURE_BATCH_Z 1 /* texture sampling (K4 / K7): read the face's z from the pixel's own batch element
                                          instead of batch 0 (the reference reads batch 0: rasterize.py:389) */
 #define NR_FLAG_EXACT_GRADIENT 2      /* K6: every per-pixel term with the reference's arithmetic (IEEE division, the double
-                                         `dist +- eps`), <= 2e-6 against the exactly summed reference terms, ~1.7x the time.
-                                         Default (flag clear): float terms through v_rcp_f32, <= 1e-5 (tolerance 1e-4). */
+                                         `dist +- eps`), <= 2e-6 against the exactly summed reference terms, ~1.5x the K6 time.
+                                         Default (flag clear): float terms through v_rcp_f32; measured <= 4.2e-5 against the
+                                         same sums over the whole test suite (full-size configs included), bound 1e-4. */
 #define NR_FLAG_K6_GLOBAL 4           /* K6: force the global-memory kernel that otherwise only serves rasters whose band
                                          does not fit in LDS (a testing aid) */
 #define NR_FLAG_K6_SCAN 8             /* K6: let every band workgroup derive its lines from the image's visible-face list
@@ -96,7 +96,9 @@ const char *nr_error_string(int code);
 size_t nr_forward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_t image_size);
 
 /* Scratch needed by nr_backward_pixel_map / nr_backward_rasterize: per image the sorted list of visible faces, their edge
- * line ranges, face -> list position, and six double sums per listed face (+ the flags when visible_faces is not passed). */
+ * line ranges, face -> list position, six double sums per listed face and the band line records (+ the flags when
+ * visible_faces is not passed).  With return_rgb == return_alpha == 0 (a depth-only nr_backward_rasterize: no K6) only the
+ * lists are needed and the size is B * F * 4 bytes + a header. */
 size_t nr_backward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_t image_size,
                                    int32_t return_rgb, int32_t return_alpha);
 
@@ -105,7 +107,8 @@ size_t nr_backward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_
  * Writes EVERY element of face_index_map (-1 where empty), weight_map (0), depth_map (far) and, when
  * non-NULL, face_inv_map (0) -- the caller need not pre-fill them (the reference does, :478-496).
  * weight_map, depth_map, face_inv_map and visible_faces may each be NULL when the caller does not need them.
- * near must be > 0 (NR_E_NEAR): depths are packed as unsigned integers, which orders positive floats only.
+ * near / far may be any numbers (rasterize.py:331 pastes them as literals): depths enter the packed z-buffer through an
+ * order-preserving integer key, so near <= 0 (faces behind the camera, negative depths) behaves as in the reference.
  */
 int nr_forward_face_index_map(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map,
                               float *face_inv_map, uint8_t *visible_faces, int32_t batch_size, int32_t num_faces,

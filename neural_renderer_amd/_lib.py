@@ -53,7 +53,6 @@ NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
 NR_FLAG_EXACT_GRADIENT = 2
 NR_FLAG_K6_GLOBAL = 4
 NR_FLAG_K6_SCAN = 8
-NR_E_NEAR = -5
 NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1
 NR_CAMERA_LOOK = 2
@@ -87,8 +86,6 @@ def check(code, what):
     if code != 0:
         msg = load().nr_error_string(code)
         text = '%s failed (%d): %s' % (what, code, msg.decode() if msg else '?')
-        if code == NR_E_NEAR:
-            raise ValueError(text)
         if code == NR_E_INDEX:
             raise IndexError(text)
         raise NRError(text)

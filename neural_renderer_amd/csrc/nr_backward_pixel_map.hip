@@ -3,6 +3,7 @@
 #include "nr_device.h"
 
 #include <atomic>
+#include <mutex>
 
 using namespace nr;
 
@@ -1632,6 +1633,19 @@ BpmLayout bpm_layout(int B, int F, int S)
     return L;
 }
 
+// the depth-only backward keeps just the visible-face lists (k_list_visible): [B] counts, then [B][F] list entries
+struct ListsLayout {
+    size_t count_off, list_off, total;
+};
+ListsLayout lists_layout(int B, int F)
+{
+    ListsLayout L;
+    L.count_off = 0;
+    L.list_off = align_up((size_t)B * sizeof(int), 256);
+    L.total = L.list_off + (size_t)B * F * sizeof(int);
+    return L;
+}
+
 constexpr size_t LDS_BUDGET = 53 * 1024 + 512;  // three workgroups per 160 KB CU (two with 256-line windows: 367 vs 337 us)
 constexpr int FAST_WIN_SMALL = 128;
 
@@ -1672,15 +1686,22 @@ int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *
 // not library state: losing it would only repeat the call.)
 struct LdsLimit {
     std::atomic<size_t> granted[32];
+    std::mutex mtx;
     LdsLimit() { for (auto &g : granted) g.store(48 * 1024); }
     int ensure(const void *kern, size_t lds)
     {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 31;
-        if (lds <= granted[dev].load(std::memory_order_relaxed) && dev != 31) return 0;
-        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds <= granted[dev].load(std::memory_order_acquire) && dev != 31) return 0;
+        // hipFuncSetAttribute SETS the limit: concurrent callers must never lower it, so the call and the record are one
+        // critical section and the value passed is the maximum of what was granted and what is asked for
+        std::lock_guard<std::mutex> lock(mtx);
+        const size_t have = granted[dev].load(std::memory_order_relaxed);
+        if (lds <= have && dev != 31) return 0;
+        const size_t want = lds > have ? lds : have;
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e != hipSuccess) return (int)e;
-        granted[dev].store(lds, std::memory_order_relaxed);
+        granted[dev].store(want, std::memory_order_release);
         return 0;
     }
 };
@@ -1720,8 +1741,9 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
 
 NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32_t return_rgb, int32_t return_alpha)
 {
-    (void)return_rgb; (void)return_alpha;
     if (check_sizes(B, F, S)) return 0;
+    // depth only (no K6): nothing but the per-image lists of the faces that own a pixel, for the K8 gather
+    if (!return_rgb && !return_alpha) return lists_layout(B, F).total;
     return bpm_layout(B, F, S).total;
 }
 
@@ -1890,12 +1912,13 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
         if (e != hipSuccess) return (int)e;
         // depth only: no K6 and therefore no lists -- built from the forward's flags when there are any (one launch), so that
         // the K8 gather visits the ~1/6 of the faces that own a pixel
-        const BpmLayout L = bpm_layout(B, F, S);
-        if (use_depth && visible_faces && workspace && workspace_bytes >= L.total && L.n_chunks <= SMALL_CHUNKS) {
+        const ListsLayout L = lists_layout(B, F);
+        const int n_chunks = (F + VIS_CHUNK - 1) / VIS_CHUNK;
+        if (use_depth && visible_faces && workspace && workspace_bytes >= L.total && n_chunks <= SMALL_CHUNKS) {
             unsigned char *ws = (unsigned char *)workspace;
             int *list = (int *)(ws + L.list_off), *count = (int *)(ws + L.count_off);
-            hipLaunchKernelGGL(k_list_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, visible_faces,
-                               list, count, F, L.n_chunks);
+            hipLaunchKernelGGL(k_list_visible, dim3((unsigned)n_chunks, (unsigned)B), dim3(VIS_CHUNK), 0, st, visible_faces,
+                               list, count, F, n_chunks);
             vis_list = list;
             vis_count = count;
         }

@@ -32,13 +32,24 @@ namespace {
 //                    face_inv maps (every element, init values where no face was found, rasterize.py:478-496) and,
 //                    on request, the per-face "owns a pixel" flags that the backward's K6 pipeline starts from.
 // The packed minimum reproduces the reference's winner rule "smaller zp, ties -> lower face index" (it
-// scans faces in ascending order with a strict `<`, rasterize.py:300,334): zp > near > 0, so the float bit
-// pattern is order-preserving as an unsigned integer.  The result does not depend on the order of the
-// atomics: face_index_map is bit-reproducible.
+// scans faces in ascending order with a strict `<`, rasterize.py:300,334).  The depth goes in as the usual
+// order-preserving integer key of a float (depth_key: sign bit set for positive values, all bits flipped for
+// negative ones), so any `near` -- the reference accepts any, :331 -- orders correctly, faces behind the camera
+// (negative zp with near < 0) included.  The result does not depend on the order of the atomics:
+// face_index_map is bit-reproducible.
 constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized by k_face_raster (measured with the round-2 form of
                                   // the kernel: 128 / 64 make config 4 15 % / 28 % slower, the headline +0 / +11 %)
 constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (wave_raster); beyond, and strips: one workgroup (k_large_raster)
 constexpr unsigned long long ZEMPTY = ~0ull;
+
+// monotone float -> uint32 key: a < b  <=>  depth_key(a) < depth_key(b) for all non-NaN floats; -0 is keyed as +0 (the
+// reference's `zp < depth_min` does not tell them apart, so the lower face index must win between them).  A candidate
+// always satisfies zp < (float)far, so its key is below 0xff800000 and the packed word below ZEMPTY.
+__device__ __forceinline__ unsigned depth_key(float zp)
+{
+    const unsigned u = __float_as_uint(zp + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 struct FaceGeo {
     float x0, y0, z0, x1, y1, z1, x2, y2, z2, i0, i1, i2, i3, i4, i5, i6, i7, i8;
@@ -180,7 +191,7 @@ __device__ __forceinline__ bool slot_pixel(const FaceWaveLds<FACES> &L, int e, i
     const int x = L.x_lo[s] + (e & 255), y = L.y_lo[s] + ((e >> 8) & 255);
     float zp, w0, w1, w2;
     const bool ok = eval_inside(q, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2);
-    key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)L.fn[s];
+    key = ((unsigned long long)depth_key(zp) << 32) | (unsigned)L.fn[s];
     at = zbuf + ((size_t)L.img[s] * S + y) * S + x;
     return ok;
 }
@@ -368,7 +379,7 @@ __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu
         const int x = e & 0xffff, y = e >> 16;
         float zp, w0, w1, w2;
         if (eval_inside(g, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2))
-            atomicMin(zimg + (size_t)y * S + x, ((unsigned long long)__float_as_uint(zp) << 32) | fnu);
+            atomicMin(zimg + (size_t)y * S + x, ((unsigned long long)depth_key(zp) << 32) | fnu);
     };
     for (int base = first; base < n_cand; base += step) {  // (wave-uniform trip count)
         const int k = base + lane;
@@ -589,7 +600,6 @@ NR_API const char *nr_error_string(int code)
         case NR_E_SIZE: return "nr: size out of range";
         case NR_E_WORKSPACE: return "nr: workspace missing or too small";
         case NR_E_MODE: return "nr: nothing to do / inconsistent optional arguments";
-        case NR_E_NEAR: return "nr: near must be > 0 (the z-buffer packs positive depths; the reference default is 0.1)";
         case NR_E_INDEX: return "nr: a vertex index lies outside [0, num_vertices)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "nr: unknown error";
     }
@@ -625,7 +635,6 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
 {
     if (!faces || !face_index_map) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
-    if (!(near > 0.0)) return NR_E_NEAR;  // the packed z-buffer needs positive depths (reference default 0.1)
     const FwdLayout L = fwd_layout(B, F, S);
     if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
     const size_t n = (size_t)B * F, P = (size_t)B * S * S;

@@ -14,8 +14,9 @@ SURVEY quirk Q1 under sharding: the reference samples textures with the vertex d
 (rasterize.py:389).  A shard's element 0 is not the global one, so a sharded run with per-view cameras and non-uniform
 textures (BASELINE configs 2 and 4) would differ from the unsharded run.  `broadcast_reference_faces` ships rank 0's
 first projected view to every rank once per step (F*36 bytes: 177 KB for the teapot); passed as `Rasterize.faces_z_ref` /
-`Renderer.faces_z_ref` / `rasterize(..., faces_z_ref=)` it makes sharded and unsharded outputs and gradients identical
-bit for bit (tests/test_sharding_gpu.py).  With fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) nothing needs to be exchanged.
+`Renderer.faces_z_ref` / `rasterize(..., faces_z_ref=)` it makes sharded and unsharded images and texture gradients
+identical bit for bit and the vertex gradients identical up to the order of K6's double-precision atomics, i.e. the last
+bit of a heavily cancelling entry (tests/test_sharding_gpu.py).  With fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) nothing needs to be exchanged.
 """
 import os
 

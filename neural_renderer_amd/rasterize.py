@@ -11,6 +11,7 @@ Mirrors (reference file:line):
 There is no CPU path (the reference has none either: rasterize.py:893-897) and no eager fallback.
 """
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -33,9 +34,9 @@ if 'NEURAL_RENDERER_UNSAFE' in os.environ and int(os.environ['NEURAL_RENDERER_UN
 # attribute of a Rasterize instance) uses the pixel's own batch element.
 FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 
-# K6 (backward_pixel_map) numerics.  Default: float terms through the hardware reciprocal, <= 1e-5 from the reference's
-# terms summed exactly (north star tolerance 1e-4).  NR_EXACT_GRADIENT=1 (read once, here) or the `exact_gradient`
-# attribute of a Rasterize instance: every term with the reference's own arithmetic, <= 2e-6, ~1.7x the K6 time.
+# K6 (backward_pixel_map) numerics.  Default: float terms through the hardware reciprocal, measured <= 4.2e-5 from the
+# reference's terms summed exactly (tests bound it by the north star's 1e-4).  NR_EXACT_GRADIENT=1 (read once, here) or the
+# `exact_gradient` attribute of a Rasterize instance: every term with the reference's own arithmetic, <= 2e-6, ~1.5x the K6 time.
 EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
 
 
@@ -133,7 +134,12 @@ class _RasterizeFunction(torch.autograd.Function):
                 _lib.ptr(background), bg_per_batch, B, F, S, ts, float(cfg['near']), float(cfg['far']),
                 float(cfg['eps']), flags, workspace.data_ptr(), ws_bytes, stream), 'nr_forward_rasterize')
 
-        ctx.cfg = dict(cfg, B=B, F=F, S=S, ts=ts, flags=flags)
+        ctx.cfg = dict(cfg, keep=None, B=B, F=F, S=S, ts=ts, flags=flags)
+        keep = cfg.get('keep')
+        if keep is not None:  # the maps the reference leaves on the Function instance (rasterize.py:39-58); no copies
+            keep.update(faces=faces_c, textures=textures_c, face_index_map=face_index_map, weight_map=weight_map,
+                        depth_map=depth_map, rgb_map=rgb_map, alpha_map=alpha_map, batch_size=B, num_faces=F,
+                        texture_size=ts if return_rgb else None)
         ctx.z_ref = z_ref
         ctx.visible = visible
         ctx.set_materialize_grads(False)  # an unused output arrives as `None` in backward and its terms are skipped
@@ -181,6 +187,10 @@ class _RasterizeFunction(torch.autograd.Function):
                 _lib.ptr(g_depth) if use_depth else None, grad_faces.data_ptr(), _lib.ptr(grad_textures),
                 B, F, S, ts, float(cfg['eps']), cfg['flags'], _lib.ptr(ctx.visible), workspace.data_ptr(), ws_bytes,
                 stream), 'nr_backward_rasterize')
+        owner = cfg['owner']() if cfg.get('owner') is not None else None
+        if owner is not None:  # rasterize.py:41-51: the gradient buffers stay readable on the instance
+            owner.grad_rgb_map, owner.grad_alpha_map, owner.grad_depth_map = g_rgb, g_alpha, g_depth
+            owner.grad_faces, owner.grad_textures = grad_faces, grad_textures
         return grad_faces, grad_textures, None
 
 
@@ -253,10 +263,20 @@ class Rasterize(object):
         # [F,3,3] faces of the global batch element 0 when this call renders a shard of a larger batch (SURVEY Q1:
         # the reference samples textures with batch element 0's depths); None = element 0 of this call
         self.faces_z_ref = None
-        self.face_index_map = None
+        # buffers of the last call, as on the reference's Function (rasterize.py:39-64).  The reference also keeps
+        # face_inv_map and the two sampling maps; here they are recomputed inside the backward kernels instead of being
+        # stored, so those three attributes stay None.
+        self.faces = self.textures = None
+        self.grad_rgb_map = self.grad_alpha_map = self.grad_depth_map = None
+        self.rgb_map = self.alpha_map = self.depth_map = None
+        self.grad_faces = self.grad_textures = None
+        self.face_index_map = self.weight_map = None
+        self.face_inv_map = self.sampling_index_map = self.sampling_weight_map = None
+        self.batch_size = self.num_faces = self.texture_size = None
 
     def __call__(self, faces, textures=None):
-        cfg = dict(image_size=self.image_size, near=self.near, far=self.far, eps=self.eps,
+        keep = {}
+        cfg = dict(keep=keep, owner=weakref.ref(self), image_size=self.image_size, near=self.near, far=self.far, eps=self.eps,
                    background_color=self.background_color if self.background_color is not None
                    else DEFAULT_BACKGROUND_COLOR,
                    return_rgb=bool(self.return_rgb), return_alpha=bool(self.return_alpha),
@@ -265,6 +285,8 @@ class Rasterize(object):
         if not self.return_rgb:
             textures = None
         rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg)
+        for k, v in keep.items():
+            setattr(self, k, v)
         self.face_index_map = fi
         return rgb, alpha, depth
 

@@ -71,7 +71,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_host_only_entry_points(lib_path):
     lib = _lib.load()
-    assert lib.nr_version() == 200
+    assert lib.nr_version() == 300
     assert lib.nr_error_string(0) == b'success'
     assert b'workspace' in lib.nr_error_string(-3)
     assert lib.nr_forward_workspace_bytes(64, 4928, 256) >= 64 * 256 * 256 * 8 + 64 * 4928 * 4
@@ -86,9 +86,9 @@ def test_argument_errors_do_not_need_a_gpu(lib_path):
     assert lib.nr_backward_depth_map(None, None, None, None, None, None, None, 1, 1, 8, None) == -1
     assert lib.nr_forward_texture_sampling(None, None, None, 1, None, None, None, None, None, None, 0, None,
                                            1, 1, 8, 2, 1e-3, 0, None) == -4
-    # near <= 0 has its own code and message (the packed z-buffer needs positive depths)
-    assert lib.nr_forward_face_index_map(1, 1, None, None, None, None, 1, 1, 8, 0.0, 100.0, None, 0, None) == -5
-    assert b'near' in lib.nr_error_string(-5)
+    # near <= 0 is accepted like in the reference (rasterize.py:331): the call gets as far as the workspace check
+    assert lib.nr_forward_face_index_map(1, 1, None, None, None, None, 1, 1, 8, 0.0, 100.0, None, 0, None) == -3
+    assert lib.nr_forward_face_index_map(1, 1, None, None, None, None, 1, 1, 8, -1.0, 100.0, None, 0, None) == -3
 
 
 def test_cpu_tensors_are_refused():

@@ -127,6 +127,36 @@ def test_edge_cases_forward(S):
     check_forward(fw, fn)
 
 
+@pytest.mark.parametrize('near,far', [(0, 100), (0.0, 2.5), (-1, 100), (-1.5, -0.25), (-100, 1.5)])
+def test_near_zero_and_negative_like_the_reference(near, far):
+    """The reference accepts any `near` (rasterize.py:331 pastes it as a literal): near = 0 and negative near planes, with
+    faces behind the camera (negative depths, drawn when near < 0), faces straddling the camera plane (1 / (w0/z0 + ..) of
+    mixed signs: huge, infinite or NaN depths) and a z-fight between +0-ish depths.  The packed z-buffer orders depths
+    through a monotone integer key, so every map must agree with the oracle bit for bit, and so must the gradients'
+    NaN pattern / values."""
+    rng = np.random.default_rng(31)
+    faces = edge_case_scene(rng, B=2, F=120)
+    faces[:, 20:40, :, 2] = -rng.uniform(0.3, 3.0, (2, 20, 3)).astype(np.float32)       # behind the camera
+    faces[:, 40:50, 0, 2] *= -1.0                                                        # straddling the camera plane
+    faces[:, 50:55, :, 2] = rng.uniform(1e-30, 1e-20, (2, 5, 3)).astype(np.float32)      # depths just above zero
+    faces[:, 55:60, :, 2] = -rng.uniform(1e-30, 1e-20, (2, 5, 3)).astype(np.float32)     # ... and just below
+    textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    for S in (32, 67):
+        fn = oracle_forward(faces, textures, S, near, far, 1e-3, (0.3, 0.2, 0.1), True, True, True)
+        fw = abi.forward(faces, textures, S, float(near), float(far), 1e-3, (0.3, 0.2, 0.1), 0, True, True, True,
+                         want_face_inv=True)
+        fi = abi.host(fw['face_index_map'])
+        assert int((fi != fn.face_index_map).sum()) == 0
+        for name in ('weight_map', 'depth_map', 'face_inv_map', 'rgb_map', 'alpha_map'):
+            np.testing.assert_array_equal(abi.host(fw[name]), getattr(fn, name), err_msg=name)  # (NaN == NaN here)
+    if near < 0 and far > 0:
+        assert (fn.depth_map < 0).any() and (fn.depth_map > 0).any()  # both sides of the camera were drawn
+    # gradients on the well-conditioned part of the scene (no straddling faces: their depths are +-inf / NaN)
+    faces[:, 40:50, 0, 2] *= -1.0
+    faces[:, 50:60, :, 2] = np.abs(faces[:, 50:60, :, 2]) + 1.0
+    check_backward(faces, textures, 48, 1e-3, (True, True, True), seed=32, near=near, far=far)
+
+
 def test_single_face_and_empty_image():
     one = np.array([[[[0.8, 0.8, 1.], [0.0, -0.5, 1.], [0.2, -0.4, 1.]]]], np.float32)
     for faces in (one, one[:, :, ::-1].copy()):  # front-facing / back-facing only (empty image)
@@ -195,11 +225,12 @@ def grads_for(fn, rng, rgb=True, alpha=True, depth=True):
     return g_rgb, g_alpha, g_depth
 
 
-def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts_bg=(0.2, 0.4, 0.6), k6_flags=0):
+def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts_bg=(0.2, 0.4, 0.6), k6_flags=0, near=0.1,
+                   far=100):
     rgb, alpha, depth = modes
     rng = np.random.default_rng(seed)
-    fn = oracle_forward(faces, textures, S, 0.1, 100, eps, ts_bg, rgb, alpha, depth)
-    fw = abi.forward(faces, textures, S, 0.1, 100.0, eps, ts_bg, 0, rgb, alpha, depth,
+    fn = oracle_forward(faces, textures, S, near, far, eps, ts_bg, rgb, alpha, depth)
+    fw = abi.forward(faces, textures, S, float(near), float(far), eps, ts_bg, 0, rgb, alpha, depth,
                      want_face_inv=residual_maps and depth, want_sampling=residual_maps and rgb)
     check_forward(fw, fn)
     # the forward's per-face flags: exactly the faces that own a pixel
@@ -383,8 +414,11 @@ def test_known_answer_gradients_through_renderer():
 
 
 def test_determinism_and_batch_independence():
-    """Run twice -> identical bits (no atomics in forward / K6); a view rendered inside a batch equals the same
-    view rendered alone (the property the multi-GPU sharding relies on)."""
+    """Run twice -> identical forward bits (the packed z-buffer minimum does not depend on the order of its atomics); a view
+    rendered inside a batch equals the same view rendered alone (the property the multi-GPU sharding relies on).
+    K6 sums its per-line / per-face partials with double-precision atomics whose order is not fixed: grad_faces is
+    reproducible up to the rounding of a double sum to float (a last-bit difference in rare, heavily cancelling entries),
+    so the gradients are compared to 1e-6 of the largest one, not bit for bit."""
     faces, _ = H.teapot_views(8, 128)
     rng = np.random.default_rng(13)
     g = rng.normal(size=(8, 128, 128)).astype(np.float32)
@@ -393,13 +427,14 @@ def test_determinism_and_batch_independence():
         fw = abi.forward(faces, None, 128, return_alpha=True, return_depth=True)
         gf, _ = abi.backward(fw, g_alpha=g)
         outs.append((abi.host(fw['face_index_map']), abi.host(fw['depth_map']), abi.host(gf)))
-    for a, b in zip(*outs):
+    for a, b in list(zip(*outs))[:2]:
         np.testing.assert_array_equal(a, b)
+    assert H.rel_err(outs[0][2], outs[1][2]) <= 1e-6
     fw1 = abi.forward(faces[5:6], None, 128, return_alpha=True, return_depth=True)
     gf1, _ = abi.backward(fw1, g_alpha=g[5:6])
     np.testing.assert_array_equal(abi.host(fw1['face_index_map'])[0], outs[0][0][5])
     np.testing.assert_array_equal(abi.host(fw1['depth_map'])[0], outs[0][1][5])
-    np.testing.assert_array_equal(abi.host(gf1)[0], outs[0][2][5])
+    assert H.rel_err(abi.host(gf1)[0], outs[0][2][5]) <= 1e-6
 
 
 def test_headline_size_properties():

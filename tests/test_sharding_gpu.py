@@ -1,7 +1,7 @@
 """`-m gpu`: the batch-of-views sharding of the multi-GPU path is result-preserving under the reference-literal Q1 behaviour
 (textures are sampled with the vertex depths of batch element 0, rasterize.py:389): 8 views with per-view cameras and
 random textures rendered as one batch and as two shards of 4 -- each shard handed the global element 0's faces as
-`faces_z_ref` -- give identical bits for rgb, grad_textures and grad_faces.  Without the hand-over the second shard differs
+`faces_z_ref` -- give identical bits for rgb and grad_textures and the same grad_faces up to the order of K6's double atomics.  Without the hand-over the second shard differs
 (the test would notice a kernel that ignores the pointer), with fix_batch_z nothing needs to be handed over."""
 import numpy as np
 import pytest
@@ -31,12 +31,23 @@ def _run_abi(faces, textures, g_rgb, g_alpha, z_ref, flags=0):
     return abi.host(fw['rgb_map']), abi.host(gf), abi.host(gt)
 
 
+def _same(parts, full, names):
+    """Shards == batch: bit for bit for the images and grad_textures (atomic-free kernels); grad_faces consists of the same
+    per-pixel terms either way, but K6 adds its per-line partial sums with double-precision atomics whose order is not fixed,
+    so the float it rounds to may differ in the last bit for a heavily cancelling entry: compared to 1e-6 of the largest."""
+    for k, name in enumerate(names):
+        got = np.concatenate((parts[0][k], parts[1][k]))
+        if name == 'grad_faces':
+            assert H.rel_err(got, full[k]) <= 1e-6, name
+        else:
+            np.testing.assert_array_equal(got, full[k], err_msg=name)
+
+
 def test_two_shards_equal_one_batch_through_the_c_abi():
     faces, textures, g_rgb, g_alpha = _scene()
     full = _run_abi(faces, textures, g_rgb, g_alpha, None)
     parts = [_run_abi(faces[s], textures[s], g_rgb[s], g_alpha[s], faces[0]) for s in (slice(0, 4), slice(4, 8))]
-    for k, name in enumerate(('rgb_map', 'grad_faces', 'grad_textures')):
-        np.testing.assert_array_equal(np.concatenate((parts[0][k], parts[1][k])), full[k], err_msg=name)
+    _same(parts, full, ('rgb_map', 'grad_faces', 'grad_textures'))
     # sensitivity: a shard that samples with ITS OWN first view's depths is a different (wrong) result ...
     alone = _run_abi(faces[4:], textures[4:], g_rgb[4:], g_alpha[4:], None)
     assert np.abs(alone[0] - full[0][4:]).max() > 1e-3
@@ -71,5 +82,4 @@ def test_two_shards_equal_one_batch_through_the_operator():
     # what rank 0 would broadcast (single process: the helper returns its own first view)
     z_ref = nrd.broadcast_reference_faces(torch.tensor(faces[:4], device='cuda'))
     parts = [run(slice(0, 4), z_ref), run(slice(4, 8), z_ref)]
-    for k, name in enumerate(('rgb', 'grad_faces', 'grad_textures')):
-        np.testing.assert_array_equal(np.concatenate((parts[0][k], parts[1][k])), full[k], err_msg=name)
+    _same(parts, full, ('rgb', 'grad_faces', 'grad_textures'))
