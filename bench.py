@@ -108,6 +108,23 @@ def algorithmic_bytes(B, F, S, ts):
     }
 
 
+def coverage_scaled_bytes(B, F, S, ts, covered, visible):
+    """The same figures with the terms a kernel rightly skips scaled down: weight / depth / gradient reads happen only on
+    the `covered` fraction of the pixels (12 % of a teapot view), texture reads only for the `visible` fraction of the faces.
+    A per-stage fraction of the HBM peak must be priced with THESE bytes (the unscaled figure put k_shade at 0.96 of the
+    8 TB/s spec peak, above what the part can deliver); K6 stages whole image bands and the visibility pass writes every
+    element, so their figures do not change."""
+    P, N = B * S * S, B * F
+    c, v = covered, visible
+    return {
+        'forward_face_index_map': N * 36 + P * (4 + 12 + 4),
+        'forward_texture_sampling': P * 4 + c * P * (12 + 4) + v * N * 12 * ts ** 3 + P * (12 + 4),
+        'backward_pixel_map': P * (4 + 12 + 4 + 12 + 4) + N * 72,
+        'backward_textures': P * 4 + c * P * (12 + 4 + 12) + N * 24 * ts ** 3,
+        'backward_depth_map': P * 4 + c * P * (12 + 4 + 4) + N * 72,
+    }
+
+
 def whole_step_bytes(B, F, S, ts):
     """SURVEY 8d 'Algorithmic bytes' for one Rasterize fwd+bwd with rgb + alpha + depth: forward writes rgb 12 + alpha 4 +
     depth 4 + face_index 4 + weight 12, backward reads the three gradients 20, rgb 12, alpha 4 and the residuals 20:
@@ -219,6 +236,47 @@ def renderer_end_to_end(device, batch, first_view, total_views, image_size, text
            'frontend': r.last_frontend, 'frontend_calls': dict(r.frontend_calls)}
     # the fused HIP front-end must be what ran: the module-by-module torch path is ~160 launches slower
     assert r.frontend_calls['torch'] == 0 and r.last_frontend == 'fused', r.frontend_calls
+    return out
+
+
+def measure_time_protocol(device, batch_size, image_size=256, texture_size=2):
+    """The reference's own timing protocol (misc/measure_time.py:12-18, 44-90) through the public Renderer with ITS
+    defaults (anti-aliasing on => raster 2 x image_size, eye from get_points_from_angles(2.732, 30, azimuth)): 24 azimuths,
+    `render_silhouettes` then `render`, forward (to the first pixel on the host) and backward of sum(images) timed
+    separately, first iteration dropped.  The reference stops its backward clock without synchronising (Q9: it times the
+    launch); here the clock stops after a device synchronize.  Milliseconds."""
+    import neural_renderer_amd as nr
+    v, f = load_teapot()
+    vertices = torch.from_numpy(v).to(device)[None].repeat(batch_size, 1, 1).requires_grad_(True)
+    faces = torch.from_numpy(f).to(device)[None].repeat(batch_size, 1, 1)
+    textures = torch.ones((batch_size, f.shape[0], texture_size, texture_size, texture_size, 3), device=device,
+                          requires_grad=True)
+    renderer = nr.Renderer()
+    renderer.image_size = image_size
+    out = {'batch_size': batch_size, 'image_size': image_size, 'raster': 2 * image_size if renderer.anti_aliasing else image_size,
+           'anti_aliasing': bool(renderer.anti_aliasing)}
+    for name, call in (('silhouette', lambda: renderer.render_silhouettes(vertices, faces)),
+                       ('texture', lambda: renderer.render(vertices, faces, textures))):
+        tf, tb = [], []
+        for azimuth in range(0, 360, 15):
+            renderer.eye = nr.get_points_from_angles(2.732, 30, azimuth)
+            vertices.grad = None
+            textures.grad = None
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            images = call()
+            _ = images.reshape(-1)[0].item()
+            t1 = time.perf_counter()
+            loss = images.sum()
+            _ = loss.item()
+            t2 = time.perf_counter()
+            loss.backward()
+            torch.cuda.synchronize(device)
+            t3 = time.perf_counter()
+            tf.append(t1 - t0)
+            tb.append(t3 - t2)
+        out['%s_forward_ms' % name] = float(np.mean(tf[1:]) * 1e3)
+        out['%s_backward_ms' % name] = float(np.mean(tb[1:]) * 1e3)
     return out
 
 
@@ -357,7 +415,7 @@ def main():
     from neural_renderer_amd import distributed as nrd
     _, _, dev = nrd.init_from_env()  # one process per GPU; backend "nccl" = RCCL
     dist = None
-    if world > 1:
+    if world > 1 or nrd._force():  # NR_DIST_FORCE=1: one rank, but through RCCL all the same (tests/test_rccl_gpu.py)
         import torch.distributed as dist
 
     import neural_renderer_amd as nr
@@ -368,15 +426,15 @@ def main():
     textures.requires_grad_(True)
     g_rgb, g_alpha, g_depth = upstream_gradients(faces, textures, S, eps, 1234 + rank)
 
-    gather = args.gather and world > 1
+    gather = args.gather and dist is not None
     last = {}
 
-    def make_step(f, t, size, grads, with_gather=False):
+    def make_step(f, t, size, grads, with_gather=False, exact=None):
         def step():
             f.grad = None
             t.grad = None
             fn = nr.Rasterize(size, 0.1, 100, eps, (0, 0, 0), True, True, True)
-            fn.exact_gradient = args.exact
+            fn.exact_gradient = args.exact if exact is None else exact
             rgb, alpha, depth = fn(f, t)
             if with_gather:  # the downstream loss wants the whole batch: one all-gather of the rendered shards (RCCL / xGMI)
                 last['gathered'] = nrd.all_gather_images(rgb.detach(), total=world * B)
@@ -399,14 +457,23 @@ def main():
         from neural_renderer_amd.graph import capture
         run, mode = capture(step, dev), 'hipgraph'
 
+    # Timing protocol: all ranks leave a barrier + device synchronize together, each times ITS OWN K steps up to its own
+    # device synchronize (wall clock, and HIP events on the launch stream as a cross-check), then a second barrier closes the
+    # bracket and the MAX over ranks is reduced.  The closing barrier is not inside the timed region: on RCCL it costs tens to
+    # hundreds of microseconds, which would be charged to every N > 1 point of an 8.8 ms measurement.
     for _ in range(args.warmup):
         run()
     barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         run()
-    barrier()
+    ev1.record()
+    torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    event_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    barrier()
     eager_ms = None
     if mode == 'hipgraph':  # also report the eager number
         eager_ms = time_step(local_step, dev, args.steps, 2)
@@ -450,6 +517,19 @@ def main():
                 'frac': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
+        fi_map = last['fi']
+        covered = float((fi_map >= 0).float().mean().item())
+        visible = float(torch.stack([torch.bincount(fi_map[b][fi_map[b] >= 0].flatten().long(), minlength=F) > 0
+                                     for b in range(B)]).float().mean().item())
+        scaled = coverage_scaled_bytes(B, F, S, ts, covered, visible)
+        roofline['stages'] = {
+            'covered_pixel_fraction': covered, 'visible_face_fraction': visible,
+            'per_stage': {k: {'avg_launch_us': stages[k], 'algorithmic_bytes': stage_bytes[k], 'coverage_scaled_bytes': scaled[k],
+                              'achieved_GBps': scaled[k] / (stages[k] * 1e-6) / 1e9,
+                              'frac': scaled[k] / (stages[k] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              'hbm_bytes_from_profiles': prof.get(k, {}).get('hbm_bytes_per_launch')} for k in stage_bytes},
+            'note': 'frac of each stage call priced with coverage-scaled compulsory bytes (reads the kernels rightly skip on '
+                    'uncovered pixels / invisible faces are not counted)'}
         valu = prof.get('_valu_issue', {})
         if valu.get('insts_valu_per_launch'):
             floor_us = valu['insts_valu_per_launch'] * NS_PER_WAVE_INSTR / NUM_SIMDS * 1e-3
@@ -473,6 +553,10 @@ def main():
             ms3 = time_step(make_step(faces, textures, S, ones), dev, args.steps, 2)
             extra_rows.append({'row': 'all-ones upstream gradient (reference misc/measure_time.py:60)', 'ms_per_step': ms3,
                                'mpixel_per_s_raster': B * S * S / (ms3 * 1e-3) / 1e6})
+            if not args.exact:  # the bit-faithful K6 mode on the headline batch (NR_FLAG_EXACT_GRADIENT)
+                ms5 = time_step(make_step(faces, textures, S, (g_rgb, g_alpha, g_depth), exact=True), dev, args.steps, 2)
+                extra_rows.append({'row': 'headline step with NR_FLAG_EXACT_GRADIENT (K6 with the reference\'s own arithmetic per term)',
+                                   'ms_per_step': ms5, 'mpixel_per_s_raster': B * S * S / (ms5 * 1e-3) / 1e6})
             try:  # the same step replayed from a captured HIP graph: what the ~15 launches and allocations cost the host
                 from neural_renderer_amd.graph import capture
                 ms4 = time_step(capture(local_step, dev), dev, args.steps, 2)
@@ -481,6 +565,10 @@ def main():
             except Exception as ex:  # pragma: no cover
                 extra_rows.append({'row': 'hip graph capture failed: %s' % ex, 'ms_per_step': float('nan')})
             e2e = renderer_end_to_end(dev, B, rank * B, world * B, S, ts)
+            e2e['reference_protocol'] = {
+                'what': 'misc/measure_time.py:12-18, 44-90 through Renderer() with the reference defaults (anti_aliasing on: raster 512 '
+                        'for image_size 256); forward and backward of sum(images) timed separately, ms, mean of 23 azimuths',
+                'rows': [measure_time_protocol(dev, 1), measure_time_protocol(dev, B)]}
         cpu = None
         if args.cpu_sample_views > 0 and world == 1:
             cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
@@ -489,6 +577,8 @@ def main():
             'metric': 'rasterize fwd+bwd Mpixels/sec @256x256 batch=64', 'value': value, 'unit': 'Mpixel/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'data_note': 'synthetic cameras, textures and upstream gradients; the mesh is the reference\'s teapot.obj (embedded in '
+                         'tests/golden/reference_fixtures.npz), as BASELINE.json names it',
             'config': {
                 'workload': 'teapot.obj (2464 faces, fill_back -> %d), %d azimuth views per GPU, raster %dx%d '
                             '(anti_aliasing off), texture_size %d, rgb+alpha+depth forward + backward through the '
@@ -500,6 +590,10 @@ def main():
             },
             'roofline': roofline, 'cpu_baseline': cpu, 'stages_us': stages, 'grad_check': check,
             'extra_rows': extra_rows, 'launch_mode': mode, 'eager_ms_per_step': eager_ms, 'renderer_end_to_end': e2e,
+            'timing': {'protocol': 'barrier + synchronize | K steps timed per rank up to its own synchronize (wall clock) | barrier; '
+                                   'MAX over ranks; no collective inside the timed region' + (' except the requested all_gather' if gather else ''),
+                       'rank0_hip_event_ms_per_step': event_ms_per_step,
+                       'backend': (dist.get_backend() if dist is not None else None)},
         }
         print(json.dumps(line))
     if dist is not None:

@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(HERE, 'libnr_hip.so')
 HIPCC_FLAGS = [
     '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
     '-fhip-fp32-correctly-rounded-divide-sqrt', '-munsafe-fp-atomics', '-fno-fast-math',
+    # no SLP vectorisation: it turns the unrolled per-pixel arithmetic of the K6 sweeps into v_pk_* operations glued
+    # together with register moves -- packed FP32 issues at half rate on this part, so that only costs
+    '-fno-slp-vectorize',
     '-fPIC', '-shared', '-fvisibility=hidden',
 ]
 
@@ -45,12 +48,12 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
-def build_variant(tag, defines, verbose=False):
+def build_variant(tag, defines, verbose=False, sources=None, flags=None):
     """Development aid: the same sources with extra -D macros into libnr_hip_<tag>.so, so that one GPU session can time
     alternatives of a kernel side by side (scripts pick the library through the NR_HIP_LIB environment variable, read by
     neural_renderer_amd._lib -- the library itself reads no environment).  Not used by the product."""
     out = os.path.join(HERE, 'libnr_hip_%s.so' % tag)
-    cmd = [hipcc()] + HIPCC_FLAGS + ['-D%s' % d for d in defines] + SOURCES + ['-o', out]
+    cmd = [hipcc()] + (flags or HIPCC_FLAGS) + ['-D%s' % d for d in defines] + (sources or SOURCES) + ['-o', out]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

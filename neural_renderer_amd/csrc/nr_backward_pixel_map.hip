@@ -984,13 +984,54 @@ __device__ __forceinline__ BandLine make_fast_line(const float *__restrict__ fv,
     return fast_line_finish(h, ld, S, rfn, tgt, h.live ? owner_of(h.d1_in) : -1);
 }
 
-// per-line packed segment counts: full segments in the low 16 bits, partial ones above
-__device__ __forceinline__ int line_segments(int in_rng, int out_rng)
+// Segment classes of the default kernel (k_bpm_fast).  Class F ("full out"): exactly SEG pixels of an OUT sweep -- 93 % of all
+// visits lie in out sweeps, three quarters of them in such pieces -- walked by a loop that is unrolled over its 15 pixels
+// (compile-time LDS offsets, no loop bookkeeping), has no ownership test (:707 applies to the in sweep only) and takes the
+// sign of `+- eps` once per segment: t = d1 - d1_cross keeps its sign beyond the crossing point, and so does c * t.
+// Class G: everything else -- the pieces (<= SEG pixels) of the in sweeps and the remainder of the out sweep -- walked by the
+// general loop.  Packed counts: F in the low 16 bits, G above (<= S / SEG + 2 per line).
+__device__ __forceinline__ int line_segments_fast(int in_rng, int out_rng)
 {
     const int il = (in_rng >> 16) - (in_rng & 0xffff) + 1, ol = (out_rng >> 16) - (out_rng & 0xffff) + 1;
-    const int full = (il > 0 ? il / SEG : 0) + (ol > 0 ? ol / SEG : 0);
-    const int part = (il > 0 && il % SEG != 0) + (ol > 0 && ol % SEG != 0);
-    return full | (part << 16);
+    const int full = ol > 0 ? ol / SEG : 0;
+    const int gen = (il > 0 ? (il + SEG - 1) / SEG : 0) + (ol > 0 && ol % SEG != 0);
+    return full | (gen << 16);
+}
+
+__device__ __forceinline__ SegRange decode_segment_fast(int sid, int total_full, int n_win, const int *s_pref,
+                                                        const int *line_words /* BandLine array */, int stride_words)
+{
+    SegRange r;
+    const bool is_full = sid < total_full;
+    const int id = is_full ? sid : sid - total_full;
+    const int shift = is_full ? 0 : 16;
+    int lo = 0, hi = n_win - 1;  // last line whose prefix (of this class) is <= id
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (((s_pref[mid] >> shift) & 0xffff) <= id) lo = mid; else hi = mid - 1;
+    }
+    r.line = lo;
+    const int in_rng = line_words[lo * stride_words], out_rng = line_words[lo * stride_words + 1];
+    const int k = id - ((s_pref[lo] >> shift) & 0xffff);
+    const int out_from = out_rng & 0xffff, out_to = out_rng >> 16;
+    if (is_full) {
+        r.mode_in = false;
+        r.s_from = out_from + k * SEG;
+        r.s_to = r.s_from + SEG - 1;
+    } else {
+        const int in_from = in_rng & 0xffff, in_to = in_rng >> 16;
+        const int il = in_to - in_from + 1;
+        const int n_in = il > 0 ? (il + SEG - 1) / SEG : 0;
+        r.mode_in = k < n_in;
+        if (r.mode_in) {
+            r.s_from = in_from + k * SEG;
+            r.s_to = min(r.s_from + SEG - 1, in_to);
+        } else {
+            r.s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG;
+            r.s_to = out_to;
+        }
+    }
+    return r;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1240,6 +1281,8 @@ struct FastPx {  // LDS pixel data of a band, [line][d1]
     float *g;    // gradients (g_alpha, g_r, g_g, g_b) -- or g_alpha alone
     float *c;    // colours   (alpha, r, g, b)         -- or alpha alone
     float *bg;   // colour of the band's uncovered pixels
+    unsigned *cov;  // coverage bits [line][CW words]: bit d1 & 31 of word d1 >> 5 set <=> a face owns pixel (line, d1)
+    int CW;         // words per line
 };
 
 template <bool RGB, bool ALPHA>
@@ -1249,7 +1292,10 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
                                            int axis, int band_lo, int nld, int S, int SP)
 {
     const int tid = threadIdx.x;
-    auto put = [&](int l, int fi, float al, float ga, float r, float g, float bl, float gr, float gg, float gb) {
+    // pixel d1 of band line ld.  The coverage bits (px.cov, zeroed by the caller before the barrier in front of this
+    // function) let the out sweeps skip the face index: only the covered eighth of the pixels issues the atomic.
+    auto put = [&](int ld, int d1, int fi, float al, float ga, float r, float g, float bl, float gr, float gg, float gb) {
+        const int l = ld * SP + d1;
         px.fi[l] = fi;
         if (RGB) {
             *reinterpret_cast<float4 *>(px.g + 4 * (size_t)l) = make_float4(ga, gr, gg, gb);
@@ -1260,10 +1306,12 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
             px.c[l] = al;
             if (fi < 0) px.bg[0] = al;
         }
+        if (fi >= 0) atomicOr(px.cov + ld * px.CW + (d1 >> 5), 1u << (d1 & 31));
     };
     // four adjacent pixels of a map row with one 16-byte load per field: the 4 columns of a vertical band (one thread per
-    // row) or 4 consecutive pixels of a horizontal band's line (one thread per quad); `l0 + j * lstep` is pixel j's LDS slot
-    auto put_quad = [&](size_t g, int l0, int lstep) {
+    // row; pixel j -> line j, d1 = y) or 4 consecutive pixels of a horizontal band's line (one thread per quad; pixel j ->
+    // line ld, d1 = x + j)
+    auto put_quad = [&](size_t g, int ld0, int d10, int ld_step, int d1_step) {
         const int4 vf = *reinterpret_cast<const int4 *>(fi_map + g);
         float4 va = make_float4(0, 0, 0, 0), vg = va;
         if (ALPHA) {
@@ -1286,14 +1334,14 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
         const float als[4] = {va.x, va.y, va.z, va.w}, gas[4] = {vg.x, vg.y, vg.z, vg.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            put(l0 + j * lstep, fis[j], als[j], gas[j], rr[3 * j], rr[3 * j + 1], rr[3 * j + 2], qq[3 * j], qq[3 * j + 1],
-                qq[3 * j + 2]);
+            put(ld0 + j * ld_step, d10 + j * d1_step, fis[j], als[j], gas[j], rr[3 * j], rr[3 * j + 1], rr[3 * j + 2], qq[3 * j],
+                qq[3 * j + 1], qq[3 * j + 2]);
     };
     if (axis && (S & 3) == 0) {  // a band line is an image row: thread -> (line, quad of 4 consecutive pixels)
         const int quads = S >> 2;
         for (int i = tid; i < nld * quads; i += BAND_THREADS) {
             const int ld = i / quads, x = (i - ld * quads) << 2;
-            put_quad(img + (size_t)(band_lo + ld) * S + x, ld * SP + x, 1);
+            put_quad(img + (size_t)(band_lo + ld) * S + x, ld, x, 0, 1);
         }
     } else if (axis) {  // thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
         for (int i = tid; i < nld * S; i += BAND_THREADS) {
@@ -1305,10 +1353,10 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
                 r = rgb_map[3 * g]; gn = rgb_map[3 * g + 1]; bl = rgb_map[3 * g + 2];
                 gr = g_rgb[3 * g]; gg = g_rgb[3 * g + 1]; gb = g_rgb[3 * g + 2];
             }
-            put(ld * SP + x, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
+            put(ld, x, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
         }
     } else if (nld == 4 && (S & 3) == 0) {  // 4 adjacent columns: one thread per row
-        for (int y = tid; y < S; y += BAND_THREADS) put_quad(img + (size_t)y * S + band_lo, y, SP);
+        for (int y = tid; y < S; y += BAND_THREADS) put_quad(img + (size_t)y * S + band_lo, 0, y, 1, 0);
     } else {  // generic columns: thread -> (row d1, line ld) with ld fastest
         for (int i = tid; i < nld * S; i += BAND_THREADS) {
             const int d1 = i / nld, ld = i - d1 * nld;
@@ -1319,22 +1367,27 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
                 r = rgb_map[3 * g]; gn = rgb_map[3 * g + 1]; bl = rgb_map[3 * g + 2];
                 gr = g_rgb[3 * g]; gg = g_rgb[3 * g + 1]; gb = g_rgb[3 * g + 2];
             }
-            put(ld * SP + d1, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
+            put(ld, d1, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
         }
     }
 }
 
-// Step 4 for the n_win line records in s_line (their packed segment counts already scanned into s_pref): one segment per
-// thread.  The two sums of a segment go to acc[acc_index(line, k)] (ds_add_f64), k = 0 / 1 for the edge's first / second
-// vertex; acc_index returns a negative value for "no LDS slot" and spill() then takes the sum.
+// Step 4 for the n_win line records in s_line (their packed segment counts, line_segments_fast, already scanned into s_pref):
+// one segment per thread.  The two sums of a segment go to acc[acc_index(line, k)] (ds_add_f64), k = 0 / 1 for the edge's
+// first / second vertex; acc_index returns a negative value for "no LDS slot" and spill() then takes the sum.
+#ifndef NR_K6_FB
+#define NR_K6_FB 3  // pixels of a class-F segment whose LDS reads are requested together (SEG is a multiple)
+#endif
+static_assert(SEG % NR_K6_FB == 0, "class-F batches must tile a segment");
+
 template <bool RGB, bool ALPHA, typename AccIndex, typename Spill>
 __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_line, const int *s_pref, int n_win,
                                             int total_seg, int SP, float eps_f, double *acc, AccIndex acc_index, Spill spill)
 {
     const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
     for (int sid = threadIdx.x; sid < total_all; sid += BAND_THREADS) {
-        const SegRange sr = decode_segment(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
-                                           (int)(sizeof(BandLine) / 4));
+        const SegRange sr = decode_segment_fast(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
+                                                (int)(sizeof(BandLine) / 4));
         const BandLine *L = &s_line[sr.line];
         const int4 h = *reinterpret_cast<const int4 *>(L);
         const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
@@ -1356,22 +1409,16 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             ba = px.bg[0];
         }
         const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;  // (I - ref) of an uncovered pixel
-        const int own_mask = mode_in ? -1 : 0;
         const float cross = c.x, c0k = c.y, c1k = c.z;
         const int fnr = __float_as_int(c.w);
         float f0 = 0.0f, f1 = 0.0f;
-        float d1f = (float)sr.s_from;
-        for (int l = base + sr.s_from; l <= base + sr.s_to; ++l, d1f += 1.0f) {
-            // One pixel visit.  Face index and gradients are requested together (one LDS round trip); only a covered
-            // pixel pays a second one for its colour.
-            const int fi = px.fi[l];
-            // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its
-            // leading `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the
-            // background colour, whose difference to the reference colour is a constant of the segment; a covered one
-            // reads its own colour -- a wave whose 64 pixels are all uncovered skips that block altogether.
+        // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its leading
+        // `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the background colour,
+        // whose difference to the reference colour is a constant of the segment; a covered one reads its own colour -- a wave
+        // whose 64 pixels are all uncovered skips that block altogether.
+        auto pixel_diff = [&](int l, int fi, const float4 &g4, float ga) {
             float diff;
             if (RGB) {
-                const float4 g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
                 diff = ALPHA ? dba * g4.x + dbr * g4.y : dbr * g4.y;
                 diff += dbg * g4.z;
                 diff += dbb * g4.w;
@@ -1382,19 +1429,98 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                     diff += (c4.w - rb) * g4.w;
                 }
             } else {
-                const float ga = px.g[l];
                 diff = dba * ga;
                 if (fi >= 0) diff = (px.c[l] - ra) * ga;
             }
-            // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
-            // control flow on the sweep kind
-            if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) continue;
-            const float t = d1f - cross;
-            const float x0 = c0k * t, x1 = c1k * t;                                   // :649 / :654 (2 / S folded into c)
-            const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                     // :650 / :655
-            const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
-            f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y0), f0);                // :651
-            f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
+            return diff;
+        };
+#ifndef NR_K6_NO_CLASS_F
+        if (sid < total_full) {
+            // ---- class F: SEG pixels of an out sweep, unrolled.  t = d1 - d1_cross has one sign on the whole sweep (every
+            // pixel lies beyond the crossing point), hence so have c0 * t and c1 * t: `+- eps` (:650 / :655) is picked once.
+            const int l0 = base + sr.s_from;
+            const float d1f0 = (float)sr.s_from;
+            const float t_first = d1f0 - cross;
+            const float e0 = (0.0f < c0k * t_first) ? eps_f : -eps_f, e1 = (0.0f < c1k * t_first) ? eps_f : -eps_f;
+            // one address register per array; the pixels of the segment are compile-time offsets from it
+            const float *gp = px.g + (RGB ? 4 : 1) * (size_t)l0, *cp = px.c + (RGB ? 4 : 1) * (size_t)l0;
+            // coverage bits of the segment's SEG pixels (bit k <=> pixel s_from + k is owned by some face): two words of the
+            // line's bit array, funnel-shifted -- the face index itself is not read on an out sweep (:707 is an in-sweep test)
+            unsigned cb;
+            {
+                const unsigned *cw = px.cov + ((h.z >> 16) & 0xff) * px.CW + (sr.s_from >> 5);
+                const unsigned w0 = cw[0], w1 = ((sr.s_from & 31) > 32 - SEG) ? cw[1] : 0u;  // (the last word of a line has no successor)
+                cb = (unsigned)(((((unsigned long long)w1) << 32) | w0) >> (sr.s_from & 31)) & ((1u << SEG) - 1u);
+            }
+#pragma unroll
+            for (int kb = 0; kb < SEG; kb += NR_K6_FB) {
+                float4 g4[NR_K6_FB];
+                float ga[NR_K6_FB], diff[NR_K6_FB];
+#pragma unroll
+                for (int j = 0; j < NR_K6_FB; ++j) {  // the batch's LDS requests first
+                    if (RGB) g4[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + j));
+                    else ga[j] = gp[kb + j];
+                }
+#pragma unroll
+                for (int j = 0; j < NR_K6_FB; ++j) {
+                    if (RGB) {
+                        diff[j] = ALPHA ? dba * g4[j].x + dbr * g4[j].y : dbr * g4[j].y;
+                        diff[j] += dbg * g4[j].z;
+                        diff[j] += dbb * g4[j].w;
+                    } else {
+                        diff[j] = dba * ga[j];
+                    }
+                }
+                if ((cb >> kb) & ((1u << NR_K6_FB) - 1u)) {  // a covered pixel in the batch (1 visit in 8): its own colour
+#pragma unroll
+                    for (int j = 0; j < NR_K6_FB; ++j) {
+                        if (!((cb >> (kb + j)) & 1u)) continue;
+                        if (RGB) {
+                            const float4 c4 = *reinterpret_cast<const float4 *>(cp + 4 * (kb + j));
+                            float d = ALPHA ? (c4.x - ra) * g4[j].x + (c4.y - rr) * g4[j].y : (c4.y - rr) * g4[j].y;
+                            d += (c4.z - rg) * g4[j].z;
+                            d += (c4.w - rb) * g4[j].w;
+                            diff[j] = d;
+                        } else {
+                            diff[j] = (cp[kb + j] - ra) * ga[j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NR_K6_FB; ++j) {
+                    if (diff[j] <= 0.0f) continue;                                // :647 (a NaN diff is not `<= 0`)
+                    const float t = (d1f0 + (float)(kb + j)) - cross;
+                    const float x0 = c0k * t, x1 = c1k * t;                       // :649 / :654 (2 / S folded into c)
+                    const float y0 = x0 + e0, y1 = x1 + e1;                       // :650 / :655
+                    f0 = __builtin_fmaf(-diff[j], __builtin_amdgcn_rcpf(y0), f0); // :651
+                    f1 = __builtin_fmaf(-diff[j], __builtin_amdgcn_rcpf(y1), f1); // :656
+                }
+            }
+        } else
+#endif
+        {
+            // ---- class G: a piece of an in sweep or the remainder of an out sweep, the general loop
+            const int own_mask = mode_in ? -1 : 0;
+            float d1f = (float)sr.s_from;
+            for (int l = base + sr.s_from; l <= base + sr.s_to; ++l, d1f += 1.0f) {
+                // One pixel visit.  Face index and gradients are requested together (one LDS round trip); only a covered
+                // pixel pays a second one for its colour.
+                const int fi = px.fi[l];
+                float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float ga = 0.0f;
+                if (RGB) g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
+                else ga = px.g[l];
+                const float diff = pixel_diff(l, fi, g4, ga);
+                // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
+                // control flow on the sweep kind
+                if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) continue;
+                const float t = d1f - cross;
+                const float x0 = c0k * t, x1 = c1k * t;                                   // :649 / :654 (2 / S folded into c)
+                const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                     // :650 / :655
+                const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
+                f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y0), f0);                // :651
+                f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
+            }
         }
         const double a0 = (flags & 2) ? (double)f0 : 0.0, a1 = (flags & 4) ? (double)f1 : 0.0;  // :648 / :653
         if (a0 != 0.0) { const int i0 = acc_index(sr.line, h.w, 0); if (i0 >= 0) atomicAdd(&acc[i0], a0); else spill(h.w, fnr, 0, a0); }
@@ -1433,6 +1559,8 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     px.g = (float *)carve((size_t)W * SP * NC * 4);
     px.c = (float *)carve((size_t)W * SP * NC * 4);
     px.bg = (float *)carve(16);
+    px.CW = (SP + 31) >> 5;
+    px.cov = (unsigned *)carve((size_t)W * px.CW * 4);
     BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
     int *s_pref = (int *)carve(4 * WIN);
     int *s_tmp = (int *)carve(4 * 16);
@@ -1440,6 +1568,8 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
 
     // ---- 1. stage the band
     const size_t img = (size_t)b * S * S;
+    for (int i = tid; i < W * px.CW; i += BAND_THREADS) px.cov[i] = 0u;
+    __syncthreads();
     fast_stage<RGB, ALPHA>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, img, axis, band_lo, nld, S, SP);
     NR_PHASE(1);
 
@@ -1453,7 +1583,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             if (tid < n_win) {
                 const BandLine r = recs[win + tid];
                 s_line[tid] = r;
-                n_seg = line_segments(r.in_rng, r.out_rng);
+                n_seg = line_segments_fast(r.in_rng, r.out_rng);
             }
             if (tid < 2 * n_win) s_lacc[tid] = 0.0;
             int total_seg = 0;
@@ -1536,7 +1666,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
                                                   slot_l | (e << 16) | (((e + 1) % 3) << 18),
                                                   [&](int d1) { return px.fi[ld * SP + d1]; });
                 s_line[tid] = r;
-                n_seg = line_segments(r.in_rng, r.out_rng);
+                n_seg = line_segments_fast(r.in_rng, r.out_rng);
             }
             NR_PHASE(4);
             int total_seg = 0;
@@ -1669,7 +1799,8 @@ int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *
         for (int w = BAND_WIN; w >= (exact ? BAND_WIN : FAST_WIN_SMALL); w >>= 1) {
             const size_t fixed = exact ? (sizeof(BandLine) + 12) * (size_t)w + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16
                                        : band_fixed_lds(w);
-            const size_t need = (size_t)W * SP * per_px + fixed;
+            // + the default kernel's coverage bits: (SP + 31) / 32 words per line
+            const size_t need = (size_t)W * SP * per_px + fixed + (exact ? 0 : align_up((size_t)W * ((SP + 31) / 32) * 4, 16));
             if (need <= LDS_BUDGET || (W == 1 && w == (exact ? BAND_WIN : FAST_WIN_SMALL) && need <= 160 * 1024)) {
                 *lds_bytes = need;
                 *win = w;

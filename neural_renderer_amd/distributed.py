@@ -24,6 +24,18 @@ import torch
 import torch.distributed as dist
 
 
+def _force():
+    """NR_DIST_FORCE=1 (test hook): initialise the process group and issue the collectives even for ONE rank, so that the
+    RCCL code path -- init_process_group(device_id=), barrier, all_reduce, all_gather_into_tensor / all_gather, broadcast on
+    device tensors -- can be executed on a one-GPU box (tests/test_rccl_gpu.py)."""
+    return os.environ.get('NR_DIST_FORCE', '0') not in ('', '0')
+
+
+def _active():
+    """True when collectives have to be issued: an initialised group of more than one rank (or a forced single rank)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force())
+
+
 def env_rank_world():
     return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
             int(os.environ.get('LOCAL_RANK', '0')))
@@ -41,7 +53,7 @@ def init_from_env(backend=None):
     device = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         kwargs = {}
@@ -71,15 +83,16 @@ def broadcast_reference_faces(projected_faces, src=0):
     vertices_to_faces).  One tiny broadcast; not differentiable (the reference back-propagates nothing through these
     depths either: K7 treats the sampling weights as constants)."""
     ref = projected_faces[0].detach().contiguous().clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.broadcast(ref, src=src)
     return ref
 
 
-def all_gather_images(images, total=None):
+def all_gather_images(images, total=None, force_padded=False):
     """Gather per-rank image shards [b_r, ...] into the full batch [B, ...] on every rank (not differentiable
-    through the collective; use it on detached images or gather the per-view losses instead)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    through the collective; use it on detached images or gather the per-view losses instead).  `force_padded` (tests): take
+    the pad / all_gather / trim path of uneven shards even when the shards are equal."""
+    if not _active():
         return images
     world, rank = dist.get_world_size(), dist.get_rank()
     images = images.contiguous()
@@ -93,7 +106,7 @@ def all_gather_images(images, total=None):
         sizes = [int(s.item()) for s in sizes]
     else:
         sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
-    if len(set(sizes)) == 1:
+    if len(set(sizes)) == 1 and not force_padded:
         out = images.new_empty((sum(sizes),) + tuple(images.shape[1:]))
         dist.all_gather_into_tensor(out, images)
         return out
@@ -108,7 +121,7 @@ def all_gather_images(images, total=None):
 
 def all_reduce_shared_grads(parameters):
     """Sum the gradients of parameters shared by all views (vertices / textures of one mesh) over the ranks."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return
     # every rank must issue the same sequence of collectives: a parameter without a gradient on this rank (an unused
     # output, a shard in which the mesh is not visible) contributes zeros instead of being skipped

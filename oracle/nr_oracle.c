@@ -68,6 +68,21 @@ static inline int f2i(double x)
     return (int)x;
 }
 
+/* Contraction study (tests/test_contraction.py).  The convention of this oracle and of the HIP kernels is the
+ * UN-fused reading of the reference source.  nvcc (-fmad=true, its default) is allowed to contract `a*b+c` into one fused
+ * multiply-add; the reference cannot be run here, so oracle_set_contraction(1) switches K1 and K2 to the contraction an
+ * LLVM-style compiler performs on the same expressions -- fadd(fmul(a,b), x) -> fma(a,b,x) with the FIRST product of a sum
+ * fused and the other operand evaluated (rounded) beforehand; products that are only compared (:252, :306, :310-312) have
+ * no add to fuse with -- to MEASURE how far the outputs can move: which pixels change owner, max |d depth|, max |d weight|.
+ * It is a measuring device for the error bar on "bit-exact", never the parity target. */
+static int g_fma = 0;
+API void oracle_set_contraction(int on) { g_fma = on ? 1 : 0; }
+API int oracle_get_contraction(void) { return g_fma; }
+/* a*b + c, a*b - c*d and (a*x + b*y) + c as the source has them / as a contracting compiler evaluates them */
+static inline float muladd(float a, float b, float c) { return g_fma ? fmaf(a, b, c) : a * b + c; }
+static inline float mulsub2(float a, float b, float c, float d) { return g_fma ? fmaf(a, b, -(c * d)) : a * b - c * d; }
+static inline float dot2c(float a, float x, float b, float y, float c) { return g_fma ? fmaf(a, x, b * y) + c : a * x + b * y + c; }
+
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 
@@ -96,15 +111,18 @@ API void oracle_forward_face_inv(const float *faces, float *faces_inv, int batch
         float p[3][2];
         for (int num = 0; num < 3; num++)
             for (int dim = 0; dim < 2; dim++)
-                p[num][dim] = (float)(0.5 * (double)(face[3 * num + dim] * (float)is + (float)is - 1.0f)); /* :258 */
+                p[num][dim] = (float)(0.5 * (double)(muladd(face[3 * num + dim], (float)is, (float)is) - 1.0f)); /* :258 */
 
         float face_inv[9] = {/* :261-264 */
-                             p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
-                             p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
-                             p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
-        float face_inv_denominator = (/* :265-268 */
-                                      p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
-                                      p[1][0] * (p[2][1] - p[0][1]));
+                             p[1][1] - p[2][1], p[2][0] - p[1][0], mulsub2(p[1][0], p[2][1], p[2][0], p[1][1]),
+                             p[2][1] - p[0][1], p[0][0] - p[2][0], mulsub2(p[2][0], p[0][1], p[0][0], p[2][1]),
+                             p[0][1] - p[1][1], p[1][0] - p[0][0], mulsub2(p[0][0], p[1][1], p[1][0], p[0][1])};
+        float face_inv_denominator = (/* :265-268: (m1 + m2) + m3 */
+                                      muladd(p[1][0], p[2][1] - p[0][1],
+                                             muladd(p[2][0], p[0][1] - p[1][1], p[0][0] * (p[1][1] - p[2][1]))));
+        if (!g_fma)
+            face_inv_denominator = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
+                                   p[1][0] * (p[2][1] - p[0][1]);
         for (int k = 0; k < 9; k++) face_inv[k] /= face_inv_denominator; /* :269 */
         for (int k = 0; k < 9; k++) face_inv_g[k] = face_inv[k];         /* :272 */
     }
@@ -152,9 +170,9 @@ API void oracle_forward_face_index_map(const float *faces, const float *faces_in
 
             /* :317-319 */
             float w[3];
-            w[0] = face_inv[3 * 0 + 0] * (float)xi + face_inv[3 * 0 + 1] * (float)yi + face_inv[3 * 0 + 2];
-            w[1] = face_inv[3 * 1 + 0] * (float)xi + face_inv[3 * 1 + 1] * (float)yi + face_inv[3 * 1 + 2];
-            w[2] = face_inv[3 * 2 + 0] * (float)xi + face_inv[3 * 2 + 1] * (float)yi + face_inv[3 * 2 + 2];
+            w[0] = dot2c(face_inv[3 * 0 + 0], (float)xi, face_inv[3 * 0 + 1], (float)yi, face_inv[3 * 0 + 2]);
+            w[1] = dot2c(face_inv[3 * 1 + 0], (float)xi, face_inv[3 * 1 + 1], (float)yi, face_inv[3 * 1 + 2]);
+            w[2] = dot2c(face_inv[3 * 2 + 0], (float)xi, face_inv[3 * 2 + 1], (float)yi, face_inv[3 * 2 + 2]);
 
             /* :322-327 */
             float w_sum = 0;
@@ -248,9 +266,9 @@ API void oracle_forward_face_index_map_blocked(const float *faces, const float *
                 if (!hit[j]) continue;
                 const int xi = x0 + j;
                 float w[3]; /* :317-319 */
-                w[0] = face_inv[3 * 0 + 0] * (float)xi + face_inv[3 * 0 + 1] * (float)yi + face_inv[3 * 0 + 2];
-                w[1] = face_inv[3 * 1 + 0] * (float)xi + face_inv[3 * 1 + 1] * (float)yi + face_inv[3 * 1 + 2];
-                w[2] = face_inv[3 * 2 + 0] * (float)xi + face_inv[3 * 2 + 1] * (float)yi + face_inv[3 * 2 + 2];
+                w[0] = dot2c(face_inv[3 * 0 + 0], (float)xi, face_inv[3 * 0 + 1], (float)yi, face_inv[3 * 0 + 2]);
+                w[1] = dot2c(face_inv[3 * 1 + 0], (float)xi, face_inv[3 * 1 + 1], (float)yi, face_inv[3 * 1 + 2]);
+                w[2] = dot2c(face_inv[3 * 2 + 0], (float)xi, face_inv[3 * 2 + 1], (float)yi, face_inv[3 * 2 + 2]);
                 float w_sum = 0; /* :322-327 */
                 for (int k = 0; k < 3; k++) {
                     w[k] = (float)fmin(fmax((double)w[k], 0.), 1.);
@@ -622,4 +640,4 @@ API void oracle_backward_depth_map(const float *faces, const float *depth_map, c
     }
 }
 
-API int oracle_version(void) { return 2; }
+API int oracle_version(void) { return 3; }

@@ -50,7 +50,7 @@ def lib():
     if _lib is None:
         build()
         _lib = ctypes.CDLL(_LIB)
-        if _lib.oracle_version() < 2:  # a stale prebuilt library
+        if _lib.oracle_version() < 3:  # a stale prebuilt library
             build(force=True)
             _lib = ctypes.CDLL(_LIB)
         env = os.environ.get('NR_ORACLE_THREADS')
@@ -66,6 +66,17 @@ def set_threads(n):
 
 def get_threads():
     return int(lib().oracle_get_threads())
+
+
+def set_contraction(on):
+    """Contraction study only (nr_oracle.c: oracle_set_contraction): K1 / K2 with the `a*b+c` of rasterize.py:258, :261-269,
+    :317-319 evaluated as fused multiply-adds, the way nvcc is allowed to compile the reference.  The parity convention is
+    the un-fused reading (off, the default); callers must switch it off again."""
+    lib().oracle_set_contraction(1 if on else 0)
+
+
+def get_contraction():
+    return bool(lib().oracle_get_contraction())
 
 
 # Above this many (pixel, face) pairs the forward uses the cache-blocked evaluation order of K2 (bit-identical,

@@ -38,8 +38,17 @@ def test_bench_json_line():
     w = r['whole_step']
     assert w['algorithmic_bytes'] == 92 * 4 * 256 * 256 + (108 + 24 * 8) * 4 * d['config']['num_faces']
     assert r['traffic'] is None and 'traffic_from_profiles' in r
-    assert len(d['extra_rows']) == 3 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
+    assert len(d['extra_rows']) == 4 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
+    assert any('NR_FLAG_EXACT_GRADIENT' in x['row'] for x in d['extra_rows'])
     assert d['renderer_end_to_end']['frontend'] == 'fused'
+    rows = d['renderer_end_to_end']['reference_protocol']['rows']  # misc/measure_time.py protocol, Renderer defaults (AA on)
+    assert [x['batch_size'] for x in rows] == [1, 4] and all(x['anti_aliasing'] and x['raster'] == 512 for x in rows)
+    assert all(x[k] > 0 for x in rows for k in ('silhouette_forward_ms', 'silhouette_backward_ms', 'texture_forward_ms',
+                                                 'texture_backward_ms'))
+    st = r['stages']['per_stage']
+    assert set(st) == set(d['stages_us']) - {'fused_forward_rasterize', 'fused_backward_rasterize'}
+    assert all(0 < v['coverage_scaled_bytes'] <= v['algorithmic_bytes'] and v['frac'] < 1.0 for v in st.values())
+    assert d['timing']['backend'] is None and d['timing']['rank0_hip_event_ms_per_step'] > 0
 
 
 def test_bench_refuses_to_run_without_a_gpu():
