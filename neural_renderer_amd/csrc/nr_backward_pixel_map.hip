@@ -260,6 +260,7 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per pass
 constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
+constexpr int FAST_ACC_SLOTS = 64;  // the same for the scan path of k_bpm_fast (its LDS budget also holds the segment queue)
 constexpr int SEG = 15;          // pixels of a sweep walked by one thread (odd: consecutive segments of a
                                  // sweep start 15 dwords apart, i.e. on different LDS banks)
 
@@ -894,7 +895,27 @@ __global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void
 // When a contribution is not taken (:648 / :653: d0 equals the vertex) its coefficient is +-Inf / NaN; the lane then
 // accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
 #ifdef NR_K6_PHASES  // development build: cycles spent per phase, summed over workgroups (scripts/k6_phases.py)
-__device__ unsigned long long g_k6_phase[8];
+__device__ unsigned long long g_k6_phase[24];
+// per-wave accounting inside fast_sweeps (slots 8..): 8 classify+scan, 9 barrier wait, 10 fill, 11 decode, 12 U loop, 13 M loop,
+// 14 G loop, 15 flush, 16 wave-rounds U, 17 M, 18 G, 19 idle wave-rounds
+// (accumulated per wave in LDS, one set of global atomics per wave when fast_sweeps returns: a global atomic per stamp
+// from every wave of the chip serialises on one address and slows the kernel 30x)
+#define NR_WPH_BEGIN()                                                              \
+    __shared__ unsigned s_wph[BAND_THREADS / 64][12];                               \
+    if ((threadIdx.x & 63) < 12) s_wph[threadIdx.x >> 6][threadIdx.x & 63] = 0u;    \
+    unsigned long long wph_t = clock64()
+#define NR_WPH(k)                                                                   \
+    do {                                                                            \
+        const unsigned long long wnow = clock64();                                  \
+        if ((threadIdx.x & 63) == 0) s_wph[threadIdx.x >> 6][(k) - 8] += (unsigned)(wnow - wph_t); \
+        wph_t = wnow;                                                               \
+    } while (0)
+#define NR_WCOUNT(k) do { if ((threadIdx.x & 63) == 0) s_wph[threadIdx.x >> 6][(k) - 8] += 1u; } while (0)
+#define NR_WPH_END()                                                                \
+    do {                                                                            \
+        if ((threadIdx.x & 63) < 12 && s_wph[threadIdx.x >> 6][threadIdx.x & 63])   \
+            atomicAdd(&g_k6_phase[8 + (threadIdx.x & 63)], (unsigned long long)s_wph[threadIdx.x >> 6][threadIdx.x & 63]); \
+    } while (0)
 #define NR_PHASE_BEGIN() unsigned long long ph_t = clock64()
 #define NR_PHASE(k)                                                                 \
     do {                                                                            \
@@ -908,6 +929,10 @@ __device__ unsigned long long g_k6_phase[8];
 #else
 #define NR_PHASE_BEGIN() do {} while (0)
 #define NR_PHASE(k) do {} while (0)
+#define NR_WPH_BEGIN() do {} while (0)
+#define NR_WPH(k) do {} while (0)
+#define NR_WCOUNT(k) do {} while (0)
+#define NR_WPH_END() do {} while (0)
 #endif
 
 // One line record of the fast kernel (rasterize.py:543-579, :604-609, :665-672; the reference's arithmetic: the crossing
@@ -982,56 +1007,6 @@ __device__ __forceinline__ BandLine make_fast_line(const float *__restrict__ fv,
 {
     const LineHead h = fast_line_head(fv, e, axis, d0, S);
     return fast_line_finish(h, ld, S, rfn, tgt, h.live ? owner_of(h.d1_in) : -1);
-}
-
-// Segment classes of the default kernel (k_bpm_fast).  Class F ("full out"): exactly SEG pixels of an OUT sweep -- 93 % of all
-// visits lie in out sweeps, three quarters of them in such pieces -- walked by a loop that is unrolled over its 15 pixels
-// (compile-time LDS offsets, no loop bookkeeping), has no ownership test (:707 applies to the in sweep only) and takes the
-// sign of `+- eps` once per segment: t = d1 - d1_cross keeps its sign beyond the crossing point, and so does c * t.
-// Class G: everything else -- the pieces (<= SEG pixels) of the in sweeps and the remainder of the out sweep -- walked by the
-// general loop.  Packed counts: F in the low 16 bits, G above (<= S / SEG + 2 per line).
-__device__ __forceinline__ int line_segments_fast(int in_rng, int out_rng)
-{
-    const int il = (in_rng >> 16) - (in_rng & 0xffff) + 1, ol = (out_rng >> 16) - (out_rng & 0xffff) + 1;
-    const int full = ol > 0 ? ol / SEG : 0;
-    const int gen = (il > 0 ? (il + SEG - 1) / SEG : 0) + (ol > 0 && ol % SEG != 0);
-    return full | (gen << 16);
-}
-
-__device__ __forceinline__ SegRange decode_segment_fast(int sid, int total_full, int n_win, const int *s_pref,
-                                                        const int *line_words /* BandLine array */, int stride_words)
-{
-    SegRange r;
-    const bool is_full = sid < total_full;
-    const int id = is_full ? sid : sid - total_full;
-    const int shift = is_full ? 0 : 16;
-    int lo = 0, hi = n_win - 1;  // last line whose prefix (of this class) is <= id
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (((s_pref[mid] >> shift) & 0xffff) <= id) lo = mid; else hi = mid - 1;
-    }
-    r.line = lo;
-    const int in_rng = line_words[lo * stride_words], out_rng = line_words[lo * stride_words + 1];
-    const int k = id - ((s_pref[lo] >> shift) & 0xffff);
-    const int out_from = out_rng & 0xffff, out_to = out_rng >> 16;
-    if (is_full) {
-        r.mode_in = false;
-        r.s_from = out_from + k * SEG;
-        r.s_to = r.s_from + SEG - 1;
-    } else {
-        const int in_from = in_rng & 0xffff, in_to = in_rng >> 16;
-        const int il = in_to - in_from + 1;
-        const int n_in = il > 0 ? (il + SEG - 1) / SEG : 0;
-        r.mode_in = k < n_in;
-        if (r.mode_in) {
-            r.s_from = in_from + k * SEG;
-            r.s_to = min(r.s_from + SEG - 1, in_to);
-        } else {
-            r.s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG;
-            r.s_to = out_to;
-        }
-    }
-    return r;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1283,6 +1258,7 @@ struct FastPx {  // LDS pixel data of a band, [line][d1]
     float *bg;   // colour of the band's uncovered pixels
     unsigned *cov;  // coverage bits [line][CW words]: bit d1 & 31 of word d1 >> 5 set <=> a face owns pixel (line, d1)
     int CW;         // words per line
+    int *span;      // [line][2]: first and last covered pixel of the line (first > last: none)
 };
 
 template <bool RGB, bool ALPHA>
@@ -1372,29 +1348,183 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
     }
 }
 
-// Step 4 for the n_win line records in s_line (their packed segment counts, line_segments_fast, already scanned into s_pref):
-// one segment per thread.  The two sums of a segment go to acc[acc_index(line, k)] (ds_add_f64), k = 0 / 1 for the edge's
-// first / second vertex; acc_index returns a negative value for "no LDS slot" and spill() then takes the sum.
+// --------------------------------------------------------------------------------------------------
+// Step 4 of k_bpm_fast: the sweeps of the n_win line records in s_line, one SEGMENT (<= SEG pixels of one sweep) per thread
+// and round.  Three classes of segments, each walked by its own loop:
+//   U  exactly SEG pixels of an OUT sweep, none of them covered by a face (7 of 8 pixels of an out sweep are background, and
+//      they come in long runs behind the silhouette): `I - ref` is the constant (background - reference colour), the visit
+//      reads the four gradients and nothing else; unrolled over its 15 pixels with compile-time LDS offsets;
+//   M  exactly SEG pixels of an OUT sweep with covered pixels among them (the coverage bits say which): those read their
+//      colour as well;
+//   G  everything else: the pieces (<= SEG pixels) of the in sweeps -- ownership test :707, per-pixel sign of `+- eps` -- and
+//      the remainder of the out sweep, the general loop.
+// The out classes take the sign of `+- eps` once per segment: t = d1 - d1_cross keeps its sign beyond the crossing point,
+// hence so do c0 * t and c1 * t (:650 / :655).  (Measured on the headline scene, r03: with every segment on the general loop
+// a visit costs ~27 VALU instructions; a wave whose 64 lanes walk unrelated segments executes the covered-pixel block in
+// practically every step although 1 lane in 8 needs it, so sorting the segments by coverage is what makes the cheap loop
+// cheap: U 18 instructions per visit.)
+// Segment -> thread without a search: the thread that owns line `tid` of the window classifies the line's segments (coverage
+// bits of the band, px.cov), one packed scan numbers the segments of each class through (U first, then M, then G, every class
+// starting on a multiple of 64 so that a wave never mixes classes), the owners write a (line | piece << 8) descriptor per
+// segment into a queue, and after one barrier every thread walks the ids tid, tid + 512, ... of the queue.  The queue takes
+// what the line window leaves of the workgroup's LDS (fast_band_config: ~3000 descriptors, a window's worth); a window with
+// more segments goes through it in rounds.  (The binary search over the lines' prefix sums that this replaces cost ~100
+// instructions and 9 dependent LDS round trips per segment; per-round queues of 512 entries cost a barrier and an owner
+// pass per round.)
+// The two sums of a segment go to acc[acc_index(line, tgt, k)] (ds_add_f64), k = 0 / 1 for the edge's first / second vertex;
+// acc_index returns a negative value for "no LDS slot" and spill() then takes the sum.
 #ifndef NR_K6_FB
-#define NR_K6_FB 3  // pixels of a class-F segment whose LDS reads are requested together (SEG is a multiple)
+#define NR_K6_FB 3  // pixels of an unrolled segment whose LDS reads are requested together (SEG is a multiple)
 #endif
-static_assert(SEG % NR_K6_FB == 0, "class-F batches must tile a segment");
+static_assert(SEG % NR_K6_FB == 0, "batches must tile a segment");
+constexpr int G_SHORT = 4;  // class G pieces up to this many pixels are numbered apart from the longer ones
+
+// DPP moves inside a row of 16 lanes: value of the lane D places below / one place above; a lane without such a neighbour
+// in its row, or whose neighbour is not executing, gets `old`
+template <int D>
+__device__ __forceinline__ int dpp_row_shr(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x110 + D, 0xf, 0xf, false); }
+template <int D>
+__device__ __forceinline__ float dpp_row_shr_f(float v)  // (0 where there is no such neighbour)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int dpp_row_shl1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x101, 0xf, 0xf, false); }
+
+// exclusive scan of one 64-bit word per thread over the workgroup; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long *s_tmp,
+                                                                unsigned long long *total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    unsigned long long woff = 0, tot = 0;
+    for (int w = 0; w < BAND_THREADS / 64; ++w) {
+        const unsigned long long c = s_tmp[w];
+        if (w < wave) woff += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
 
 template <bool RGB, bool ALPHA, typename AccIndex, typename Spill>
-__device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_line, const int *s_pref, int n_win,
-                                            int total_seg, int SP, float eps_f, double *acc, AccIndex acc_index, Spill spill)
+__device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_line, int n_win, int SP, float eps_f,
+                                            double *acc, AccIndex acc_index, Spill spill, void *s_queue, int qcap, bool wide,
+                                            unsigned long long *s_tmp)
 {
-    const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
-    for (int sid = threadIdx.x; sid < total_all; sid += BAND_THREADS) {
-        const SegRange sr = decode_segment_fast(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
-                                                (int)(sizeof(BandLine) / 4));
-        const BandLine *L = &s_line[sr.line];
+    const int tid = threadIdx.x;
+    NR_WPH_BEGIN();
+    // ---- owner of line `tid`: its segments by class.  The covered pixels of an out sweep lie next to the edge it starts
+    // from (the rest of the object), the background behind them: the full pieces from the one with the first covered pixel
+    // to the one with the last are class M (pmin .. pmin + nM - 1; an uncovered gap between two covered stretches -- the
+    // teapot's handle -- rides along), the others class U.  One pass over the line's coverage words finds both ends.
+    int nF = 0, nM = 0, nG = 0, nS = 0, pmin = 0, nIn = 0, rin = 0, rem = 0;
+    if (tid < n_win) {
+        const int in_rng = s_line[tid].in_rng, out_rng = s_line[tid].out_rng, geo = s_line[tid].geo;
+        const int il = (in_rng >> 16) - (in_rng & 0xffff) + 1, out_from = out_rng & 0xffff;
+        const int ol = (out_rng >> 16) - out_from + 1;
+        nF = ol > 0 ? ol / SEG : 0;
+        // class G pieces: nIn pieces of the in sweep (the last one rin pixels long) and the out remainder (rem pixels); the
+        // short ones (<= G_SHORT pixels: nine in-sweeps in ten) are numbered apart from the long ones, so that the lanes of a
+        // wave walk pieces of similar length
+        nIn = il > 0 ? (il + SEG - 1) / SEG : 0;
+        rin = il > 0 ? il - (nIn - 1) * SEG : 0;
+        rem = ol > 0 ? ol % SEG : 0;
+        nG = nIn + (rem > 0);
+        nS = (rin > 0 && rin <= G_SHORT) + (rem > 0 && rem <= G_SHORT);
+        if (nF > 0) {
+            const int ld = (geo >> 16) & 0xff;
+            const unsigned *cw = px.cov + ld * px.CW;
+            // the pieces' pixels [out_from, last], clipped to the covered span of the band line
+            const int last = out_from + nF * SEG - 1;
+            const int ca = max(out_from, px.span[2 * ld]), cb = min(last, px.span[2 * ld + 1]);
+            const int wa = ca >> 5, we = cb >> 5;  // (ca > cb: no coverage, no iteration worth making -- but wa <= we may hold)
+            int cmin = 0x7fffffff, cmax = -1;
+            for (int w = wa; w <= we && ca <= cb; ++w) {
+                unsigned m = cw[w];
+                if (w == wa) m &= 0xffffffffu << (ca & 31);
+                if (w == we) m &= 0xffffffffu >> (31 - (cb & 31));
+                if (m) {
+                    cmin = min(cmin, 32 * w + __ffs((int)m) - 1);
+                    cmax = max(cmax, 32 * w + 31 - __clz((int)m));
+                }
+            }
+            if (cmax >= 0) {
+                pmin = (cmin - out_from) / SEG;
+                nM = (cmax - out_from) / SEG - pmin + 1;
+            }
+        }
+    }
+    const int nU = nF - nM, nL = nG - nS;
+    // one scan for the four numberings (16 bits each: a window holds < 2^16 pieces of every kind by the choice of win_lines)
+    unsigned long long totals = 0;
+    const unsigned long long offs = block_excl_scan64((unsigned long long)nU | ((unsigned long long)nM << 16) |
+                                                          ((unsigned long long)nS << 32) | ((unsigned long long)nL << 48),
+                                                      s_tmp, &totals);
+    const int TU = (int)(totals & 0xffff), TM = (int)((totals >> 16) & 0xffff), TS = (int)((totals >> 32) & 0xffff),
+              TL = (int)(totals >> 48);
+    // class starts (multiples of 64): U at 0, M, G-short, G-long
+    const int MA = (TU + 63) & ~63, SA = MA + ((TM + 63) & ~63), LA = SA + ((TS + 63) & ~63), total_ids = LA + TL;
+    const int idU = (int)(offs & 0xffff), idM = MA + (int)((offs >> 16) & 0xffff), idS = SA + (int)((offs >> 32) & 0xffff),
+              idL = LA + (int)(offs >> 48);
+    unsigned short *q16 = reinterpret_cast<unsigned short *>(s_queue);
+    unsigned *q32 = reinterpret_cast<unsigned *>(s_queue);
+    NR_WPH(8);
+    // rounds of qcap ids (qcap: a multiple of BAND_THREADS; most windows fit in one round)
+    for (int lo = 0; lo < total_ids; lo += qcap) {
+        const int hi = min(lo + qcap, total_ids);
+        if (lo > 0) __syncthreads();  // the previous round's readers are done
+        if (tid < n_win) {            // descriptors (line | piece << 8) of this owner's segments with ids in [lo, hi)
+            auto put = [&](int id, int seg) {
+                if (wide) q32[id - lo] = (unsigned)tid | ((unsigned)seg << 8);
+                else q16[id - lo] = (unsigned short)(tid | (seg << 8));
+            };
+            for (int j = min(max(lo - idU, 0), nU), j1 = min(max(hi - idU, 0), nU); j < j1; ++j) put(idU + j, j < pmin ? j : j + nM);
+            for (int j = min(max(lo - idM, 0), nM), j1 = min(max(hi - idM, 0), nM); j < j1; ++j) put(idM + j, pmin + j);
+            for (int j = 0, cs = 0, cl = 0; j < nG; ++j) {  // G piece j: in piece j (j < nIn) or the out remainder
+                const int len = j < nIn - 1 ? SEG : (j == nIn - 1 ? rin : rem);
+                const int id = len <= G_SHORT ? idS + cs++ : idL + cl++;
+                if (id >= lo && id < hi) put(id, j);
+            }
+        }
+        NR_WPH(10);
+        __syncthreads();
+        NR_WPH(9);
+    for (int id = lo + tid; rfl(id) < hi; id += BAND_THREADS) {  // (wave-uniform trip count: all 64 lanes stay together)
+        const int wid = rfl(id);     // ids of a wave are 64 consecutive numbers from a multiple of 64: one class per wave
+        const int cls = wid < MA ? 0 : (wid < SA ? 1 : 2);
+        const int cls_end = min(hi, cls == 0 ? TU : (cls == 1 ? MA + TM : (wid < LA ? SA + TS : total_ids)));
+        NR_WCOUNT(16 + cls);
+        if (wid >= cls_end) continue;  // a wave of padding ids
+        // a lane on a padding id behind its class walks piece 0 of line 0 (valid LDS addresses) and throws the result away
+        const bool valid = id < cls_end;
+        const unsigned desc = valid ? (wide ? q32[id - lo] : (unsigned)q16[id - lo]) : 0u;
+        const int line = (int)(desc & 0xffu), seg = (int)(desc >> 8);
+        const BandLine *L = &s_line[line];
         const int4 h = *reinterpret_cast<const int4 *>(L);
         const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
-        const bool mode_in = sr.mode_in;
         const int flags = (h.z >> 24) & 0xff;
-        const int base = ((h.z >> 16) & 0xff) * SP;
+        const int ld = (h.z >> 16) & 0xff, base = ld * SP;
         const int d1_in = h.z & 0xffff;
+        const int out_from = h.y & 0xffff, out_to = h.y >> 16;
+        // class G: which sweep and which pixels
+        bool mode_in = false;
+        int s_from = out_from + seg * SEG, s_to = s_from + SEG - 1;
+        if (cls == 2) {
+            const int in_from = h.x & 0xffff, in_to = h.x >> 16;
+            const int il = in_to - in_from + 1;
+            const int n_in = il > 0 ? (il + SEG - 1) / SEG : 0;
+            mode_in = seg < n_in;
+            if (mode_in) { s_from = in_from + seg * SEG; s_to = min(s_from + SEG - 1, in_to); }
+            else { s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG; s_to = out_to; }
+        }
         // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
         const int lref = base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
         float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
@@ -1408,109 +1538,117 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             ra = px.c[lref];
             ba = px.bg[0];
         }
-        const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;  // (I - ref) of an uncovered pixel
+        // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its leading
+        // `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the background colour
+        // (K5), whose difference to the reference colour is a constant of the segment.
+        const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;
         const float cross = c.x, c0k = c.y, c1k = c.z;
         const int fnr = __float_as_int(c.w);
         float f0 = 0.0f, f1 = 0.0f;
-        // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its leading
-        // `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the background colour,
-        // whose difference to the reference colour is a constant of the segment; a covered one reads its own colour -- a wave
-        // whose 64 pixels are all uncovered skips that block altogether.
-        auto pixel_diff = [&](int l, int fi, const float4 &g4, float ga) {
-            float diff;
-            if (RGB) {
-                diff = ALPHA ? dba * g4.x + dbr * g4.y : dbr * g4.y;
-                diff += dbg * g4.z;
-                diff += dbb * g4.w;
-                if (fi >= 0) {
-                    const float4 c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l);
-                    diff = ALPHA ? (c4.x - ra) * g4.x + (c4.y - rr) * g4.y : (c4.y - rr) * g4.y;
-                    diff += (c4.z - rg) * g4.z;
-                    diff += (c4.w - rb) * g4.w;
-                }
-            } else {
-                diff = dba * ga;
-                if (fi >= 0) diff = (px.c[l] - ra) * ga;
-            }
-            return diff;
+        auto bg_diff = [&](const float4 &g4, float ga) {
+            if (!RGB) return dba * ga;
+            float d = ALPHA ? dba * g4.x + dbr * g4.y : dbr * g4.y;
+            d += dbg * g4.z;
+            d += dbb * g4.w;
+            return d;
         };
-#ifndef NR_K6_NO_CLASS_F
-        if (sid < total_full) {
-            // ---- class F: SEG pixels of an out sweep, unrolled.  t = d1 - d1_cross has one sign on the whole sweep (every
-            // pixel lies beyond the crossing point), hence so have c0 * t and c1 * t: `+- eps` (:650 / :655) is picked once.
-            const int l0 = base + sr.s_from;
-            const float d1f0 = (float)sr.s_from;
+        auto own_diff = [&](const float4 &c4, float ca, const float4 &g4, float ga) {  // c4 / ca: the pixel's colour
+            if (!RGB) return (ca - ra) * ga;
+            float d = ALPHA ? (c4.x - ra) * g4.x + (c4.y - rr) * g4.y : (c4.y - rr) * g4.y;
+            d += (c4.z - rg) * g4.z;
+            d += (c4.w - rb) * g4.w;
+            return d;
+        };
+        NR_WPH(11);
+#ifdef NR_K6_NO_LOOPS  // development build: everything of the sweeps but the pixel loops
+        f0 = ra + cross; f1 = dba + c0k + c1k + (float)s_from + (float)s_to + (float)fnr;
+        if (false)
+#endif
+        if (cls < 2) {
+            // ---- U / M: SEG pixels of an out sweep, unrolled; one address register per array, compile-time offsets
+            const int l0 = base + s_from;
+            const float d1f0 = (float)s_from;
             const float t_first = d1f0 - cross;
             const float e0 = (0.0f < c0k * t_first) ? eps_f : -eps_f, e1 = (0.0f < c1k * t_first) ? eps_f : -eps_f;
-            // one address register per array; the pixels of the segment are compile-time offsets from it
             const float *gp = px.g + (RGB ? 4 : 1) * (size_t)l0, *cp = px.c + (RGB ? 4 : 1) * (size_t)l0;
-            // coverage bits of the segment's SEG pixels (bit k <=> pixel s_from + k is owned by some face): two words of the
-            // line's bit array, funnel-shifted -- the face index itself is not read on an out sweep (:707 is an in-sweep test)
-            unsigned cb;
-            {
-                const unsigned *cw = px.cov + ((h.z >> 16) & 0xff) * px.CW + (sr.s_from >> 5);
-                const unsigned w0 = cw[0], w1 = ((sr.s_from & 31) > 32 - SEG) ? cw[1] : 0u;  // (the last word of a line has no successor)
-                cb = (unsigned)(((((unsigned long long)w1) << 32) | w0) >> (sr.s_from & 31)) & ((1u << SEG) - 1u);
-            }
-#pragma unroll
-            for (int kb = 0; kb < SEG; kb += NR_K6_FB) {
-                float4 g4[NR_K6_FB];
-                float ga[NR_K6_FB], diff[NR_K6_FB];
-#pragma unroll
-                for (int j = 0; j < NR_K6_FB; ++j) {  // the batch's LDS requests first
-                    if (RGB) g4[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + j));
-                    else ga[j] = gp[kb + j];
-                }
+            // One visit without a branch (:647: a NaN diff is not `<= 0` and goes through): the visits of a batch are
+            // independent instruction chains that the scheduler interleaves -- a wave spends its time here waiting for its
+            // own dependent instructions and LDS reads, not for issue slots.  y is never 0 (x and its eps have one sign), so
+            // the reciprocal is finite wherever the contribution is taken (:648 / :653) and 0 * it adds nothing.
+            float d1fb = d1f0;  // (re-declared opaque per batch below: keeps the compiler from computing all SEG values of t ahead
+                                // of the loop, which costs a register each and pushed the kernel into spilling)
+            auto visit = [&](float diff, int k) {
+                const float dm = (diff <= 0.0f) ? 0.0f : diff;
+                const float t = (d1fb + (float)k) - cross;
+                const float x0 = c0k * t, x1 = c1k * t;                       // :649 / :654 (2 / S folded into c)
+                const float y0 = x0 + e0, y1 = x1 + e1;                       // :650 / :655
+                f0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), f0);      // :651
+                f1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), f1);      // :656
+            };
+            if (cls == 0) {
+                // U: gradients only; the next batch's LDS reads are in flight while this one is evaluated
+                float4 gc[NR_K6_FB], gn[NR_K6_FB];
+                float ac[NR_K6_FB], an[NR_K6_FB];
 #pragma unroll
                 for (int j = 0; j < NR_K6_FB; ++j) {
-                    if (RGB) {
-                        diff[j] = ALPHA ? dba * g4[j].x + dbr * g4[j].y : dbr * g4[j].y;
-                        diff[j] += dbg * g4[j].z;
-                        diff[j] += dbb * g4[j].w;
-                    } else {
-                        diff[j] = dba * ga[j];
-                    }
+                    gc[j] = gn[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    ac[j] = an[j] = 0.0f;
+                    if (RGB) gc[j] = *reinterpret_cast<const float4 *>(gp + 4 * j);
+                    else ac[j] = gp[j];
                 }
-                if ((cb >> kb) & ((1u << NR_K6_FB) - 1u)) {  // a covered pixel in the batch (1 visit in 8): its own colour
 #pragma unroll
-                    for (int j = 0; j < NR_K6_FB; ++j) {
-                        if (!((cb >> (kb + j)) & 1u)) continue;
-                        if (RGB) {
-                            const float4 c4 = *reinterpret_cast<const float4 *>(cp + 4 * (kb + j));
-                            float d = ALPHA ? (c4.x - ra) * g4[j].x + (c4.y - rr) * g4[j].y : (c4.y - rr) * g4[j].y;
-                            d += (c4.z - rg) * g4[j].z;
-                            d += (c4.w - rb) * g4[j].w;
-                            diff[j] = d;
-                        } else {
-                            diff[j] = (cp[kb + j] - ra) * ga[j];
+                for (int kb = 0; kb < SEG; kb += NR_K6_FB) {
+                    asm volatile("" : "+v"(d1fb));
+                    if (kb + NR_K6_FB < SEG) {
+#pragma unroll
+                        for (int j = 0; j < NR_K6_FB; ++j) {
+                            if (RGB) gn[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + NR_K6_FB + j));
+                            else an[j] = gp[kb + NR_K6_FB + j];
                         }
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < NR_K6_FB; ++j) {
-                    if (diff[j] <= 0.0f) continue;                                // :647 (a NaN diff is not `<= 0`)
-                    const float t = (d1f0 + (float)(kb + j)) - cross;
-                    const float x0 = c0k * t, x1 = c1k * t;                       // :649 / :654 (2 / S folded into c)
-                    const float y0 = x0 + e0, y1 = x1 + e1;                       // :650 / :655
-                    f0 = __builtin_fmaf(-diff[j], __builtin_amdgcn_rcpf(y0), f0); // :651
-                    f1 = __builtin_fmaf(-diff[j], __builtin_amdgcn_rcpf(y1), f1); // :656
+                    for (int j = 0; j < NR_K6_FB; ++j) visit(bg_diff(gc[j], ac[j]), kb + j);
+#pragma unroll
+                    for (int j = 0; j < NR_K6_FB; ++j) { gc[j] = gn[j]; ac[j] = an[j]; }
+                    __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting every batch's reads to the top)
+                }
+            } else {
+                // M: every pixel's colour as well -- an uncovered one holds the background colour (K5), so the same
+                // expression serves both
+#pragma unroll
+                for (int kb = 0; kb < SEG; kb += NR_K6_FB) {
+                    asm volatile("" : "+v"(d1fb));
+                    float4 g4[NR_K6_FB], c4[NR_K6_FB];
+                    float ga[NR_K6_FB], ca[NR_K6_FB];
+#pragma unroll
+                    for (int j = 0; j < NR_K6_FB; ++j) {
+                        g4[j] = c4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        ga[j] = ca[j] = 0.0f;
+                        if (RGB) {
+                            g4[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + j));
+                            c4[j] = *reinterpret_cast<const float4 *>(cp + 4 * (kb + j));
+                        } else {
+                            ga[j] = gp[kb + j];
+                            ca[j] = cp[kb + j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NR_K6_FB; ++j) visit(own_diff(c4[j], ca[j], g4[j], ga[j]), kb + j);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        } else
-#endif
-        {
-            // ---- class G: a piece of an in sweep or the remainder of an out sweep, the general loop
+        } else {
+            // ---- G: a piece of an in sweep or the remainder of an out sweep, the general loop
             const int own_mask = mode_in ? -1 : 0;
-            float d1f = (float)sr.s_from;
-            for (int l = base + sr.s_from; l <= base + sr.s_to; ++l, d1f += 1.0f) {
-                // One pixel visit.  Face index and gradients are requested together (one LDS round trip); only a covered
-                // pixel pays a second one for its colour.
+            float d1f = (float)s_from;
+            for (int l = base + s_from; l <= base + s_to; ++l, d1f += 1.0f) {
+                // face index, gradients and colour are requested together (one LDS round trip)
                 const int fi = px.fi[l];
-                float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                float ga = 0.0f;
-                if (RGB) g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
-                else ga = px.g[l];
-                const float diff = pixel_diff(l, fi, g4, ga);
+                float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c4 = g4;
+                float ga = 0.0f, ca = 0.0f;
+                if (RGB) { g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l); c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l); }
+                else { ga = px.g[l]; ca = px.c[l]; }
+                const float diff = own_diff(c4, ca, g4, ga);  // (an uncovered pixel holds the background colour)
                 // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
                 // control flow on the sweep kind
                 if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) continue;
@@ -1522,20 +1660,49 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                 f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
             }
         }
-        const double a0 = (flags & 2) ? (double)f0 : 0.0, a1 = (flags & 4) ? (double)f1 : 0.0;  // :648 / :653
-        if (a0 != 0.0) { const int i0 = acc_index(sr.line, h.w, 0); if (i0 >= 0) atomicAdd(&acc[i0], a0); else spill(h.w, fnr, 0, a0); }
-        if (a1 != 0.0) { const int i1 = acc_index(sr.line, h.w, 1); if (i1 >= 0) atomicAdd(&acc[i1], a1); else spill(h.w, fnr, 1, a1); }
+        NR_WPH(12 + cls);
+        float p0 = (valid && (flags & 2)) ? f0 : 0.0f, p1 = (valid && (flags & 4)) ? f1 : 0.0f;  // :648 / :653
+        const int key = valid ? line : -1 - (tid & 63);  // (a padding lane: a run of its own)
+#ifndef NR_K6_NO_RUNSUM
+        // The pieces of one line sit on neighbouring lanes (consecutive ids), and all of them add to the same two sums: 64
+        // lanes on ~10 addresses make the LDS serialise an atomic per lane.  So the sums of each run of equal lines are formed
+        // with DPP moves first (a segmented scan inside the 16-lane rows; a run that crosses a row is flushed in two parts),
+        // and only the last lane of a run issues the atomic.  The run sums are float like the segment sums they add up (<= 16
+        // of them, a tree of depth 4; in double the moves and selects come in pairs and the step costs what it saves at raster
+        // 256: stage 249 vs 239 us, 946 vs 897 at raster 512); everything behind them stays double.  Which pieces share a run
+        // depends on the order of the line records, so two calls agree to ~1e-6 of the largest gradient, not to the bit.
+        // (All 64 lanes execute this: the loop keeps the wave together.)
+        {
+            const int k1 = dpp_row_shr<1>(-1, key), k2 = dpp_row_shr<2>(-1, key), k4 = dpp_row_shr<4>(-1, key),
+                      k8 = dpp_row_shr<8>(-1, key);
+            float q0 = dpp_row_shr_f<1>(p0), q1 = dpp_row_shr_f<1>(p1);
+            if (k1 == key) { p0 += q0; p1 += q1; }
+            q0 = dpp_row_shr_f<2>(p0); q1 = dpp_row_shr_f<2>(p1);
+            if (k2 == key) { p0 += q0; p1 += q1; }
+            q0 = dpp_row_shr_f<4>(p0); q1 = dpp_row_shr_f<4>(p1);
+            if (k4 == key) { p0 += q0; p1 += q1; }
+            q0 = dpp_row_shr_f<8>(p0); q1 = dpp_row_shr_f<8>(p1);
+            if (k8 == key) { p0 += q0; p1 += q1; }
+            if (dpp_row_shl1(-1, key) == key) p0 = p1 = 0.0f;  // not the last lane of its run
+        }
+#endif
+        const double a0 = (double)p0, a1 = (double)p1;
+        if (a0 != 0.0) { const int i0 = acc_index(line, h.w, 0); if (i0 >= 0) atomicAdd(&acc[i0], a0); else spill(h.w, fnr, 0, a0); }
+        if (a1 != 0.0) { const int i1 = acc_index(line, h.w, 1); if (i1 >= 0) atomicAdd(&acc[i1], a1); else spill(h.w, fnr, 1, a1); }
+        NR_WPH(15);
     }
+    }
+    NR_WPH_END();
 }
 
-template <bool RGB, bool ALPHA, int WIN>
+template <bool RGB, bool ALPHA>
 __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
     double *__restrict__ scratch, const int *__restrict__ band_lines, const int *__restrict__ band_start,
     const int *__restrict__ lines_ok, const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int SP,
-    float eps_f, int B, int win_lines)
+    float eps_f, int B, int win_lines, int qcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -1561,8 +1728,11 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     px.bg = (float *)carve(16);
     px.CW = (SP + 31) >> 5;
     px.cov = (unsigned *)carve((size_t)W * px.CW * 4);
+    px.span = (int *)carve(4 * 2 * 4);  // (W <= 4 lines)
+    const int WIN = win_lines;        // line records per window (a multiple of 4; fast_band_config)
     BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
-    int *s_pref = (int *)carve(4 * WIN);
+    const bool wide = S > 255 * SEG;  // piece numbers beyond 8 bits: 32-bit descriptors
+    void *s_queue = carve((size_t)qcap * (wide ? 4 : 2));  // segment descriptors of a window (or of a round of it)
     int *s_tmp = (int *)carve(4 * 16);
     unsigned char *rest = smem + off;  // the two paths below lay out what is left differently
 
@@ -1571,6 +1741,16 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     for (int i = tid; i < W * px.CW; i += BAND_THREADS) px.cov[i] = 0u;
     __syncthreads();
     fast_stage<RGB, ALPHA>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, img, axis, band_lo, nld, S, SP);
+    __syncthreads();
+    if (tid < nld) {  // covered span of each band line (the sweeps' classification looks no further)
+        int first = 0x7fffffff, last = -1;
+        for (int w = 0; w < px.CW; ++w) {
+            const unsigned m = px.cov[tid * px.CW + w];
+            if (m) { first = min(first, 32 * w + __ffs((int)m) - 1); last = 32 * w + 31 - __clz((int)m); }
+        }
+        px.span[2 * tid] = first;
+        px.span[2 * tid + 1] = last;
+    }
     NR_PHASE(1);
 
     if (lines_ok[b]) {
@@ -1579,21 +1759,13 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
         const BandLine *recs = line_buf + (size_t)b * cap + band_start[bidx];
         for (int win = 0; win < n_band_lines; win += win_lines) {
             const int n_win = min(n_band_lines - win, win_lines);
-            int n_seg = 0;
-            if (tid < n_win) {
-                const BandLine r = recs[win + tid];
-                s_line[tid] = r;
-                n_seg = line_segments_fast(r.in_rng, r.out_rng);
-            }
+            if (tid < n_win) s_line[tid] = recs[win + tid];
             if (tid < 2 * n_win) s_lacc[tid] = 0.0;
-            int total_seg = 0;
-            const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);  // (two barriers inside: s_line is visible after)
-            if (tid < n_win) s_pref[tid] = seg_off;
             __syncthreads();
             NR_PHASE(5);
 #ifndef NR_K6_NO_SWEEPS
-            fast_sweeps<RGB, ALPHA>(px, s_line, s_pref, n_win, total_seg, SP, eps_f, s_lacc,
-                                    [](int line, int, int k) { return 2 * line + k; }, [](int, int, int, double) {});
+            fast_sweeps<RGB, ALPHA>(px, s_line, n_win, SP, eps_f, s_lacc, [](int line, int, int k) { return 2 * line + k; },
+                                    [](int, int, int, double) {}, s_queue, qcap, wide, reinterpret_cast<unsigned long long *>(s_tmp));
 #endif
             __syncthreads();
             NR_PHASE(6);
@@ -1615,8 +1787,8 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     int *s_rec = (int *)rest;
     int *s_recfn = s_rec + WIN;
     double *s_acc = (double *)(s_recfn + WIN);          // WIN is a multiple of 4: 8-byte aligned
-    int *s_slotpos = (int *)(s_acc + 3 * ACC_SLOTS);
-    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
+    int *s_slotpos = (int *)(s_acc + 3 * FAST_ACC_SLOTS);
+    if (tid < 3 * FAST_ACC_SLOTS) s_acc[tid] = 0.0;
     __syncthreads();
     const int n_vis = vis_count[b];
     const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
@@ -1638,7 +1810,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
         const int packed_off = block_excl_scan(nl | ((nl > 0) << 20), s_tmp, &total_packed);
         const int line_off = packed_off & 0xfffff, slot = packed_off >> 20;
         const int total_lines = total_packed & 0xfffff;
-        if (nl > 0 && slot < ACC_SLOTS) s_slotpos[slot] = chunk + tid;
+        if (nl > 0 && slot < FAST_ACC_SLOTS) s_slotpos[slot] = chunk + tid;
         NR_PHASE(2);
 
         for (int win = 0; win < total_lines; win += win_lines) {
@@ -1657,34 +1829,28 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
             NR_PHASE(3);
 
             // ---- 3. line setup, one line per thread
-            int n_seg = 0;
             if (tid < n_win) {
                 const int rec = s_rec[tid];
                 const int slot_l = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
                 const int rfn = s_recfn[tid];
-                const BandLine r = make_fast_line(faces + ((size_t)b * F + rfn) * 9, e, axis, band_lo + ld, ld, S, rfn,
-                                                  slot_l | (e << 16) | (((e + 1) % 3) << 18),
-                                                  [&](int d1) { return px.fi[ld * SP + d1]; });
-                s_line[tid] = r;
-                n_seg = line_segments_fast(r.in_rng, r.out_rng);
+                s_line[tid] = make_fast_line(faces + ((size_t)b * F + rfn) * 9, e, axis, band_lo + ld, ld, S, rfn,
+                                             slot_l | (e << 16) | (((e + 1) % 3) << 18),
+                                             [&](int d1) { return px.fi[ld * SP + d1]; });
             }
-            NR_PHASE(4);
-            int total_seg = 0;
-            const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
-            if (tid < n_win) s_pref[tid] = seg_off;
             __syncthreads();
-            NR_PHASE(5);
+            NR_PHASE(4);
 #ifndef NR_K6_NO_SWEEPS
             fast_sweeps<RGB, ALPHA>(
-                px, s_line, s_pref, n_win, total_seg, SP, eps_f, s_acc,
+                px, s_line, n_win, SP, eps_f, s_acc,
                 [](int, int tgt, int k) {
                     const int sl = tgt & 0xffff;
-                    return sl < ACC_SLOTS ? 3 * sl + ((tgt >> (k ? 18 : 16)) & 3) : -1;
+                    return sl < FAST_ACC_SLOTS ? 3 * sl + ((tgt >> (k ? 18 : 16)) & 3) : -1;
                 },
                 [&](int tgt, int fnr, int k, double a) {  // more faces with lines in this pass than LDS slots
                     const int pos = vis_position(vis_list + (size_t)b * F, n_vis, fnr);
                     atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * ((tgt >> (k ? 18 : 16)) & 3) + (1 - axis), a);
-                });
+                },
+                s_queue, qcap, wide, reinterpret_cast<unsigned long long *>(s_tmp));
 #endif
             __syncthreads();
             NR_PHASE(6);
@@ -1692,7 +1858,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
 
         // ---- 5. per-face sums of this chunk -> global double scratch
         {
-            const int n_slots = min(total_packed >> 20, ACC_SLOTS);
+            const int n_slots = min(total_packed >> 20, FAST_ACC_SLOTS);
             if (tid < 3 * n_slots) {
                 const int sl = tid / 3, v = tid - 3 * sl;
                 const double a = s_acc[tid];
@@ -1776,37 +1942,55 @@ ListsLayout lists_layout(int B, int F)
     return L;
 }
 
-constexpr size_t LDS_BUDGET = 53 * 1024 + 512;  // three workgroups per 160 KB CU (two with 256-line windows: 367 vs 337 us)
-constexpr int FAST_WIN_SMALL = 128;
-
-// line records + segment prefixes + scan scratch + background colour + the larger of the two paths' private parts
-// (records path: two double sums per line; scan path: compaction records + per-face accumulator slots) + alignment slack
-constexpr size_t band_fixed_lds(int win)
+constexpr size_t LDS_BUDGET = 53 * 1024;  // three workgroups per 160 KB CU, allocation granules of 512 bytes included (3 x 53.5 KB would not fit)
+// LDS of k_bpm_band (exact kernel): band width (lines per workgroup) for the given raster size and modes; 0 = does not fit
+// (global fallback)
+int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes, int w_max = 4)
 {
-    const size_t a = 16 * (size_t)win, b = 8 * (size_t)win + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS;
-    return (sizeof(BandLine) + 4) * (size_t)win + 64 + 16 + (a > b ? a : b) + 8 * 16;
-}
-
-// band width (lines per workgroup) and line window for the given raster size and modes; 0 = does not fit (global fallback)
-int band_width(int S, bool rgb, bool alpha, bool exact, size_t *lds_bytes, int *win, int w_max = 4)
-{
-    const size_t per_px = exact ? 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0) : (rgb ? 36 : 12);
+    const size_t per_px = 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0);
     const size_t SP = (size_t)S + 4;
     // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
     // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
     for (int W = w_max; W >= 1; W >>= 1) {
-        // three workgroups per CU with a 128-line window beat two with 256 (the phases of co-resident workgroups overlap)
-        for (int w = BAND_WIN; w >= (exact ? BAND_WIN : FAST_WIN_SMALL); w >>= 1) {
-            const size_t fixed = exact ? (sizeof(BandLine) + 12) * (size_t)w + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16
-                                       : band_fixed_lds(w);
-            // + the default kernel's coverage bits: (SP + 31) / 32 words per line
-            const size_t need = (size_t)W * SP * per_px + fixed + (exact ? 0 : align_up((size_t)W * ((SP + 31) / 32) * 4, 16));
-            if (need <= LDS_BUDGET || (W == 1 && w == (exact ? BAND_WIN : FAST_WIN_SMALL) && need <= 160 * 1024)) {
-                *lds_bytes = need;
-                *win = w;
-                return W;
-            }
+        const size_t fixed = (sizeof(BandLine) + 12) * (size_t)BAND_WIN + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16;
+        const size_t need = (size_t)W * SP * per_px + fixed;
+        if (need <= LDS_BUDGET || (W == 1 && need <= 160 * 1024)) {
+            *lds_bytes = need;
+            return W;
         }
+    }
+    return 0;
+}
+
+// LDS of k_bpm_fast: pixel arrays [W][SP] (face index 4 B, gradients and colours 16 B each -- 4 B each for alpha alone),
+// coverage bits, and what is left is split between the line window (32 B record + 16 B for the records path's two double
+// sums per line, or the scan path's compaction records and accumulator slots) and the segment queue (2 or 4 B per
+// descriptor; a line has ~S / 22 + 3 segments).  Returns W (0: the raster does not fit, global fallback).
+int fast_band_config(int S, bool rgb, int w_max, size_t *lds_bytes, int *win, int *qcap)
+{
+    const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 255 * SEG ? 4 : 2;
+    const size_t segs_per_line = (size_t)S / 22 + 3;
+    auto lines_bytes = [&](int ww) {
+        const size_t a = 16 * (size_t)ww, b = 8 * (size_t)ww + 28 * (size_t)FAST_ACC_SLOTS;
+        return sizeof(BandLine) * (size_t)ww + (a > b ? a : b);
+    };
+    for (int W = w_max; W >= 1; W >>= 1) {
+        const size_t px = (size_t)W * SP * per_px + align_up((size_t)W * ((SP + 31) / 32) * 4, 16) + 16 /* bg */ + 32 /* spans */ + 64 /* scan */ +
+                          8 * 16 /* alignment slack */;
+        // the three-workgroups-per-CU budget; a one-line band may take the whole LDS
+        const size_t lim = (W == 1 && px + lines_bytes(32) + BAND_THREADS * dsz > LDS_BUDGET) ? 160 * 1024 : LDS_BUDGET;
+        if (px + lines_bytes(32) + BAND_THREADS * dsz > lim) continue;
+        const size_t rest = lim - px;
+        int w = (int)(rest / (48 + segs_per_line * dsz));
+        w = max(32, min(BAND_WIN, w / 32 * 32));
+        while (w > 32 && lines_bytes(w) + BAND_THREADS * dsz > rest) w -= 32;
+        if (W > 1 && w < 96) continue;  // a band this wide leaves no room for a useful line window: narrower bands
+        size_t q = (rest - lines_bytes(w)) / dsz / BAND_THREADS * BAND_THREADS;
+        q = q > 16384 ? 16384 : q;
+        *win = w;
+        *qcap = (int)q;
+        *lds_bytes = px + lines_bytes(w) + q * dsz;
+        return W;
     }
     return 0;
 }
@@ -1852,19 +2036,19 @@ int launch_band(const float *faces, const int32_t *fi, const float *rgb, const f
     return 0;
 }
 
-template <bool RGB, bool ALPHA, int WIN>
+template <bool RGB, bool ALPHA>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
                 const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
-                int B, int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
+                int B, int F, int S, int W, size_t lds, double eps, int win_lines, int qcap, hipStream_t st)
 {
     static LdsLimit limit;
-    auto kern = k_bpm_fast<RGB, ALPHA, WIN>;
+    auto kern = k_bpm_fast<RGB, ALPHA>;
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
-                       (float)eps, B, min(win_lines, WIN));
+                       (float)eps, B, win_lines, qcap);
     return 0;
 }
 
@@ -1897,12 +2081,12 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const bool exact = (flags & NR_FLAG_EXACT_GRADIENT) != 0;
 
     size_t lds = 0;
-    int win = BAND_WIN;
+    int win = BAND_WIN, qcap = 0;
     // Narrower bands when the launch would have few band workgroups (small batches): the chip holds 768 of them at a time and
     // half of a teapot view's bands are empty; 16 views: stage 113 -> 104 us with W = 2, 4 views 70 -> 50, 1 view 66 -> 40 (W = 1).
     int w_max = 4;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
-    const int W = band_width(S, rgb, alpha, exact, &lds, &win, w_max);
+    const int W = exact ? band_width(S, rgb, alpha, &lds, w_max) : fast_band_config(S, rgb, w_max, &lds, &win, &qcap);
     if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
         const dim3 grid((unsigned)n), block(WAVE);
         if (rgb && alpha)
@@ -1976,8 +2160,9 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                            (const int *)(ws + L.cband_off), n_sum, band_lines, band_start, band_cursor, lines_ok, line_buf, L.cap, F,
                            S, W, n_bands);
     }
-    // lines per window: the packed segment scan keeps the count of full segments in 16 bits (<= win * 2 * S / SEG)
-    const int win_lines = max(1, min(BAND_WIN, (int)(65535ll * SEG / (2ll * S))));
+    // lines per window: the packed segment scans keep the count of full segments in 16 bits (<= win * 2 * S / SEG)
+    int win_lines = max(1, min(exact ? BAND_WIN : win, (int)(65535ll * SEG / (2ll * S))));
+    if (!exact) win_lines = max(4, win_lines & ~3);  // (k_bpm_fast lays 8-byte data out behind win_lines ints)
     int rc;
     if (exact) {
         const bool pow2 = (S & (S - 1)) == 0;
@@ -1990,13 +2175,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
 #undef NR_BAND
     } else {
 #define NR_FAST(R, A)                                                                                                   \
-    (win == BAND_WIN                                                                                                    \
-         ? launch_fast<R, A, BAND_WIN>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
-                                       vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, \
-                                       eps, win_lines, st)                                                                \
-         : launch_fast<R, A, FAST_WIN_SMALL>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map,    \
-                                             vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf,  \
-                                             L.cap, B, F, S, W, lds, eps, win_lines, st))
+    launch_fast<R, A>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch, \
+                      band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, win_lines, qcap, st)
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
     }
@@ -2074,9 +2254,9 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
 // development build only (not declared in include/nr_hip.h): cycles per phase of k_bpm_fast summed over workgroups
 NR_API int nr_debug_k6_phases(unsigned long long *out8, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_k6_phase), 8 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_k6_phase), 24 * sizeof(unsigned long long));
     if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[24] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_k6_phase), z, sizeof(z));
     }
     return (int)e;

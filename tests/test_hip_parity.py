@@ -20,6 +20,7 @@ RTOL = 1e-4  # north_star tolerance for floating-point outputs
 # terms in float through the hardware reciprocal, NR_FLAG_EXACT_GRADIENT with the reference's own arithmetic
 K6_BOUND_DEFAULT = 1e-4  # the north star's tolerance; measured 1e-6 .. 3e-5 (profiles/r02*_parity_errors.jsonl)
 K6_BOUND_EXACT = 2e-6
+SAME_TERMS = 4e-6  # two evaluations of the same per-pixel terms in different summation orders
 EXACT = 2  # _lib.NR_FLAG_EXACT_GRADIENT
 K6_GLOBAL = 4  # _lib.NR_FLAG_K6_GLOBAL
 K6_SCAN = 8    # _lib.NR_FLAG_K6_SCAN
@@ -271,12 +272,13 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
         if rgb or alpha:
             gf2, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                   use_face_inv_map=residual_maps, k6_flags=flags, use_visible=False)
-            # same terms either way; only the order of the double atomics (and of K8's float adds) can differ
-            assert H.rel_err(abi.host(gf2), gf) <= 1e-6
+            # same terms either way; what can differ is the order of the line records, hence which segment sums share a float
+            # run sum before the double atomics (and the order of K8's float adds): a few 1e-7 of the largest gradient
+            assert H.rel_err(abi.host(gf2), gf) <= SAME_TERMS
             if not flags & EXACT:  # the default kernel's second way to its line records (in-kernel face scan): same terms again
                 gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                       use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
-                assert H.rel_err(abi.host(gf3), gf) <= 1e-6
+                assert H.rel_err(abi.host(gf3), gf) <= SAME_TERMS
     if rgb:
         gt = abi.host(gt)
         assert not np.isnan(gt).any(), 'grad_textures has unwritten elements'
@@ -418,7 +420,8 @@ def test_determinism_and_batch_independence():
     rendered inside a batch equals the same view rendered alone (the property the multi-GPU sharding relies on).
     K6 sums its per-line / per-face partials with double-precision atomics whose order is not fixed: grad_faces is
     reproducible up to the rounding of a double sum to float (a last-bit difference in rare, heavily cancelling entries),
-    so the gradients are compared to 1e-6 of the largest one, not bit for bit."""
+    and the default kernel forms float sums over the
+    segments that happen to share a run of lanes: the gradients are compared to 4e-6 of the largest one, not bit for bit."""
     faces, _ = H.teapot_views(8, 128)
     rng = np.random.default_rng(13)
     g = rng.normal(size=(8, 128, 128)).astype(np.float32)
@@ -429,12 +432,12 @@ def test_determinism_and_batch_independence():
         outs.append((abi.host(fw['face_index_map']), abi.host(fw['depth_map']), abi.host(gf)))
     for a, b in list(zip(*outs))[:2]:
         np.testing.assert_array_equal(a, b)
-    assert H.rel_err(outs[0][2], outs[1][2]) <= 1e-6
+    assert H.rel_err(outs[0][2], outs[1][2]) <= SAME_TERMS
     fw1 = abi.forward(faces[5:6], None, 128, return_alpha=True, return_depth=True)
     gf1, _ = abi.backward(fw1, g_alpha=g[5:6])
     np.testing.assert_array_equal(abi.host(fw1['face_index_map'])[0], outs[0][0][5])
     np.testing.assert_array_equal(abi.host(fw1['depth_map'])[0], outs[0][1][5])
-    assert H.rel_err(abi.host(gf1)[0], outs[0][2][5]) <= 1e-6
+    assert H.rel_err(abi.host(gf1)[0], outs[0][2][5]) <= SAME_TERMS
 
 
 def test_headline_size_properties():
@@ -621,7 +624,9 @@ def test_high_resolution_dense_mesh():
 @pytest.mark.parametrize('modes', [(True, True, True), (False, True, False), (False, False, True), (True, False, False)],
                          ids=['all', 'alpha', 'depth', 'rgb'])
 def test_fused_backward_equals_stage_calls(modes):
-    """nr_backward_rasterize == nr_backward_pixel_map + nr_backward_textures + nr_backward_depth_map, bit for bit."""
+    """nr_backward_rasterize == nr_backward_pixel_map + nr_backward_textures + nr_backward_depth_map: the same kernels on the
+    same data, so grad_textures and the depth-only grad_faces agree bit for bit; with K6 in play grad_faces agrees up to the
+    order of its line records (placed with atomics: which segment sums share a float run sum, the order of the double adds)."""
     rgb, alpha, depth = modes
     faces, _ = H.teapot_views(3, 96)
     rng = np.random.default_rng(41)
@@ -632,7 +637,10 @@ def test_fused_backward_equals_stage_calls(modes):
     g_depth = rng.normal(size=(3, 96, 96)).astype(np.float32) if depth else None
     gf_a, gt_a = abi.backward(fw, g_rgb, g_alpha, g_depth)
     gf_b, gt_b = abi.backward_fused(fw, g_rgb, g_alpha, g_depth)
-    np.testing.assert_array_equal(abi.host(gf_a), abi.host(gf_b))
+    if rgb or alpha:
+        assert H.rel_err(abi.host(gf_a), abi.host(gf_b)) <= SAME_TERMS
+    else:
+        np.testing.assert_array_equal(abi.host(gf_a), abi.host(gf_b))
     if rgb:
         np.testing.assert_array_equal(abi.host(gt_a), abi.host(gt_b))
 
