@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     const float *__restrict__ g_rgb, float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts,
     double eps, int fix_batch_z, int L,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces)
+    float *__restrict__ grad_faces, const double *__restrict__ k6_scratch, const int *__restrict__ slot_of)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
     __shared__ int s_queue[512];  // owned pixels waiting for their evaluation (walk_owned_pixels)
@@ -141,12 +141,26 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     const int n_tex = ts * ts * ts * 3;
     int gi = blockIdx.x * (256 / L) + grp;  // global face index b * F + fn
     bool face_ok = gi < n_faces_total;
+    int slot = 0;
     if (vis_list) {  // blockIdx.y = image, slot -> face through the image's visible list
         // The grid covers F list slots per image, the list holds the ~1/6 of them that own a pixel: the other workgroups
         // leave here (they used to run the 24-sum reduction below on zeros -- 40 % of the kernel's instructions at the
-        // headline size).  Their faces' zeros come from the fill in front of the kernel (storing them from here, through a
-        // list of the invisible faces, cost 9 us to save a 6 us fill).
-        const int slot = gi, n_vis = vis_count[blockIdx.y];
+        // headline size).
+        if (slot_of) {
+            // Fused backward (K6's scratch and face -> list position map are handed over): this launch also finishes K6 --
+            // a listed face's grad_faces are the rounded scratch sums (+ the K8 sums), see the epilogue -- and every
+            // workgroup first STORES the zeros of the unlisted faces among the 256 / L faces with ITS numbers (grad_faces
+            // and grad_textures), which replaces k_bpm_finalize and the fill in front of this kernel: two launches and
+            // their gaps (~12 us of a 280 us backward) for stores that hide behind the gather's latency.
+            const int f = gi;  // this group's face by NUMBER (the list slot of the same number is dealt with below)
+            if (f < F && slot_of[(size_t)blockIdx.y * F + f] < 0) {
+                const size_t ff = (size_t)blockIdx.y * F + f;
+                if (sub < 9) grad_faces[ff * 9 + sub] = 0.0f;
+                for (int k = sub; k < n_tex; k += L) grad_textures[ff * n_tex + k] = 0.0f;
+            }
+        }
+        slot = gi;
+        const int n_vis = vis_count[blockIdx.y];
         if ((int)blockIdx.x * (256 / L) >= n_vis) return;
         face_ok = slot < n_vis;
         gi = face_ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + slot] : 0;
@@ -258,14 +272,27 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
             for (int k = sub; k < n_tex; k += L) dst[k] = (float)acc_l[k];
         }
     }
-    if (DEPTH) {  // L <= 64 here (the host only fuses when a face group fits in one wave)
-        if (__ballot(any_box) == 0ull) return;
+    if (DEPTH || k6_scratch) {  // L <= 64 when DEPTH (the host only fuses K8 when a face group fits in one wave)
+        if (DEPTH && __ballot(any_box) != 0ull) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) dacc[k] = (L == 16) ? row16_sum_last(dacc[k]) : group_sum(dacc[k], L);
-        if (face_ok && any_box && sub == ((L == 16) ? 15 : 0)) {
+            for (int k = 0; k < 9; k++) dacc[k] = (L == 16) ? row16_sum_last(dacc[k]) : group_sum(dacc[k], L);
+        }
+        if (face_ok && sub == ((L == 16) ? 15 : 0)) {
             float *gf = grad_faces + (size_t)gi * 9;
+            if (k6_scratch) {
+                // K6's result for this face (rasterize.py:736 stores, K8 then accumulates, :881-883): the double sums of
+                // its list position rounded to float, z = 0; the K8 sums (zero without a box of this kernel's) on top
+                const double *sc = k6_scratch + ((size_t)blockIdx.y * F + slot) * 6;
 #pragma unroll
-            for (int k = 0; k < 9; k++) gf[k] += dacc[k];
+                for (int v = 0; v < 3; v++) {
+                    gf[3 * v + 0] = (float)sc[2 * v + 0] + dacc[3 * v + 0];
+                    gf[3 * v + 1] = (float)sc[2 * v + 1] + dacc[3 * v + 1];
+                    gf[3 * v + 2] = 0.0f + dacc[3 * v + 2];
+                }
+            } else if (any_box) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) gf[k] += dacc[k];
+            }
         }
     }
 }
@@ -572,9 +599,11 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
                               const float *weight_map,
                               const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F,
                               int S, int ts, double eps, int flags, const int *vis_list, const int *vis_count,
-                              hipStream_t st, const float *g_depth, float *grad_faces, int *depth_done)
+                              hipStream_t st, const float *g_depth, float *grad_faces, int *depth_done,
+                              const double *k6_scratch, const int *slot_of, int *k6_finalized)
 {
     if (depth_done) *depth_done = 0;
+    if (k6_finalized) *k6_finalized = 0;
     if (!face_index_map || !grad_rgb_map || !grad_textures || !faces) return NR_E_NULL;
     if ((sampling_index_map == nullptr) != (sampling_weight_map == nullptr)) return NR_E_MODE;
     if (!sampling_weight_map && (!weight_map || !depth_map)) return NR_E_NULL;
@@ -591,7 +620,11 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     const bool ts2_static = ts == 2 && (float)(1.0 - eps) < 1.0f;
     if (ts == 2 && !ts2_static) g_depth = nullptr;
     if (g_depth && depth_done) *depth_done = 1;
-    if (vis_list) {
+    // K6's finish folded into the gather (see the kernel): needs the lists, a face-per-group kernel and somewhere to store
+    const bool fold = vis_list && k6_scratch && slot_of && grad_faces && ts <= 13;
+    if (!fold) k6_scratch = nullptr, slot_of = nullptr;
+    if (fold && k6_finalized) *k6_finalized = 1;
+    if (vis_list && !fold) {
         // only visible faces are visited: everything else is zero
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
@@ -601,11 +634,13 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         if (g_depth)
             hipLaunchKernelGGL((k_backward_textures_face<true, true>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces);
+                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
+                               slot_of);
         else
             hipLaunchKernelGGL((k_backward_textures_face<true, false>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, nullptr, nullptr);
+                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, (const float *)nullptr,
+                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of);
     } else if (ts <= 13) {
         const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
         const int per = 256 / L;
@@ -614,11 +649,13 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         if (g_depth && L <= 64)
             hipLaunchKernelGGL((k_backward_textures_face<false, true>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces);
+                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
+                               slot_of);
         else
             hipLaunchKernelGGL((k_backward_textures_face<false, false>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, nullptr, nullptr);
+                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, (const float *)nullptr,
+                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of);
     }
     if (ts <= 8) {
         // faces the gathers above left out (more than BIG_PX candidates): a workgroup each
@@ -672,7 +709,7 @@ NR_API int nr_backward_textures(const int32_t *face_index_map, const float *samp
 {
     return run_backward_textures(face_index_map, sampling_weight_map, sampling_index_map, faces, faces_z_ref, weight_map,
                                  depth_map, grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, nullptr, nullptr,
-                                 (hipStream_t)stream, nullptr, nullptr, nullptr);
+                                 (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 NR_API int nr_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,

@@ -2112,10 +2112,13 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                                const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                                float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
                                int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
-                               hipStream_t st, const int **vis_list_out, const int **vis_count_out)
+                               hipStream_t st, const int **vis_list_out, const int **vis_count_out,
+                               const double **defer_scratch, const int **defer_slot_of)
 {
     if (vis_list_out) *vis_list_out = nullptr;
     if (vis_count_out) *vis_count_out = nullptr;
+    if (defer_scratch) *defer_scratch = nullptr;
+    if (defer_slot_of) *defer_slot_of = nullptr;
     if (!faces || !face_index_map || !grad_faces) return NR_E_NULL;
     if (!return_rgb && !return_alpha) return NR_E_MODE;  // rasterize.py:523-524 returns early; callers skip the call
     if (return_rgb && (!rgb_map || !grad_rgb_map)) return NR_E_NULL;
@@ -2227,9 +2230,21 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
 #undef NR_FAST
     }
     if (rc) return rc;
+    if (defer_scratch && defer_slot_of) {  // the caller finishes (the fused gather, in the same launch as K7 / K8)
+        *defer_scratch = scratch;
+        *defer_slot_of = slot_of;
+        return launch_status();
+    }
     hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, slot_of, grad_faces,
                        F, n);
     return launch_status();
+}
+
+void nr::run_bpm_finalize(const double *scratch, const int *slot_of, float *grad_faces, int B, int F, hipStream_t st)
+{
+    const int n = B * F;
+    hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, slot_of, grad_faces,
+                       F, n);
 }
 
 NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
@@ -2258,11 +2273,17 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
     hipStream_t st = (hipStream_t)stream;
     const bool use_rgb = grad_rgb_map != nullptr, use_alpha = grad_alpha_map != nullptr, use_depth = grad_depth_map != nullptr;
     const int *vis_list = nullptr, *vis_count = nullptr;
+    // K6's last step (rounding the double sums into grad_faces, zeros for the unlisted faces) rides in the K7 / K8 gather's
+    // launch when there is one that walks faces (texture_size <= 13)
+    const bool fold = use_rgb && grad_textures && ts >= 2 && ts <= 13;
+    const double *k6_scratch = nullptr;
+    const int *k6_slot_of = nullptr;
     if (use_rgb || use_alpha) {
         if (int rc = run_backward_pixel_map(faces, face_index_map, use_rgb ? rgb_map : nullptr,
                                             use_alpha ? alpha_map : nullptr, grad_rgb_map, grad_alpha_map, grad_faces,
                                             B, F, S, eps, use_rgb, use_alpha, flags, visible_faces, workspace,
-                                            workspace_bytes, st, &vis_list, &vis_count))
+                                            workspace_bytes, st, &vis_list, &vis_count, fold ? &k6_scratch : nullptr,
+                                            fold ? &k6_slot_of : nullptr))
             return rc;
     } else {
         const hipError_t e = hipMemsetAsync(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
@@ -2283,10 +2304,13 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
     int depth_done = 0;
     if (use_rgb && grad_textures) {
         // when both gradients are wanted, K8 rides along in the K7 gather (one walk of each face's screen box)
+        int finalized = 0;
         if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, faces_z_ref, weight_map, depth_map,
                                            grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
-                                           use_depth ? grad_depth_map : nullptr, grad_faces, &depth_done))
+                                           use_depth ? grad_depth_map : nullptr, grad_faces, &depth_done, k6_scratch,
+                                           k6_slot_of, &finalized))
             return rc;
+        if (k6_scratch && !finalized) run_bpm_finalize(k6_scratch, k6_slot_of, grad_faces, B, F, st);  // (not expected)
     }
     if (use_depth && !depth_done) {
         if (int rc = run_backward_depth_map(faces, depth_map, face_index_map, nullptr, weight_map, grad_depth_map,

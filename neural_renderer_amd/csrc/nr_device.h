@@ -244,13 +244,20 @@ int run_backward_pixel_map(const float *faces, const int32_t *face_index_map, co
                            const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                            float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
                            int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
-                           hipStream_t st, const int **vis_list_out, const int **vis_count_out);
+                           hipStream_t st, const int **vis_list_out, const int **vis_count_out,
+                           const double **defer_scratch = nullptr, const int **defer_slot_of = nullptr);
+// defer_scratch / defer_slot_of (both or none): the caller will finish K6 itself -- rounding the double sums of the listed
+// faces into grad_faces and storing the zeros of the others (run_backward_textures does, or run_bpm_finalize) -- so
+// k_bpm_finalize is not launched; NULLs come back when the band pipeline did not run (global-memory fallback: grad_faces
+// are complete).
+void run_bpm_finalize(const double *scratch, const int *slot_of, float *grad_faces, int B, int F, hipStream_t st);
 int run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
                           const int32_t *sampling_index_map, const float *faces, const float *faces_z_ref,
                           const float *weight_map,
                           const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F, int S,
                           int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st,
-                          const float *g_depth_fused, float *grad_faces_fused, int *depth_done);
+                          const float *g_depth_fused, float *grad_faces_fused, int *depth_done,
+                          const double *k6_scratch, const int *slot_of, int *k6_finalized);
 int run_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                            const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
                            float *grad_faces, int B, int F, int S, const int *vis_list, const int *vis_count,
