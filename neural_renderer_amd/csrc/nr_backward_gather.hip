@@ -146,19 +146,11 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         // The grid covers F list slots per image, the list holds the ~1/6 of them that own a pixel: the other workgroups
         // leave here (they used to run the 24-sum reduction below on zeros -- 40 % of the kernel's instructions at the
         // headline size).
-        if (slot_of) {
-            // Fused backward (K6's scratch and face -> list position map are handed over): this launch also finishes K6 --
-            // a listed face's grad_faces are the rounded scratch sums (+ the K8 sums), see the epilogue -- and every
-            // workgroup first STORES the zeros of the unlisted faces among the 256 / L faces with ITS numbers (grad_faces
-            // and grad_textures), which replaces k_bpm_finalize and the fill in front of this kernel: two launches and
-            // their gaps (~12 us of a 280 us backward) for stores that hide behind the gather's latency.
-            const int f = gi;  // this group's face by NUMBER (the list slot of the same number is dealt with below)
-            if (f < F && slot_of[(size_t)blockIdx.y * F + f] < 0) {
-                const size_t ff = (size_t)blockIdx.y * F + f;
-                if (sub < 9) grad_faces[ff * 9 + sub] = 0.0f;
-                for (int k = sub; k < n_tex; k += L) grad_textures[ff * n_tex + k] = 0.0f;
-            }
-        }
+        // (Fused backward with K6's scratch handed over: the epilogue also finishes K6 for the listed faces.  The unlisted
+        // faces' zeros come from K6's compaction kernel (grad_faces) and from the fill in front of this launch (grad_textures):
+        // storing them from here -- every workgroup the faces with its numbers -- was measured: neutral at the headline size,
+        // +19 us on config 4 and 2.5x this kernel's time on 1024 views of 32 x 32, where 5 M faces mean 300 k workgroups that
+        // each wait for a slot_of load before they can leave.)
         slot = gi;
         const int n_vis = vis_count[blockIdx.y];
         if ((int)blockIdx.x * (256 / L) >= n_vis) return;
@@ -624,7 +616,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     const bool fold = vis_list && k6_scratch && slot_of && grad_faces && ts <= 13;
     if (!fold) k6_scratch = nullptr, slot_of = nullptr;
     if (fold && k6_finalized) *k6_finalized = 1;
-    if (vis_list && !fold) {
+    if (vis_list) {
         // only visible faces are visited: everything else is zero
         const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != hipSuccess) return (int)e;

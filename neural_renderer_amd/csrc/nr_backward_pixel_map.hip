@@ -329,6 +329,14 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
     z[0] = z[1] = z[2] = make_double2(0.0, 0.0);
 }
 
+// grad_faces of a face that owns no pixel (K6 contributes nothing, rasterize.py:604 / :707; K8 neither): when the fused
+// backward finishes K6 inside its gather launch, the compaction -- which visits every face anyway -- stores these zeros
+__device__ __forceinline__ void zero_face(float *__restrict__ o)
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) o[k] = 0.0f;
+}
+
 // Ordered compaction: every face gets slot_of = its position in the image's sorted list of visible faces, or -1.  One
 // workgroup per chunk of 1024 faces.
 //   Meshes of up to SMALL_CHUNKS chunks, one launch (k_compact_par): a workgroup counts the flags of the chunks in front of
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *
                                                            const float *__restrict__ faces, unsigned *__restrict__ rng,
                                                            double *__restrict__ scratch, int S,
                                                            int *__restrict__ chunk_band, int n_bands, int W,
-                                                           int *__restrict__ band_cursor)
+                                                           int *__restrict__ band_cursor, float *__restrict__ zero_faces)
 {
     extern __shared__ int s_band[];  // [2][n_bands] lines per band of this chunk's faces
     __shared__ int s_wcnt[VIS_CHUNK / 64];
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *
         const int before = off + __popcll(m & ((1ull << lane) - 1ull));  // visible faces in front of fn
         slot_of[(size_t)b * F + fn] = v ? before : -1;
         if (v) emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W);
+        else if (zero_faces) zero_face(zero_faces + ((size_t)b * F + fn) * 9);
     }
     __syncthreads();
     int *row = chunk_band + ((size_t)b * n_chunks + chunk) * 2 * n_bands;
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
                                                                const float *__restrict__ faces,
                                                                unsigned *__restrict__ rng, double *__restrict__ scratch,
                                                                int S, int *__restrict__ band_lines, int n_bands, int W,
-                                                               int lds_counters)
+                                                               int lds_counters, float *__restrict__ zero_faces)
 {
     // This workgroup's lines per band are counted in LDS and only the non-zero counters go to the image's global ones:
     // one device-wide atomic per (face, edge, band) cost 315 us on config 5 (same-address atomics from all 8 XCDs).
@@ -469,6 +478,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
     if (fn < F) {
         const int before = off + __popcll(m & ((1ull << lane) - 1ull));  // visible faces in front of fn
         slot_of[(size_t)b * F + fn] = v ? before : -1;
+        if (!v && zero_faces) zero_face(zero_faces + ((size_t)b * F + fn) * 9);
         if (v)
             emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch,
                          lds_counters ? s_band : band_lines + (size_t)b * 2 * n_bands, n_bands, W);
@@ -1748,7 +1758,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
     double *__restrict__ scratch, const int *__restrict__ band_lines, const int *__restrict__ band_start,
     const int *__restrict__ lines_ok, const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int SP,
-    float eps_f, int B, int win_lines, int qcap)
+    float eps_f, int B, int win_lines, int win_scan, int qcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -1775,9 +1785,15 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     px.CW = (((SP + 31) >> 5) + 3) & ~3;  // words per line, a multiple of four (16-byte reads of the classification)
     px.cov = (unsigned *)carve((size_t)W * px.CW * 4);
     px.span = (int *)carve(4 * 2 * 4);  // (W <= 4 lines)
-    const int WIN = win_lines;        // line records per window (a multiple of 4; fast_band_config)
-    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
     const bool wide = S > 255 * FSEG;  // piece numbers beyond 8 bits: 32-bit descriptors
+    // The rest of the workgroup's LDS is split between the line window (32 B record + the private part of the path: two
+    // double sums per line, or the scan path's compaction records and accumulator slots) and the segment queue by the host
+    // (fast_band_config).  (A per-band split inside the kernel -- equal windows, as few as let a window's segments through the
+    // queue in one round -- was measured and lost to the fixed split, 258 vs 242 us: it trades windows of 224 lines with two
+    // rounds for twice as many windows.)
+    const int WIN = min(win_lines, win_scan);  // (win_lines: the cap that keeps a window's segment counts in 16 bits)
+    win_lines = WIN;
+    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
     void *s_queue = carve((size_t)qcap * (wide ? 4 : 2));  // segment descriptors of a window (or of a round of it)
     int *s_tmp = (int *)carve(4 * 16);
     unsigned char *rest = smem + off;  // the two paths below lay out what is left differently
@@ -2011,11 +2027,17 @@ int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes, int w_max = 4)
 // LDS of k_bpm_fast: pixel arrays [W][SP] (face index 4 B, gradients and colours 16 B each -- 4 B each for alpha alone),
 // coverage bits, and what is left is split between the line window (32 B record + 16 B for the records path's two double
 // sums per line, or the scan path's compaction records and accumulator slots) and the segment queue (2 or 4 B per
-// descriptor; a line has ~S / 22 + 3 segments).  Returns W (0: the raster does not fit, global fallback).
+// descriptor).  Returns W (0: the raster does not fit, global fallback).
 int fast_band_config(int S, bool rgb, int w_max, size_t *lds_bytes, int *win, int *qcap)
 {
     const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 255 * FSEG ? 4 : 2;
-    const size_t segs_per_line = (size_t)S / 22 + 3;
+    // segments per line the split is made for: measured, stage times in us, raster 256: S/22 (192 lines, 3072 descriptors)
+    // 240, S/32 (224, 2560) 230, S/48 (256, 2048: two rounds per window) 267; raster 512: S/22 (160, 4096) 906, S/32 (192,
+    // 3584) 891, S/48 (224, 2560) 766 -- a band of a 512 x 512 teapot view has ~185 lines: one window instead of two
+#ifndef NR_K6_SPL_DIV
+#define NR_K6_SPL_DIV (S <= 320 ? 32 : 48)
+#endif
+    const size_t segs_per_line = (size_t)S / NR_K6_SPL_DIV + 3;
     auto lines_bytes = [&](int ww) {
         const size_t a = 16 * (size_t)ww, b = 8 * (size_t)ww + 28 * (size_t)FAST_ACC_SLOTS;
         return sizeof(BandLine) * (size_t)ww + (a > b ? a : b);
@@ -2086,7 +2108,7 @@ template <bool RGB, bool ALPHA>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
                 const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
-                int B, int F, int S, int W, size_t lds, double eps, int win_lines, int qcap, hipStream_t st)
+                int B, int F, int S, int W, size_t lds, double eps, int win_lines, int win_scan, int qcap, hipStream_t st)
 {
     static LdsLimit limit;
     auto kern = k_bpm_fast<RGB, ALPHA>;
@@ -2094,7 +2116,7 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
-                       (float)eps, B, win_lines, qcap);
+                       (float)eps, B, win_lines, win_scan, qcap);
     return 0;
 }
 
@@ -2152,6 +2174,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
 
     const BpmLayout L = bpm_layout(B, F, S);
     if (!workspace || workspace_bytes < L.total) return NR_E_WORKSPACE;
+    const bool defer = defer_scratch && defer_slot_of;  // the caller's gather finishes the listed faces (see nr_device.h)
     unsigned char *ws = (unsigned char *)workspace;
     int *band_lines = (int *)(ws + L.band_off);
     const int n_bands = (S + W - 1) / W;
@@ -2185,7 +2208,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         n_sum = L.n_chunks;
         hipLaunchKernelGGL(k_compact_par, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK),
                            (size_t)2 * n_bands * sizeof(int), st, vflags, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng,
-                           scratch, S, chunk_band, n_bands, W, band_cursor);
+                           scratch, S, chunk_band, n_bands, W, band_cursor, defer ? grad_faces : (float *)nullptr);
         if (!use_records)
             hipLaunchKernelGGL(k_band_total, dim3((unsigned)B), dim3(256), 0, st, chunk_band, n_sum, band_lines, band_start,
                                lines_ok, n_bands);
@@ -2196,7 +2219,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         const int lds_counters = n_bands <= 4096;  // 32 KB of LDS at most
         hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK),
                            lds_counters ? (size_t)2 * n_bands * sizeof(int) : 0, st, vflags, chunk_count, vis_list, vis_count,
-                           slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W, lds_counters);
+                           slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W, lds_counters,
+                           defer ? grad_faces : (float *)nullptr);
         if (!exact)
             hipLaunchKernelGGL(k_band_scan, dim3((unsigned)B), dim3(256), 0, st, band_lines, band_start, band_cursor, lines_ok,
                                n_bands, cap, 0);
@@ -2210,7 +2234,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                            S, W, n_bands);
     }
     // lines per window: the packed segment scans keep the count of full segments in 16 bits (<= win * 2 * S / SEG)
-    int win_lines = max(1, min(exact ? BAND_WIN : win, (int)(65535ll * (exact ? SEG : FSEG) / (2ll * S))));
+    int win_lines = max(1, min(BAND_WIN, (int)(65535ll * (exact ? SEG : FSEG) / (2ll * S))));
     if (!exact) win_lines = max(4, win_lines & ~3);  // (k_bpm_fast lays 8-byte data out behind win_lines ints)
     int rc;
     if (exact) {
@@ -2225,12 +2249,12 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     } else {
 #define NR_FAST(R, A)                                                                                                   \
     launch_fast<R, A>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch, \
-                      band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, win_lines, qcap, st)
+                      band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, win_lines, win, qcap, st)
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
     }
     if (rc) return rc;
-    if (defer_scratch && defer_slot_of) {  // the caller finishes (the fused gather, in the same launch as K7 / K8)
+    if (defer) {  // the caller finishes the listed faces (the fused gather, in the same launch as K7 / K8)
         *defer_scratch = scratch;
         *defer_slot_of = slot_of;
         return launch_status();

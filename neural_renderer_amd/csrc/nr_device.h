@@ -246,10 +246,10 @@ int run_backward_pixel_map(const float *faces, const int32_t *face_index_map, co
                            int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
                            hipStream_t st, const int **vis_list_out, const int **vis_count_out,
                            const double **defer_scratch = nullptr, const int **defer_slot_of = nullptr);
-// defer_scratch / defer_slot_of (both or none): the caller will finish K6 itself -- rounding the double sums of the listed
-// faces into grad_faces and storing the zeros of the others (run_backward_textures does, or run_bpm_finalize) -- so
-// k_bpm_finalize is not launched; NULLs come back when the band pipeline did not run (global-memory fallback: grad_faces
-// are complete).
+// defer_scratch / defer_slot_of (both or none): the caller will finish K6 itself for the LISTED faces -- rounding the double
+// sums of their list positions into grad_faces (run_backward_textures does, or run_bpm_finalize for all faces) -- so
+// k_bpm_finalize is not launched and the compaction kernel stores the zeros of the unlisted faces; NULLs come back when
+// the band pipeline did not run (global-memory fallback: grad_faces are complete).
 void run_bpm_finalize(const double *scratch, const int *slot_of, float *grad_faces, int B, int F, hipStream_t st);
 int run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
                           const int32_t *sampling_index_map, const float *faces, const float *faces_z_ref,
