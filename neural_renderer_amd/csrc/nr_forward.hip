@@ -51,6 +51,17 @@ __device__ __forceinline__ unsigned depth_key(float zp)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// z-buffer word.  Classic (epoch < 0): depth key << 32 | face index, empty = all ones after the per-call fill.  Epoch mode
+// (NR_FLAG_ZBUF_EPOCH, a workspace the caller keeps between calls): epoch << 56 | depth key << 24 | face index (< 2^24); the
+// caller counts the epoch DOWN from call to call, so every word of an earlier call is larger than any word of this one and
+// loses the atomic minimum -- no fill and no clean-up pass (3 x 33.5 MB of z-buffer traffic per forward become 2 x) -- and
+// the resolve pass treats a word whose epoch is not the current one as empty.
+__device__ __forceinline__ unsigned long long zword(float zp, unsigned fn, int epoch)
+{
+    const unsigned long long k = depth_key(zp);
+    return epoch < 0 ? (k << 32) | fn : ((unsigned long long)(unsigned)epoch << 56) | (k << 24) | fn;
+}
+
 struct FaceGeo {
     float x0, y0, z0, x1, y1, z1, x2, y2, z2, i0, i1, i2, i3, i4, i5, i6, i7, i8;
 };
@@ -181,7 +192,7 @@ __device__ __forceinline__ void wave_lds_sync()
 template <int FACES>
 __device__ __forceinline__ bool slot_pixel(const FaceWaveLds<FACES> &L, int e, int S, double near_d, double far_d,
                                            unsigned long long *__restrict__ zbuf, unsigned long long &key,
-                                           unsigned long long *&at)
+                                           unsigned long long *&at, int epoch)
 {
     const int s = e >> 16;
     FaceGeo q;
@@ -191,7 +202,7 @@ __device__ __forceinline__ bool slot_pixel(const FaceWaveLds<FACES> &L, int e, i
     const int x = L.x_lo[s] + (e & 255), y = L.y_lo[s] + ((e >> 8) & 255);
     float zp, w0, w1, w2;
     const bool ok = eval_inside(q, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2);
-    key = ((unsigned long long)depth_key(zp) << 32) | (unsigned)L.fn[s];
+    key = zword(zp, (unsigned)L.fn[s], epoch);
     at = zbuf + ((size_t)L.img[s] * S + y) * S + x;
     return ok;
 }
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                                                      int *__restrict__ large_list, int *__restrict__ wave_list,
                                                      int *__restrict__ n_large,
                                                      unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
-                                                     int S, double near_d, double far_d)
+                                                     int S, double near_d, double far_d, int epoch)
 {
     __shared__ FaceWaveLds<FACES> lds[4];
     FaceWaveLds<FACES> &L = lds[threadIdx.x >> 6];
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                 const int pix_here = min(FR_PIX, n_pix - pbase);
                 for (int pp = lane; pp < pix_here; pp += 64) {
                     unsigned long long key, *at;
-                    if (slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key, at)) atomicMin(at, key);
+                    if (slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key, at, epoch)) atomicMin(at, key);
                 }
                 FWD_PH(5);
             }
@@ -368,7 +379,7 @@ constexpr int CQ = 128;  // queue words per wave: < 64 waiting + <= 64 new
 template <class PixelOf>
 __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu, int n_cand, int first, int step,
                                                   PixelOf pixel_of, int *__restrict__ queue, int S, double near_d,
-                                                  double far_d, unsigned long long *__restrict__ zimg)
+                                                  double far_d, unsigned long long *__restrict__ zimg, int epoch)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -379,7 +390,7 @@ __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu
         const int x = e & 0xffff, y = e >> 16;
         float zp, w0, w1, w2;
         if (eval_inside(g, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2))
-            atomicMin(zimg + (size_t)y * S + x, ((unsigned long long)depth_key(zp) << 32) | fnu);
+            atomicMin(zimg + (size_t)y * S + x, zword(zp, fnu, epoch));
     };
     for (int base = first; base < n_cand; base += step) {  // (wave-uniform trip count)
         const int k = base + lane;
@@ -408,7 +419,7 @@ __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu
 // queues 1/5 of its faces): one wave per face, lanes stride over the box.
 __device__ __forceinline__ void wave_raster(const float *__restrict__ faces, unsigned long long *__restrict__ zbuf,
                                             const int *__restrict__ wave_list, const int *__restrict__ n_wave, int F, int S,
-                                            double near_d, double far_d, int *__restrict__ queue)
+                                            double near_d, double far_d, int *__restrict__ queue, int epoch)
 {
     const int n = *n_wave + 1;  // the counter starts at -1
     const int waves = gridDim.x * (blockDim.x >> 6);
@@ -428,7 +439,7 @@ __device__ __forceinline__ void wave_raster(const float *__restrict__ faces, uns
                 y = cd.y_lo + yy;
                 return true;
             },
-            queue, S, near_d, far_d, zbuf + (size_t)b * S * S);
+            queue, S, near_d, far_d, zbuf + (size_t)b * S * S, epoch);
     }
 }
 
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
                                                       unsigned long long *__restrict__ zbuf,
                                                       const int *__restrict__ large_list, const int *__restrict__ wave_list,
                                                       const int *__restrict__ n_large, int F, int S, double near_d,
-                                                      double far_d)
+                                                      double far_d, int epoch)
 {
     __shared__ int s_queue[4][CQ];
     int *queue = s_queue[threadIdx.x >> 6];
@@ -454,9 +465,9 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
         raster_candidates(
             g, (unsigned)(i - b * F), cd.n, (int)(threadIdx.x >> 6) * 64, 256,
             [&](int k, int &x, int &y) { return cand_pixel(cd, k, S, x, y); }, queue, S, near_d, far_d,
-            zbuf + (size_t)b * S * S);
+            zbuf + (size_t)b * S * S, epoch);
     }
-    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d, queue);
+    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d, queue, epoch);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -548,9 +559,12 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
                                                  const float *__restrict__ zbase, const float *__restrict__ textures,
                                                  float *__restrict__ rgb_map, const float *__restrict__ background,
                                                  int bg_per_batch, float *__restrict__ alpha_map, int ts, double eps,
-                                                 int fix_batch_z)
+                                                 int fix_batch_z, int epoch, int *__restrict__ queue_counters)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // epoch mode: nobody fills the workspace for the next call, so the two queue counters go back to -1 here (the raster
+    // kernels that read them are done: this launch is behind them on the stream)
+    if (i == 0 && epoch >= 0) { queue_counters[0] = -1; queue_counters[1] = -1; }
     if (i >= n_pixels) return;
     const unsigned long long pk = zbuf[i];
     int fn = -1;
@@ -558,8 +572,9 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
     float inv[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     int b = 0;
     if (rgb_map || alpha_map) b = (int)(i / ((size_t)S * S));
-    if (pk != ZEMPTY) {
-        fn = (int)(unsigned)(pk & 0xffffffffu);
+    const bool hit = epoch < 0 ? pk != ZEMPTY : (int)(pk >> 56) == epoch;
+    if (hit) {
+        fn = epoch < 0 ? (int)(unsigned)(pk & 0xffffffffu) : (int)(unsigned)(pk & 0xffffffu);
         const size_t SS = (size_t)S * S;
         b = (int)(i / SS);
         const int pn = (int)(i - (size_t)b * SS);
@@ -631,7 +646,8 @@ namespace {
 int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, float *depth_map, float *face_inv_map,
                 unsigned char *visible_faces, int B, int F, int S, double near, double far, void *workspace,
                 size_t workspace_bytes, hipStream_t st, const float *faces_z_ref, const float *textures, float *rgb_map,
-                const float *background, int bg_per_batch, float *alpha_map, int ts, double eps, int fix_batch_z)
+                const float *background, int bg_per_batch, float *alpha_map, int ts, double eps, int fix_batch_z,
+                int flags = 0)
 {
     if (!faces || !face_index_map) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
@@ -643,26 +659,34 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     int *n_large = (int *)(ws + L.count_off);
     int *large_list = (int *)(ws + L.list_off);
 
-    // one fill: ZEMPTY words and, right behind them, the large-face counter at -1
-    const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
-    if (he != hipSuccess) return (int)he;
+    // Epoch mode (NR_FLAG_ZBUF_EPOCH, see zword): the caller keeps the workspace, filled it with 0xff bytes once and counts
+    // the epoch down; nothing is filled here.  It needs face indices below 2^24; otherwise, and without the flag:
+    // one fill: ZEMPTY words and, right behind them, the two queue counters at -1
+    int epoch = -1;
+    if ((flags & NR_FLAG_ZBUF_EPOCH) && F < (1 << 24)) {
+        epoch = (flags >> 8) & 0xff;
+        if (epoch > 254) return NR_E_MODE;  // 255 is the epoch of a freshly filled word
+    } else {
+        const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
+        if (he != hipSuccess) return (int)he;
+    }
     int *wave_list = large_list + n;
     {
         const bool pow2 = (S & (S - 1)) == 0, few = n < 2048 * 64;
 #define NR_FACE_RASTER(P, FC, G)                                                                                           \
     hipLaunchKernelGGL((k_face_raster<P, FC, G>), dim3((unsigned)((n + 4 * FC - 1) / (4 * FC))), dim3(256), 0, st, faces, zbuf, \
-                       large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far)
+                       large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far, epoch)
         if (few) { if (pow2) NR_FACE_RASTER(true, 32, 8); else NR_FACE_RASTER(false, 32, 8); }
         else { if (pow2) NR_FACE_RASTER(true, 64, 16); else NR_FACE_RASTER(false, 64, 16); }
 #undef NR_FACE_RASTER
     }
     // a resident grid loops over the two queues; with empty queues (a fine mesh) its workgroups read two counters and leave
     hipLaunchKernelGGL(k_large_raster, dim3(2048), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
-                       far);
+                       far, epoch);
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, zbuf, face_index_map,
                        weight_map, depth_map, face_inv_map, visible_faces, F, S, near, far, P,
                        faces_z_ref ? faces_z_ref : faces, textures, rgb_map, background, bg_per_batch, alpha_map, ts, eps,
-                       fix_batch_z);
+                       fix_batch_z, epoch, n_large);
     return launch_status();
 }
 }  // namespace
@@ -690,7 +714,7 @@ NR_API int nr_forward_rasterize(const float *faces, const float *faces_z_ref, co
     }
     return run_forward(faces, face_index_map, weight_map, depth_map, nullptr, visible_faces, B, F, S, near, far,
                        workspace, workspace_bytes, (hipStream_t)stream, faces_z_ref, textures, rgb_map, background,
-                       bg_per_batch, alpha_map, ts, eps, (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0);
+                       bg_per_batch, alpha_map, ts, eps, (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, flags);
 }
 
 NR_API int nr_forward_texture_sampling(const float *faces, const float *faces_z_ref, const float *textures,

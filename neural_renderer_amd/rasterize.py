@@ -59,6 +59,33 @@ def _background_tensor(bg, device):
     return t
 
 
+_ZBUF_CACHE = {}
+
+
+def _forward_workspace(lib, dev, stream, B, F, S):
+    """The forward's scratch (z-buffer + queues) and the flags that go with it.  Kept per (device, stream, sizes) and reused
+    with a falling epoch number (include/nr_hip.h: NR_FLAG_ZBUF_EPOCH), so that the library neither fills the z-buffer
+    before a call nor cleans it afterwards; refilled with 0xff every 255 calls.  While a HIP graph is being captured the
+    epoch would be frozen into the graph, so capture takes a throw-away workspace and the filling path."""
+    ws_bytes = lib.nr_forward_workspace_bytes(B, F, S)
+    if ws_bytes == 0:
+        raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
+    if F >= (1 << 24) or torch.cuda.is_current_stream_capturing():
+        return torch.empty((ws_bytes,), dtype=torch.uint8, device=dev), ws_bytes, 0
+    key = (dev.index, int(stream), B, F, S)
+    ent = _ZBUF_CACHE.get(key)
+    if ent is None:
+        if len(_ZBUF_CACHE) >= 8:  # a handful of shapes at a time: drop the oldest
+            _ZBUF_CACHE.pop(next(iter(_ZBUF_CACHE)))
+        ent = _ZBUF_CACHE[key] = [torch.empty((ws_bytes,), dtype=torch.uint8, device=dev), -1]
+    if ent[1] < 0:
+        ent[0].fill_(255)
+        ent[1] = 254
+    epoch = ent[1]
+    ent[1] -= 1
+    return ent[0], ws_bytes, _lib.NR_FLAG_ZBUF_EPOCH | (epoch << 8)
+
+
 class _RasterizeFunction(torch.autograd.Function):
     """forward(ctx, faces, textures, cfg) -> (rgb_map [B,S,S,3] | None, alpha_map [B,S,S] | None,
     depth_map [B,S,S] | None); backward(ctx, g_rgb, g_alpha, g_depth) -> (grad_faces, grad_textures, None)."""
@@ -96,10 +123,7 @@ class _RasterizeFunction(torch.autograd.Function):
             face_index_map = torch.empty((B, S, S), dtype=torch.int32, device=dev)
             weight_map = torch.empty((B, S, S, 3), dtype=torch.float32, device=dev) if need_wd else None
             depth_map = torch.empty((B, S, S), dtype=torch.float32, device=dev) if need_wd else None
-            ws_bytes = lib.nr_forward_workspace_bytes(B, F, S)
-            if ws_bytes == 0:
-                raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
-            workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            workspace, ws_bytes, ws_flags = _forward_workspace(lib, dev, stream, B, F, S)
             rgb_map = alpha_map = background = None
             bg_per_batch = 0
             if return_rgb:
@@ -132,7 +156,7 @@ class _RasterizeFunction(torch.autograd.Function):
                 faces_c.data_ptr(), _lib.ptr(z_ref), _lib.ptr(textures_c), face_index_map.data_ptr(),
                 _lib.ptr(weight_map), _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(alpha_map), _lib.ptr(visible),
                 _lib.ptr(background), bg_per_batch, B, F, S, ts, float(cfg['near']), float(cfg['far']),
-                float(cfg['eps']), flags, workspace.data_ptr(), ws_bytes, stream), 'nr_forward_rasterize')
+                float(cfg['eps']), flags | ws_flags, workspace.data_ptr(), ws_bytes, stream), 'nr_forward_rasterize')
 
         ctx.cfg = dict(cfg, keep=None, B=B, F=F, S=S, ts=ts, flags=flags)
         keep = cfg.get('keep')

@@ -128,8 +128,8 @@ def backward_fused(fw, g_rgb=None, g_alpha=None, g_depth=None, k6_flags=0, use_v
 
 
 def forward_fused(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, background=(0, 0, 0), flags=0,
-                  return_rgb=False, return_alpha=True, return_depth=False, faces_z_ref=None):
-    """nr_forward_rasterize (visibility + shading behind one call)."""
+                  return_rgb=False, return_alpha=True, return_depth=False, faces_z_ref=None, workspace=None):
+    """nr_forward_rasterize (visibility + shading behind one call).  workspace: a kept scratch tensor (NR_FLAG_ZBUF_EPOCH calls)."""
     lib = _lib.load()
     f = dev(faces, torch.float32)
     B, F = f.shape[:2]
@@ -149,7 +149,7 @@ def forward_fused(faces, textures=None, S=64, near=0.1, far=100.0, eps=1e-4, bac
     if return_alpha:
         out['alpha_map'] = torch.full((B, S, S), float('nan'), device='cuda')
     wsb = lib.nr_forward_workspace_bytes(B, F, S)
-    ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+    ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device='cuda')
     _lib.check(lib.nr_forward_rasterize(
         f.data_ptr(), _lib.ptr(out['faces_z_ref']), _lib.ptr(t), out['face_index_map'].data_ptr(),
         out['weight_map'].data_ptr(), out['depth_map'].data_ptr(), _lib.ptr(out.get('rgb_map')),

@@ -742,6 +742,46 @@ def test_fused_forward_equals_stage_calls():
         np.testing.assert_array_equal(abi.host(a[k]), abi.host(b[k]), err_msg=k)
 
 
+def test_kept_workspace_epochs_equal_the_filling_forward():
+    """NR_FLAG_ZBUF_EPOCH (include/nr_hip.h): a forward workspace kept between calls, filled with 0xff once and used with
+    falling epoch numbers, gives the maps of the per-call-fill path bit for bit -- over a whole cycle of 255 epochs with the
+    scene changing from call to call (stale words of every earlier scene must read as empty), across the refill, with queued
+    large faces (the queue counters are reset by the resolve pass), and the operator (which runs this way) agrees too."""
+    from neural_renderer_amd import _lib
+    import neural_renderer_amd as nr
+    rng = np.random.default_rng(77)
+    S = 48
+    scenes = []
+    for k in range(4):
+        f = H.random_scene(rng, 2, 60, size=0.2 + 0.2 * k)
+        f[:, 0, :, :2] *= 6.0   # a face with a large screen box: goes through the queues
+        scenes.append(f)
+    tex = rng.uniform(0, 1, (2, 60, 2, 2, 2, 3)).astype(np.float32)
+    ref = [abi.forward_fused(f, tex, S, 0.1, 100.0, 1e-3, (0.2, 0.3, 0.4), 0, True, True, True) for f in scenes]
+    lib = _lib.load()
+    ws = torch.empty(lib.nr_forward_workspace_bytes(2, 60, S), dtype=torch.uint8, device='cuda')
+    names = ('face_index_map', 'weight_map', 'depth_map', 'rgb_map', 'alpha_map', 'visible_faces')
+    call = 0
+    for cycle in range(2):
+        ws.fill_(255)
+        for epoch in range(254, -1, -1):
+            k = call % 4
+            call += 1
+            if cycle == 1 and epoch < 250:
+                break  # (the second cycle only has to prove the refill)
+            fw = abi.forward_fused(scenes[k], tex, S, 0.1, 100.0, 1e-3, (0.2, 0.3, 0.4), _lib.NR_FLAG_ZBUF_EPOCH | (epoch << 8),
+                                   True, True, True, workspace=ws)
+            if epoch % 16 == 0 or epoch > 250 or epoch < 3:
+                for name in names:
+                    np.testing.assert_array_equal(abi.host(fw[name]), abi.host(ref[k][name]), err_msg='%s epoch %d' % (name, epoch))
+    # the operator: several calls in a row on changing scenes
+    for k in (0, 1, 2, 3, 0):
+        rgb, alpha, depth = nr.Rasterize(S, 0.1, 100, 1e-3, (0.2, 0.3, 0.4), True, True, True)(
+            torch.tensor(scenes[k], device='cuda'), torch.tensor(tex, device='cuda'))
+        np.testing.assert_array_equal(rgb.cpu().numpy(), abi.host(ref[k]['rgb_map']))
+        np.testing.assert_array_equal(depth.cpu().numpy(), abi.host(ref[k]['depth_map']))
+
+
 def test_vertices_to_faces_gather_and_atomic_scatter():
     """nr_vertices_to_faces / _backward (reference vertices_to_faces.py:4-21 + Chainer get_item backward) through the
     torch-facing function: the gather is exact, the scatter-add matches np.add.at up to float summation order."""
