@@ -3,7 +3,7 @@
 The public names are the reference's (neural_renderer/__init__.py:1-16); `import neural_renderer` is an alias package."""
 # the operator and its wrappers (HIP kernels behind include/nr_hip.h)
 from .rasterize import (Rasterize, rasterize, rasterize_depth, rasterize_rgbad, rasterize_silhouettes,
-                        use_unsafe_rasterizer)
+                        use_unsafe_rasterizer, use_graph_replay)
 from .renderer import Renderer
 # geometry / lighting glue in front of the rasterizer
 from .cross import cross
@@ -22,6 +22,6 @@ from .save_obj import save_obj
 from . import distributed, graph
 
 __version__ = '0.2.0'
-__all__ = ['Rasterize', 'rasterize', 'rasterize_depth', 'rasterize_rgbad', 'rasterize_silhouettes', 'use_unsafe_rasterizer',
+__all__ = ['Rasterize', 'rasterize', 'rasterize_depth', 'rasterize_rgbad', 'rasterize_silhouettes', 'use_unsafe_rasterizer', 'use_graph_replay',
            'Renderer', 'cross', 'get_points_from_angles', 'lighting', 'look', 'look_at', 'perspective', 'vertices_to_faces',
            'load_obj', 'Mesh', 'Adam', 'save_obj']

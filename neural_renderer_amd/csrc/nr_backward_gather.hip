@@ -618,8 +618,8 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     if (fold && k6_finalized) *k6_finalized = 1;
     if (vis_list) {
         // only visible faces are visited: everything else is zero
-        const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+        const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
+        if (e != 0) return e;
     }
     if (ts2_static && !sampling_weight_map) {
         const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
@@ -665,8 +665,8 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     }
     if (ts > 13) {
         // huge cubes: the reference's per-pixel scatter with hardware atomics
-        const hipError_t e = hipMemsetAsync(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+        const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
+        if (e != 0) return e;
         const size_t np = (size_t)B * S * S;
         hipLaunchKernelGGL(k_backward_textures_atomic, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st,
                            face_index_map, sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map,

@@ -2083,7 +2083,7 @@ struct LdsLimit {
         if (lds <= have && dev != 31) return 0;
         const size_t want = lds > have ? lds : have;
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
-        if (e != hipSuccess) return (int)e;
+        if (e != 0) return e;
         granted[dev].store(want, std::memory_order_release);
         return 0;
     }
@@ -2188,8 +2188,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const unsigned char *vflags = visible_faces;
     if (!vflags) {  // the forward's flags were not kept: one pass over face_index_map rebuilds them
         unsigned char *f = ws + L.flags_off;
-        const hipError_t he = hipMemsetAsync(f, 0, (size_t)n, st);
-        if (he != hipSuccess) return (int)he;
+        const int he = fill_bytes(f, 0, (size_t)n, st);
+        if (he != 0) return he;
         const size_t P = (size_t)B * S * S;
         hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, face_index_map, f, F,
                            S * S, P);
@@ -2310,8 +2310,8 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
                                             fold ? &k6_slot_of : nullptr))
             return rc;
     } else {
-        const hipError_t e = hipMemsetAsync(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
-        if (e != hipSuccess) return (int)e;
+        const int e = fill_bytes(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
+        if (e != 0) return e;
         // depth only: no K6 and therefore no lists -- built from the forward's flags when there are any (one launch), so that
         // the K8 gather visits the ~1/6 of the faces that own a pixel
         const ListsLayout L = lists_layout(B, F);

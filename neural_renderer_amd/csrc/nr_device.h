@@ -222,6 +222,30 @@ __device__ __forceinline__ unsigned xcd_block(unsigned n_blocks)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+#ifdef __HIPCC__
+// Fills of the library's own instead of hipMemsetAsync: a captured HIP graph that holds a memset node on memory from outside
+// the graph's pool misbehaves on replay on ROCm 7.2 (the 0xff fill of the z-buffer faults on the second replay, the zero
+// fill of grad_textures leaves garbage) -- found with the operator's graph-replay mode.  Kernel nodes replay fine.
+static __global__ __launch_bounds__(256) void k_fill_bytes(unsigned char *__restrict__ dst, size_t bytes, unsigned value32)
+{
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i0 >= bytes) return;
+    if (i0 + 16 <= bytes && ((size_t)(dst + i0) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst + i0) = make_uint4(value32, value32, value32, value32);
+    } else {
+        for (size_t i = i0; i < bytes && i < i0 + 16; ++i) dst[i] = (unsigned char)value32;
+    }
+}
+// every byte of [dst, dst + bytes) = byte; returns a hipError_t as int (0 = ok)
+inline int fill_bytes(void *dst, int byte, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return 0;
+    const unsigned b = (unsigned)(byte & 0xff), v = b | (b << 8) | (b << 16) | (b << 24);
+    hipLaunchKernelGGL(k_fill_bytes, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, st, (unsigned char *)dst, bytes, v);
+    return (int)hipGetLastError();
+}
+#endif
+
 inline int check_sizes(int B, int F, int S)
 {
     if (B < 1 || B > 65535 || F < 1 || S < 1 || S > 16384) return NR_E_SIZE;  // B: several kernels put the image on grid.y

@@ -667,8 +667,7 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
         epoch = (flags >> 8) & 0xff;
         if (epoch > 254) return NR_E_MODE;  // 255 is the epoch of a freshly filled word
     } else {
-        const hipError_t he = hipMemsetAsync(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st);
-        if (he != hipSuccess) return (int)he;
+        if (int he = fill_bytes(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st)) return he;  // (nr_device.h: not a memset node)
     }
     int *wave_list = large_list + n;
     {

@@ -506,16 +506,16 @@ NR_API int nr_frontend_backward(const float *vertices, const int32_t *faces_idx,
     if (grad_eye) {
         if (!workspace || workspace_bytes < nr_frontend_workspace_bytes(B)) return NR_E_WORKSPACE;
         cam_acc = (double *)workspace;
-        hipError_t e = hipMemsetAsync(cam_acc, 0, nr_frontend_workspace_bytes(B), st);
-        if (e != hipSuccess) return (int)e;
+        int e = fill_bytes(cam_acc, 0, nr_frontend_workspace_bytes(B), st);
+        if (e != 0) return e;
         if (!eye_per_batch) {
-            e = hipMemsetAsync(grad_eye, 0, 3 * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
+            e = fill_bytes(grad_eye, 0, 3 * sizeof(float), st);
+            if (e != 0) return e;
         }
     }
     if (grad_vertices) {
-        const hipError_t e = hipMemsetAsync(grad_vertices, 0, (size_t)B * Nv * 3 * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+        const int e = fill_bytes(grad_vertices, 0, (size_t)B * Nv * 3 * sizeof(float), st);
+        if (e != 0) return e;
     }
     const dim3 grid((unsigned)(((size_t)Nf * FE_LANES + FE_THREADS - 1) / FE_THREADS), (unsigned)B);
     hipLaunchKernelGGL(k_frontend_backward, grid, dim3(FE_THREADS), 0, st, vertices, faces_idx, textures, eye, grad_faces,

@@ -70,8 +70,8 @@ NR_API int nr_vertices_to_faces_backward(const float *grad_faces, const int32_t 
     if (!grad_faces || !faces_idx || !grad_vertices) return NR_E_NULL;
     if (B < 1 || Nv < 1 || Nf < 1) return NR_E_SIZE;
     hipStream_t st = (hipStream_t)stream;
-    const hipError_t e = hipMemsetAsync(grad_vertices, 0, (size_t)B * Nv * 3 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    const int e = fill_bytes(grad_vertices, 0, (size_t)B * Nv * 3 * sizeof(float), st);
+    if (e != 0) return e;
     const size_t cpb = (size_t)Nf * 3, n = (size_t)B * cpb;
     hipLaunchKernelGGL(k_vertices_to_faces_backward, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, grad_faces,
                        faces_idx, grad_vertices, Nv, n, cpb, idx_per_batch);

@@ -59,6 +59,24 @@ def _background_tensor(bg, device):
     return t
 
 
+# Graph replay (not in the reference): for fixed shapes the forward and the backward of the operator are each captured once
+# in a HIP graph and replayed from then on -- at small batches the ~12 launches of a step take longer to ISSUE than to run
+# (BASELINE config 2, 16 views: 0.27 ms eager, 0.18 ms replayed).  Off by default; `use_graph_replay(True)`, the
+# NR_GRAPH_REPLAY=1 environment variable (read once, here) or the `graph_replay` attribute of a Rasterize / Renderer
+# instance switch it on.  Semantics stay those of the eager operator: inputs are copied into the graphs' fixed buffers and
+# results are returned as copies, so callers may keep them; what replay cannot offer is two forwards of the same shapes in
+# flight before the first one's backward (the residual maps live in the fixed buffers) -- that raises.  Measured (config 2):
+# 0.25 ms eager -> 0.21 ms with replay; a step captured as a whole by the caller (neural_renderer_amd.graph.capture: no
+# copies, loss and optimizer inside) 0.17 ms -- prefer that where the whole step is fixed.  Known limitation (ROCm 7.2 /
+# torch 2.10): a whole-step capture started AFTER this mode has run in the same process crashes; use one or the other.
+GRAPH_REPLAY = bool(int(os.environ.get('NR_GRAPH_REPLAY', '0')))
+
+
+def use_graph_replay(flag):
+    global GRAPH_REPLAY
+    GRAPH_REPLAY = bool(flag)
+
+
 _ZBUF_CACHE = {}
 
 
@@ -218,6 +236,173 @@ class _RasterizeFunction(torch.autograd.Function):
         return grad_faces, grad_textures, None
 
 
+def _capture(fn, dev):
+    """Warm `fn` up on a side stream, then capture it (see neural_renderer_amd.graph.capture)."""
+    from .graph import capture
+    return capture(fn, dev, warmup=2)
+
+
+class _GraphEntry(object):
+    """Fixed buffers + captured graphs of one (device, sizes, configuration) of the operator."""
+
+    def __init__(self, lib, dev, cfg, B, F, S, ts, bg, bg_per_batch, has_z_ref):
+        self.lib, self.dev, self.cfg = lib, dev, cfg
+        self.dims = (B, F, S, ts)
+        f32 = dict(dtype=torch.float32, device=dev)
+        rgb, alpha, depth = cfg['return_rgb'], cfg['return_alpha'], cfg['return_depth']
+        need_wd = rgb or depth
+        self.faces = torch.zeros((B, F, 3, 3), **f32)
+        self.textures = torch.zeros((B, F, ts, ts, ts, 3), **f32) if rgb else None
+        self.z_ref = torch.zeros((F, 3, 3), **f32) if has_z_ref else None
+        self.background = bg.clone() if bg is not None else None
+        self.bg_per_batch = bg_per_batch
+        self.face_index_map = torch.empty((B, S, S), dtype=torch.int32, device=dev)
+        self.weight_map = torch.empty((B, S, S, 3), **f32) if need_wd else None
+        self.depth_map = torch.empty((B, S, S), **f32) if need_wd else None
+        self.rgb_map = torch.empty((B, S, S, 3), **f32) if rgb else None
+        self.alpha_map = torch.empty((B, S, S), **f32) if alpha else None
+        self.visible = torch.empty((B, F), dtype=torch.uint8, device=dev)
+        ws_bytes = lib.nr_forward_workspace_bytes(B, F, S)
+        if ws_bytes == 0:
+            raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
+        self.fwd_ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        self.flags = (_lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg['fix_batch_z'] else 0) | \
+                     (_lib.NR_FLAG_EXACT_GRADIENT if cfg['exact_gradient'] else 0)
+        self.generation = 0
+        self.pending = None  # generation of the forward whose residuals the buffers hold and whose backward may still come
+        self.bwd = {}        # (use_rgb, use_alpha, use_depth, want grad_textures) -> (graph, buffers)
+        self.eager_bwd = {}  # the same for combinations the forward did not foresee: (launcher, buffers)
+        with torch.cuda.device(dev):
+            self.fwd = _capture(self._forward, dev)
+
+    def _forward(self):
+        B, F, S, ts = self.dims
+        cfg = self.cfg
+        _lib.check(self.lib.nr_forward_rasterize(
+            self.faces.data_ptr(), _lib.ptr(self.z_ref), _lib.ptr(self.textures), self.face_index_map.data_ptr(),
+            _lib.ptr(self.weight_map), _lib.ptr(self.depth_map), _lib.ptr(self.rgb_map), _lib.ptr(self.alpha_map),
+            self.visible.data_ptr(), _lib.ptr(self.background), self.bg_per_batch, B, F, S, ts, float(cfg['near']),
+            float(cfg['far']), float(cfg['eps']), self.flags, self.fwd_ws.data_ptr(), self.fwd_ws.numel(),
+            _stream_ptr(self.dev)), 'nr_forward_rasterize')
+
+    def _backward_buffers(self, use_rgb, use_alpha, use_depth, want_gt):
+        B, F, S, ts = self.dims
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        buf = {'g_rgb': torch.zeros((B, S, S, 3), **f32) if use_rgb else None,
+               'g_alpha': torch.zeros((B, S, S), **f32) if use_alpha else None,
+               'g_depth': torch.zeros((B, S, S), **f32) if use_depth else None,
+               'grad_faces': torch.empty((B, F, 3, 3), **f32),
+               'grad_textures': torch.empty((B, F, ts, ts, ts, 3), **f32) if want_gt else None}
+        ws_bytes = self.lib.nr_backward_workspace_bytes(B, F, S, int(use_rgb), int(use_alpha))
+        buf['ws'] = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=self.dev)
+
+        def run():
+            _lib.check(self.lib.nr_backward_rasterize(
+                self.faces.data_ptr(), _lib.ptr(self.z_ref), self.face_index_map.data_ptr(), _lib.ptr(self.weight_map),
+                _lib.ptr(self.depth_map), _lib.ptr(self.rgb_map) if use_rgb else None,
+                _lib.ptr(self.alpha_map) if use_alpha else None, _lib.ptr(buf['g_rgb']), _lib.ptr(buf['g_alpha']),
+                _lib.ptr(buf['g_depth']), buf['grad_faces'].data_ptr(), _lib.ptr(buf['grad_textures']), B, F, S, ts,
+                float(self.cfg['eps']), self.flags, self.visible.data_ptr(), buf['ws'].data_ptr(), ws_bytes,
+                _stream_ptr(self.dev)), 'nr_backward_rasterize')
+        return run, buf
+
+    def prepare_backward(self, key):
+        """Capture the backward for one combination of present gradients -- on the CALLER's thread, from the forward: autograd
+        runs `backward` on its own device thread, and a graph captured there left the process in a state in which a later
+        capture on the main thread crashed (ROCm 7.2 / torch 2.10)."""
+        if key not in self.bwd:
+            run, buf = self._backward_buffers(*key)
+            with torch.cuda.device(self.dev):
+                self.bwd[key] = (_capture(run, self.dev), buf)
+
+    def backward_runner(self, key):
+        """(callable, buffers): the captured graph when the forward prepared this combination, else plain launches."""
+        ent = self.bwd.get(key)
+        if ent is None:
+            ent = self.eager_bwd.get(key)
+            if ent is None:
+                ent = self.eager_bwd[key] = self._backward_buffers(*key)
+        return ent
+
+
+_GRAPH_CACHE = {}
+
+
+class _GraphedRasterizeFunction(torch.autograd.Function):
+    """The operator replayed from captured graphs (see GRAPH_REPLAY): same results as _RasterizeFunction."""
+
+    @staticmethod
+    def forward(ctx, faces, textures, entry):
+        cfg = entry.cfg
+        entry.faces.copy_(faces.detach())
+        if entry.textures is not None:
+            entry.textures.copy_(textures.detach())
+        entry.fwd()
+        entry.generation += 1
+        entry.pending = entry.generation
+        ctx.entry, ctx.generation = entry, entry.generation
+        ctx.set_materialize_grads(False)
+        fi = entry.face_index_map.clone()
+        ctx.mark_non_differentiable(fi)
+        return (entry.rgb_map.clone() if cfg['return_rgb'] else None, entry.alpha_map.clone() if cfg['return_alpha'] else None,
+                entry.depth_map.clone() if cfg['return_depth'] else None, fi)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth, _g_fi):
+        entry, cfg = ctx.entry, ctx.entry.cfg
+        if entry.generation != ctx.generation:
+            raise RuntimeError('graph replay: a later forward of the same shapes has replaced the residual maps of this call; '
+                               'run backward before the next forward of these shapes, or switch graph replay off')
+        use_rgb = cfg['return_rgb'] and g_rgb is not None
+        use_alpha = cfg['return_alpha'] and g_alpha is not None
+        use_depth = cfg['return_depth'] and g_depth is not None
+        if not (use_rgb or use_alpha or use_depth):
+            return None, None, None
+        want_gt = bool(use_rgb and ctx.needs_input_grad[1])
+        graph, buf = entry.backward_runner((use_rgb, use_alpha, use_depth, want_gt))
+        for name, g in (('g_rgb', g_rgb if use_rgb else None), ('g_alpha', g_alpha if use_alpha else None),
+                        ('g_depth', g_depth if use_depth else None)):
+            if g is not None:
+                buf[name].copy_(g)
+        graph()
+        return buf['grad_faces'].clone(), (buf['grad_textures'].clone() if want_gt else None), None
+
+
+def _graph_entry(faces, textures, cfg):
+    """The cached graphs for this call's device / sizes / configuration, or None when the call is not eligible (CPU tensors
+    raise in the eager operator; tensor-valued backgrounds or z references that change between calls are handled by value)."""
+    if not faces.is_cuda or faces.dtype != torch.float32 or faces.dim() != 4 or torch.cuda.is_current_stream_capturing():
+        return None
+    dev = faces.device
+    B, F = int(faces.shape[0]), int(faces.shape[1])
+    S = int(cfg['image_size'])
+    ts = 0
+    bg, bg_per_batch, bg_key = None, 0, None
+    if cfg['return_rgb']:
+        if textures is None or textures.dim() != 6 or textures.dtype != torch.float32 or tuple(textures.shape[:2]) != (B, F):
+            return None
+        ts = int(textures.shape[2])
+        b = cfg['background_color']
+        if torch.is_tensor(b):
+            return None  # a device-side background may change between calls: eager path
+        arr = np.asarray(b, dtype=np.float32)
+        if arr.shape == (B, 3):
+            bg_per_batch = 1
+        elif arr.shape != (3,):
+            return None
+        bg, bg_key = _background_tensor(b, dev), arr.tobytes()
+    if cfg.get('faces_z_ref') is not None:
+        return None  # sharded batches hand a reference view over per call: eager path
+    key = (dev.index, B, F, S, ts, cfg['return_rgb'], cfg['return_alpha'], cfg['return_depth'], float(cfg['near']),
+           float(cfg['far']), float(cfg['eps']), bg_key, bg_per_batch, cfg['fix_batch_z'], cfg['exact_gradient'])
+    entry = _GRAPH_CACHE.get(key)
+    if entry is None:
+        if len(_GRAPH_CACHE) >= 8:
+            _GRAPH_CACHE.pop(next(iter(_GRAPH_CACHE)))
+        entry = _GRAPH_CACHE[key] = _GraphEntry(_lib.load(), dev, dict(cfg), B, F, S, ts, bg, bg_per_batch, False)
+    return entry
+
+
 class _ImageEpilogue(torch.autograd.Function):
     """rgb_map [B,S,S,3] -> [B,3,is,is], alpha / depth maps [B,S,S] -> [B,is,is]: NHWC -> NCHW, vertical flip and (with
     anti-aliasing) the 2x2 mean of rasterize.py:953-969, forward and backward each as one kernel (csrc/nr_image.hip)."""
@@ -284,6 +469,7 @@ class Rasterize(object):
         self.return_depth = return_depth
         self.fix_batch_z = FIX_TEXTURE_BATCH_Z
         self.exact_gradient = EXACT_GRADIENT
+        self.graph_replay = GRAPH_REPLAY  # replay the operator from captured HIP graphs (fixed shapes; see GRAPH_REPLAY)
         # [F,3,3] faces of the global batch element 0 when this call renders a shard of a larger batch (SURVEY Q1:
         # the reference samples textures with batch element 0's depths); None = element 0 of this call
         self.faces_z_ref = None
@@ -308,7 +494,18 @@ class Rasterize(object):
                    exact_gradient=bool(self.exact_gradient), faces_z_ref=self.faces_z_ref)
         if not self.return_rgb:
             textures = None
-        rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg)
+        entry = _graph_entry(faces, textures, cfg) if self.graph_replay else None
+        if entry is not None and torch.is_grad_enabled() and (faces.requires_grad or (textures is not None and textures.requires_grad)):
+            # the usual case: every requested output receives a gradient
+            entry.prepare_backward((bool(self.return_rgb), bool(self.return_alpha), bool(self.return_depth),
+                                    bool(self.return_rgb and textures is not None and textures.requires_grad)))
+        if entry is not None:
+            rgb, alpha, depth, fi = _GraphedRasterizeFunction.apply(faces, textures, entry)
+            keep.update(faces=entry.faces, textures=entry.textures, weight_map=entry.weight_map, depth_map=depth if depth is not None else entry.depth_map,
+                        rgb_map=rgb, alpha_map=alpha, batch_size=entry.dims[0], num_faces=entry.dims[1],
+                        texture_size=entry.dims[3] if self.return_rgb else None)
+        else:
+            rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg)
         for k, v in keep.items():
             setattr(self, k, v)
         self.face_index_map = fi
@@ -328,6 +525,7 @@ def rasterize_rgbad(
         return_alpha=True,
         return_depth=True,
         faces_z_ref=None,
+        graph_replay=None,
 ):
     """RGB, alpha and depth images from faces (and textures for RGB) -- reference rasterize.py:900-977.
 
@@ -337,6 +535,8 @@ def rasterize_rgbad(
     size = image_size * 2 if anti_aliasing else image_size  # 2x super-sampling, :945-951
     fn = Rasterize(size, near, far, eps, background_color, return_rgb, return_alpha, return_depth)
     fn.faces_z_ref = faces_z_ref
+    if graph_replay is not None:
+        fn.graph_replay = bool(graph_replay)
     rgb, alpha, depth = fn(*inputs)
     # transpose & vertical flip (:953-960) and 0.5x down-sampling (:962-969): one HIP kernel per direction
     rgb, alpha, depth = _ImageEpilogue.apply(rgb, alpha, depth, bool(anti_aliasing))
@@ -357,11 +557,12 @@ def rasterize(
         eps=DEFAULT_EPS,
         background_color=DEFAULT_BACKGROUND_COLOR,
         faces_z_ref=None,
+        graph_replay=None,
 ):
     """RGB images [B, 3, image_size, image_size] -- reference rasterize.py:980-1008."""
     return rasterize_rgbad(
         faces, textures, image_size, anti_aliasing, near, far, eps, background_color, True, False, False,
-        faces_z_ref=faces_z_ref)['rgb']
+        faces_z_ref=faces_z_ref, graph_replay=graph_replay)['rgb']
 
 
 def rasterize_silhouettes(
@@ -371,9 +572,11 @@ def rasterize_silhouettes(
         near=DEFAULT_NEAR,
         far=DEFAULT_FAR,
         eps=DEFAULT_EPS,
+        graph_replay=None,
 ):
     """Alpha channels [B, image_size, image_size] -- reference rasterize.py:1011-1034."""
-    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, True, False)['alpha']
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, True, False,
+                           graph_replay=graph_replay)['alpha']
 
 
 def rasterize_depth(
@@ -383,9 +586,11 @@ def rasterize_depth(
         near=DEFAULT_NEAR,
         far=DEFAULT_FAR,
         eps=DEFAULT_EPS,
+        graph_replay=None,
 ):
     """Depth images [B, image_size, image_size] -- reference rasterize.py:1037-1060."""
-    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, False, True)['depth']
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, False, True,
+                           graph_replay=graph_replay)['depth']
 
 
 def use_unsafe_rasterizer(flag):

@@ -50,6 +50,9 @@ class Renderer(object):
         self.frontend_calls = {'fused': 0, 'torch': 0}
         # [F,3,3] faces of the global batch element 0 when this renderer draws a shard of a larger batch
         self.faces_z_ref = None
+        # not in the reference: replay the rasterizer from captured HIP graphs (fixed shapes; None = the module default,
+        # neural_renderer_amd.use_graph_replay / NR_GRAPH_REPLAY; see rasterize.py)
+        self.graph_replay = None
 
     def _project(self, vertices, faces):
         """camera + perspective + gather (renderer.py:40-51, :60-71, :92-103)."""
@@ -91,14 +94,14 @@ class Renderer(object):
     def render_silhouettes(self, vertices, faces):
         faces, _ = self._frontend(vertices, faces)
         # NB: near / far / rasterizer_eps are NOT forwarded here (renderer.py:52)
-        return rasterize_silhouettes(faces, self.image_size, self.anti_aliasing)
+        return rasterize_silhouettes(faces, self.image_size, self.anti_aliasing, graph_replay=self.graph_replay)
 
     def render_depth(self, vertices, faces):
         faces, _ = self._frontend(vertices, faces)
-        return rasterize_depth(faces, self.image_size, self.anti_aliasing)  # renderer.py:72 (Q2)
+        return rasterize_depth(faces, self.image_size, self.anti_aliasing, graph_replay=self.graph_replay)  # renderer.py:72 (Q2)
 
     def render(self, vertices, faces, textures):
         faces, textures = self._frontend(vertices, faces, textures)
         return rasterize(
             faces, textures, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
-            self.background_color, faces_z_ref=self.faces_z_ref)
+            self.background_color, faces_z_ref=self.faces_z_ref, graph_replay=self.graph_replay)

@@ -62,10 +62,19 @@ def run(name, faces, textures, S, modes, eps, iters=10, graph=False):
     row = {'config': name, 'B': B, 'F': F, 'S': S, 'ts': 0 if textures is None else textures.shape[2],
            'modes': ''.join(c for c, m in zip('rad', modes) if m), 'coverage': round(cov, 4),
            'ms_fwd_bwd': round(ms, 4), 'ms_fwd': round(ms_f, 4), 'mpixel_s': round(B * S * S / ms / 1e3, 1)}
-    if graph:  # the same step replayed from a captured HIP graph (neural_renderer_amd.graph): host-bound sizes only
+    if graph:  # host-bound sizes only
+        # the same step captured as a whole by the caller (neural_renderer_amd.graph.capture): no copies.  (First: a whole-step
+        # capture AFTER the operator's replay mode has run in the same process crashes on ROCm 7.2 / torch 2.10.)
         replay = nr.graph.capture(step, dev)
         ms_g = timeit(replay, iters)
         row.update(ms_fwd_bwd_hipgraph=round(ms_g, 4), mpixel_s_hipgraph=round(B * S * S / ms_g / 1e3, 1))
+        # the plain API with the operator's graph replay on (nr.use_graph_replay: copies in, replay, copies out)
+        nr.use_graph_replay(True)
+        try:
+            ms_r = timeit(step, iters)
+        finally:
+            nr.use_graph_replay(False)
+        row.update(ms_fwd_bwd_graph_replay=round(ms_r, 4), mpixel_s_graph_replay=round(B * S * S / ms_r / 1e3, 1))
     print(json.dumps(row), flush=True)
 
 
