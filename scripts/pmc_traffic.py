@@ -13,8 +13,8 @@ several stages (k_resolve: nr_forward_face_index_map and the fused nr_forward_ra
 nr_backward_pixel_map and the fused nr_backward_rasterize) is therefore split by dispatch order: its occurrences are
 dealt to the stages that launch it, in call order, in equal shares.  If the occurrence count does not fit that protocol
 the kernel's overall average is used for each of its stages and the record says so (`attribution: "name"`).
-rocclr fills / copies cannot be told apart by name; the library's own fills are added ANALYTICALLY (their sizes are
-known: the forward's z-buffer fill, the fused backward's grad_textures fill) and listed under `fills_analytic`.
+The library's own fills are `nr::k_fill_bytes` launches (z-buffer: both forward stage calls; grad_textures: the fused backward)
+and are attributed like every other kernel.
 """
 import json
 import sqlite3
@@ -30,6 +30,7 @@ KERNEL_STAGES = [
     ('k_face_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
     ('k_large_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
     ('k_resolve', ['forward_face_index_map', 'fused_forward_rasterize']),
+    ('k_fill_bytes', ['forward_face_index_map', 'fused_forward_rasterize', 'fused_backward_rasterize']),
     ('k_shade', ['forward_texture_sampling']),
 ] + [(k, ['backward_pixel_map', 'fused_backward_rasterize']) for k in K6] + [
     ('k_backward_textures_face<true, false>', ['backward_textures']),
@@ -99,11 +100,9 @@ def attribute(rows, scale):
 def analytic_fills(B, F, S, ts):
     P, N = B * S * S, B * F
     zfill = (P + 1) * 8
-    return {
-        'forward_face_index_map': {'z-buffer fill (hipMemsetAsync)': zfill},
-        'fused_forward_rasterize': {'z-buffer fill (hipMemsetAsync)': zfill},
-        'fused_backward_rasterize': {'grad_textures fill (hipMemsetAsync)': N * ts ** 3 * 12},
-    }
+    # (up to round 2 the library filled with hipMemsetAsync, whose rocclr kernels cannot be told apart by name; since round 3
+    # its fills are nr::k_fill_bytes launches with counters of their own: KERNEL_STAGES lists them, nothing is added here)
+    return {}
 
 
 def main():
