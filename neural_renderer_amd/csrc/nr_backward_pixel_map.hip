@@ -257,7 +257,10 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 //          `dist +- eps`), sums in double: the result is the correctly rounded sum of the reference's terms up to double
 //          round-off (<= 2e-6 against the exactly summed oracle).
 //   k_bpm_fast  the north star's tolerance (1e-4) spent where it buys time; see the comment above that kernel.
-constexpr int BAND_THREADS = 512;
+#ifndef NR_BAND_THREADS
+#define NR_BAND_THREADS 512
+#endif
+constexpr int BAND_THREADS = NR_BAND_THREADS;
 constexpr int BAND_WIN = 256;    // line records per pass
 constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
 constexpr int FAST_ACC_SLOTS = 64;  // the same for the scan path of k_bpm_fast (its LDS budget also holds the segment queue)
@@ -2004,7 +2007,10 @@ ListsLayout lists_layout(int B, int F)
     return L;
 }
 
-constexpr size_t LDS_BUDGET = 53 * 1024;  // three workgroups per 160 KB CU, allocation granules of 512 bytes included (3 x 53.5 KB would not fit)
+#ifndef NR_LDS_BUDGET
+#define NR_LDS_BUDGET (53 * 1024)
+#endif
+constexpr size_t LDS_BUDGET = NR_LDS_BUDGET;  // three workgroups per 160 KB CU, allocation granules of 512 bytes included (3 x 53.5 KB would not fit)
 // LDS of k_bpm_band (exact kernel): band width (lines per workgroup) for the given raster size and modes; 0 = does not fit
 // (global fallback)
 int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes, int w_max = 4)
@@ -2155,7 +2161,10 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     int win = BAND_WIN, qcap = 0;
     // Narrower bands when the launch would have few band workgroups (small batches): the chip holds 768 of them at a time and
     // half of a teapot view's bands are empty; 16 views: stage 113 -> 104 us with W = 2, 4 views 70 -> 50, 1 view 66 -> 40 (W = 1).
-    int w_max = 4;
+#ifndef NR_K6_WMAX
+#define NR_K6_WMAX 4
+#endif
+    int w_max = NR_K6_WMAX;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
     const int W = exact ? band_width(S, rgb, alpha, &lds, w_max) : fast_band_config(S, rgb, w_max, &lds, &win, &qcap);
     if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
