@@ -22,9 +22,13 @@
  *   nr_create_texture_image       <- create_texture_image kernels of save_obj(textures=...)   save_obj.py:32-146
  *   nr_frontend_forward/_backward <- fill_back + lighting + look_at/look + perspective + vertices_to_faces
  *                                    of Renderer.render*                                  renderer.py:35-107
+ *   nr_forward_rasterize_lit / nr_backward_rasterize_lit / nr_frontend_forward_light / _backward_light: the fused
+ *                                   rasterizer and front-end with per-face light colours instead of lit, duplicated
+ *                                   textures (renderer.py:77-103 with lighting.py:50-51 moved into K4 / K7)
  *
  * Conventions
- *   - plain device pointers (hipMalloc / torch caching allocator memory), C-contiguous, float32 / int32;
+ *   - plain device pointers (hipMalloc / torch caching allocator memory), C-contiguous, float32 / int32, every buffer
+ *     16-byte aligned (hipMalloc gives 256, torch 512: the kernels move maps, textures and workspaces as 16-byte words);
  *     sizes are int32; near / far / eps are doubles because the reference pastes their Python repr into
  *     the kernel source as double literals (rasterize.py:226-234, 428-433, 737-743).
  *   - the library owns no memory and keeps no state between calls (it reads no environment variable; the one thing it
@@ -204,6 +208,42 @@ int nr_backward_rasterize(const float *faces, const float *faces_z_ref, const in
                           const uint8_t *visible_faces, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Per-face light colours instead of lit, duplicated textures.  Renderer.render (reference renderer.py:77-103)
+ * hands the rasterizer textures that fill_back duplicated (:79, the copy with its first and third cube axis exchanged) and
+ * lighting multiplied by one colour per face (lighting.py:50-51): 2 x B x Nf x ts^3 x 3 floats that are written, read back
+ * by the few faces that own a pixel, and whose equally large gradient travels the other way.  The _lit entry points take
+ * the ORIGINAL cubes plus the per-face colours and do both inside the shading:
+ *     rgb(pixel of face f) = light[b, f, :] * sum_taps w * cube(f)[tap]          cube(f) = textures[b, f] for f < Nf,
+ *                                                                               textures[b, f - Nf] transposed for f >= Nf
+ * which is the reference's value up to the rounding order of the light product (the reference rounds light * texel per
+ * texel and sums, this rounds the sum and multiplies: 1 ulp class, <= 2e-7 relative; tests/test_face_light_gpu.py).
+ * Every other output is bit-identical (the geometry does not depend on textures).
+ *   light [B, F, 3]; texture_faces = Nf with F == Nf or F == 2 * Nf; textures / grad_textures [B, Nf, ts,ts,ts, 3].
+ *   backward: grad_textures is the gradient w.r.t. the ORIGINAL cubes (light factor included); grad_light [B, F, 3]
+ *   (optional) the gradient of the colours, for nr_frontend_backward_light.  Needs texture_size <= 13 (NR_E_SIZE above:
+ *   callers keep the lit-texture path for huge cubes).  lit == NULL: exactly nr_forward_rasterize / nr_backward_rasterize.
+ */
+typedef struct nr_face_light {
+    const float *light;     /* DEVICE [B, F, 3] */
+    int32_t texture_faces;  /* Nf */
+    const float *textures;  /* backward: the cubes again (DEVICE), needed when grad_light is given */
+    float *grad_light;      /* backward: DEVICE [B, F, 3] or NULL; every element stored */
+} nr_face_light;
+
+int nr_forward_rasterize_lit(const nr_face_light *lit, const float *faces, const float *faces_z_ref, const float *textures,
+                             int32_t *face_index_map, float *weight_map, float *depth_map, float *rgb_map, float *alpha_map,
+                             uint8_t *visible_faces, const float *background, int32_t bg_per_batch, int32_t batch_size,
+                             int32_t num_faces, int32_t image_size, int32_t texture_size, double near, double far,
+                             double eps, int32_t flags, void *workspace, size_t workspace_bytes, void *stream);
+int nr_backward_rasterize_lit(const nr_face_light *lit, const float *faces, const float *faces_z_ref,
+                              const int32_t *face_index_map, const float *weight_map, const float *depth_map,
+                              const float *rgb_map, const float *alpha_map, const float *grad_rgb_map,
+                              const float *grad_alpha_map, const float *grad_depth_map, float *grad_faces,
+                              float *grad_textures, int32_t batch_size, int32_t num_faces, int32_t image_size,
+                              int32_t texture_size, double eps, int32_t flags, const uint8_t *visible_faces,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * vertices_to_faces (reference neural_renderer/vertices_to_faces.py:4-21): faces_out[b,f,k,:] = vertices[b, faces_idx[.,f,k], :]
  * and its backward (Chainer's get_item backward = scatter-add): grad_vertices[b, faces_idx[.,f,k], :] += grad_faces[b,f,k,:]
  * with hardware float atomics; grad_vertices [B,Nv,3] is zero-filled by the call.  faces_idx is [B,Nf,3] int32 when
@@ -280,6 +320,22 @@ int nr_frontend_backward(const float *vertices, const int32_t *faces_idx, const 
                          int32_t num_faces, int32_t texture_size, int32_t idx_per_batch, int32_t eye_per_batch,
                          int32_t fill_back, const nr_camera *camera, const nr_light *light, void *workspace,
                          size_t workspace_bytes, void *stream);
+
+/*
+ * The same front-end for the _lit rasterizer entry points: no textures in or out.  light_out [B,F,3] receives the colour of
+ * every face (lighting.py:28-47) and of its reversed copy; nr_frontend_backward_light takes the gradient of those colours
+ * (grad_light [B,F,3], e.g. from nr_backward_rasterize_lit; NULL = none) in place of grad_textures_out.  The gradient of the
+ * textures does not pass through here (nr_backward_rasterize_lit stores it).
+ */
+int nr_frontend_forward_light(const float *vertices, const int32_t *faces_idx, const float *eye, float *faces_out,
+                              float *light_out, int32_t batch_size, int32_t num_vertices, int32_t num_faces,
+                              int32_t idx_per_batch, int32_t eye_per_batch, int32_t fill_back, const nr_camera *camera,
+                              const nr_light *light, void *stream);
+int nr_frontend_backward_light(const float *vertices, const int32_t *faces_idx, const float *eye, const float *grad_faces,
+                               const float *grad_light, float *grad_vertices, float *grad_eye, int32_t batch_size,
+                               int32_t num_vertices, int32_t num_faces, int32_t idx_per_batch, int32_t eye_per_batch,
+                               int32_t fill_back, const nr_camera *camera, const nr_light *light, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /*
  * Texture baking of load_obj(load_texture=True) (K10, reference load_obj.py:87-144): for every texel (i0,i1,i2) of every

@@ -22,7 +22,12 @@ class Light(_c.Structure):
                 ('color_ambient', _c.c_float * 3), ('color_directional', _c.c_float * 3), ('direction', _c.c_float * 3)]
 
 
-_cam_p, _light_p = _c.POINTER(Camera), _c.POINTER(Light)
+class FaceLight(_c.Structure):
+    """struct nr_face_light (include/nr_hip.h): per-face light colours for the _lit entry points."""
+    _fields_ = [('light', _vp), ('texture_faces', _i32), ('textures', _vp), ('grad_light', _vp)]
+
+
+_cam_p, _light_p, _fl_p = _c.POINTER(Camera), _c.POINTER(Light), _c.POINTER(FaceLight)
 
 # name -> (restype, argtypes); mirrors include/nr_hip.h one to one
 SIGNATURES = {
@@ -47,6 +52,10 @@ SIGNATURES = {
     'nr_frontend_workspace_bytes': (_sz, [_i32]),
     'nr_frontend_forward': (_c.c_int, [_vp] * 6 + [_i32] * 7 + [_cam_p, _light_p, _vp]),
     'nr_frontend_backward': (_c.c_int, [_vp] * 9 + [_i32] * 7 + [_cam_p, _light_p, _vp, _sz, _vp]),
+    'nr_forward_rasterize_lit': (_c.c_int, [_fl_p] + [_vp] * 10 + [_i32] * 5 + [_f64] * 3 + [_i32, _vp, _sz, _vp]),
+    'nr_backward_rasterize_lit': (_c.c_int, [_fl_p] + [_vp] * 12 + [_i32] * 4 + [_f64, _i32, _vp, _vp, _sz, _vp]),
+    'nr_frontend_forward_light': (_c.c_int, [_vp] * 5 + [_i32] * 6 + [_cam_p, _light_p, _vp]),
+    'nr_frontend_backward_light': (_c.c_int, [_vp] * 7 + [_i32] * 6 + [_cam_p, _light_p, _vp, _sz, _vp]),
 }
 
 NR_FLAG_FIX_TEXTURE_BATCH_Z = 1

@@ -131,10 +131,12 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     const float *__restrict__ g_rgb, float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts,
     double eps, int fix_batch_z, int L,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces, const double *__restrict__ k6_scratch, const int *__restrict__ slot_of)
+    float *__restrict__ grad_faces, const double *__restrict__ k6_scratch, const int *__restrict__ slot_of, FaceLight lit)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
     __shared__ int s_queue[512];  // owned pixels waiting for their evaluation (walk_owned_pixels)
+    __shared__ int s_own;         // lit, L == 256: does the workgroup's face own a pixel?
+    __shared__ float s_gl[3];     // lit, L == 256: the face's light-colour gradient
 
     const int tid = threadIdx.x;
     const int grp = tid / L, sub = tid - grp * L;
@@ -166,8 +168,11 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 #pragma unroll
     for (int k = 0; k < 9; k++) dacc[k] = 0.0f;
     bool any_box = false;
+    bool own = false;  // this lane evaluated a pixel of the face (lit: only such faces store, see FaceLight)
     if (!TS2) {
         for (int k = sub; k < n_tex; k += L) acc_l[k] = 0.0;
+        if (tid < 3) s_gl[tid] = 0.0f;
+        if (tid == 0) s_own = 0;
         __syncthreads();
     }
 
@@ -179,6 +184,15 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 #pragma unroll
     for (int k = 0; k < 3; k++) dc.tmp[k] = dc.zz[k] = 0.0f;
     float face_z[3] = {1.0f, 1.0f, 1.0f};
+    // lit: the face's original cube.  Its reversed copy shares it and samples it with axes 0 and 2 exchanged: the walk below
+    // flattens that copy's taps in the ORIGINAL layout (compute_taps' flip), so the sums need no transposition afterwards.
+    bool flip = false;
+    size_t cube = 0;  // b * Nf + original face
+    if (lit.light) {
+        const int b = vis_list ? (int)blockIdx.y : gi / F, f = gi - b * F;
+        flip = f >= lit.tex_faces;
+        cube = (size_t)b * lit.tex_faces + (flip ? f - lit.tex_faces : f);
+    }
     if (face_ok) {
         const int b = gi / F;
         fn = gi - b * F;
@@ -205,6 +219,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         if (depth_map) depth = depth_map[p];
         if (DEPTH) gd = g_depth[p];
         const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
+        own = true;
         Taps t;
         if (sampling_weight_map) {
 #pragma unroll
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                 t.isc[pn] = sampling_index_map[8 * p + pn];
             }
         } else {
-            compute_taps(face_z, wk, depth, ts, eps, t);
+            compute_taps(face_z, wk, depth, ts, eps, t, flip);
         }
         if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
             const float depth2 = depth * depth;
@@ -240,11 +255,60 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         }
     });
 
+    // lit: does the face own a pixel at all?  (only then it stores: FaceLight)
+    bool owned = false;
+    if (lit.light) {
+        if (L <= 64) {
+            const unsigned long long bm = __ballot(own);
+            owned = L == 64 ? bm != 0ull : ((bm >> (tid & 48)) & 0xffffull) != 0ull;
+        } else {
+            if (own) s_own = 1;
+            __syncthreads();
+            owned = s_own != 0;
+        }
+    }
     if (TS2) {
         // L == 16 here: reduce inside the 16-lane row, its last lane stores the face's 24 floats (96 B)
 #pragma unroll
         for (int k = 0; k < 24; k++) acc[k] = row16_sum_last(acc[k]);
-        if (face_ok && sub == 15) {
+        if (lit.light) {
+            if (face_ok && sub == 15 && owned) {
+                // corner pn holds texel bitrev3(pn) of the sampled cube (the static taps above); the reversed copy samples the
+                // transposed cube, whose texel bitrev3(pn) is texel pn of the original one
+                const float *lc = lit.light + (size_t)gi * 3;
+                const float l3[3] = {lc[0], lc[1], lc[2]};
+                float tx[24];
+                if (lit.textures) {  // 96 B per cube, 16 B aligned (nr_hip.h)
+                    const float4 *src = reinterpret_cast<const float4 *>(lit.textures + cube * 24);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const float4 v = src[k];
+                        tx[4 * k] = v.x; tx[4 * k + 1] = v.y; tx[4 * k + 2] = v.z; tx[4 * k + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 24; k++) tx[k] = 0.0f;
+                }
+                float o[24], gl[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int r = (u & 1) * 4 + (u & 2) + (u >> 2);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float a = flip ? acc[3 * u + c] : acc[3 * r + c];
+                        o[3 * u + c] = a * l3[c];
+                        gl[c] += a * tx[3 * u + c];
+                    }
+                }
+                float4 *dst = reinterpret_cast<float4 *>(grad_textures + cube * 24);
+#pragma unroll
+                for (int k = 0; k < 6; k++) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+                if (lit.grad_light) {
+                    float *gd = lit.grad_light + (size_t)gi * 3;
+                    gd[0] = gl[0]; gd[1] = gl[1]; gd[2] = gl[2];
+                }
+            }
+        } else if (face_ok && sub == 15) {
             float o[24];
 #pragma unroll
             for (int pn = 0; pn < 8; pn++) {
@@ -256,6 +320,45 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
             float4 *dst = reinterpret_cast<float4 *>(grad_textures + (size_t)gi * 24);
 #pragma unroll
             for (int k = 0; k < 6; k++) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        }
+    } else if (lit.light) {
+        __syncthreads();
+        float gl0 = 0.0f, gl1 = 0.0f, gl2 = 0.0f;
+        if (face_ok && owned) {
+            const float *lc = lit.light + (size_t)gi * 3;
+            const float l3[3] = {lc[0], lc[1], lc[2]};
+            const float *tex = lit.textures ? lit.textures + cube * n_tex : nullptr;
+            float *dst = grad_textures + cube * n_tex;
+            // (the loads of the cube in a loop of their own: interleaved with the stores, which the compiler must assume to
+            // alias them, every one of them would be a separate round trip)
+            if (tex) {
+                for (int k = sub; k < n_tex; k += L) {
+                    const int c = k % 3;
+                    const float v = (float)acc_l[k] * tex[k];
+                    gl0 += c == 0 ? v : 0.0f;
+                    gl1 += c == 1 ? v : 0.0f;
+                    gl2 += c == 2 ? v : 0.0f;
+                }
+            }
+            for (int k = sub; k < n_tex; k += L) {
+                const int c = k % 3;
+                dst[k] = (float)acc_l[k] * (c == 0 ? l3[0] : (c == 1 ? l3[1] : l3[2]));
+            }
+        }
+        if (lit.grad_light) {
+            if (L <= 64) {
+                gl0 = group_sum(gl0, L); gl1 = group_sum(gl1, L); gl2 = group_sum(gl2, L);
+            } else {
+                if (gl0 != 0.0f) atomicAdd(&s_gl[0], gl0);
+                if (gl1 != 0.0f) atomicAdd(&s_gl[1], gl1);
+                if (gl2 != 0.0f) atomicAdd(&s_gl[2], gl2);
+                __syncthreads();
+                gl0 = s_gl[0]; gl1 = s_gl[1]; gl2 = s_gl[2];
+            }
+            if (face_ok && owned && sub == 0) {
+                float *gd = lit.grad_light + (size_t)gi * 3;
+                gd[0] = gl0; gd[1] = gl1; gd[2] = gl2;
+            }
         }
     } else {
         __syncthreads();
@@ -305,12 +408,13 @@ __global__ __launch_bounds__(256) void k_backward_big(
     const float *__restrict__ zbase, const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
     float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces, const unsigned char *__restrict__ visible)
+    float *__restrict__ grad_faces, const unsigned char *__restrict__ visible, FaceLight lit)
 {
     extern __shared__ __attribute__((aligned(16))) double s_tex[];  // [ts^3 * 3] texel sums of the face being walked
     __shared__ int s_list[256];
     __shared__ int s_wave_n[4];
-    __shared__ float s_red[33];  // 9 depth sums + 24 texel sums (TEX == 2)
+    __shared__ float s_red[36];  // 9 depth sums + 24 texel sums (TEX == 2) + 3 light-colour sums (lit)
+    __shared__ int s_own;        // lit: the face being walked owns a pixel
     const int tid = threadIdx.x;
     if (vis_list && (int)blockIdx.x * 256 >= vis_count[blockIdx.y]) return;  // slots behind the image's list
     int n_big;
@@ -354,9 +458,12 @@ __global__ __launch_bounds__(256) void k_backward_big(
         if (DEPTH) dc = depth_constants(f, S);
         const float *fz = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fn * 9;  // :389, Q1
         const float face_z[3] = {fz[2], fz[5], fz[8]};
+        const bool flip = TEX && lit.light && fn >= lit.tex_faces;  // the reversed copy: taps in the original cube's layout
         for (int k = tid; k < n_lds; k += 256) s_tex[k] = 0.0;
-        if (tid < 33) s_red[tid] = 0.0f;
+        if (tid < 36) s_red[tid] = 0.0f;
+        if (tid == 0) s_own = 0;
         __syncthreads();
+        bool own = false;
         float dacc[9], tacc[24];
 #pragma unroll
         for (int k = 0; k < 9; k++) dacc[k] = 0.0f;
@@ -368,6 +475,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
             if (!cand_pixel(cd, i, S, x, y)) continue;
             const size_t p = img + (size_t)y * S + x;
             if (face_index_map[p] != fn) continue;
+            own = true;
             float wk[3] = {0.0f, 0.0f, 0.0f}, depth = 0.0f;
             if (weight_map) { wk[0] = weight_map[3 * p]; wk[1] = weight_map[3 * p + 1]; wk[2] = weight_map[3 * p + 2]; }
             if (depth_map) depth = depth_map[p];
@@ -380,7 +488,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
                         t.isc[pn] = sampling_index_map[8 * p + pn];
                     }
                 } else {
-                    compute_taps(face_z, wk, depth, ts, eps, t);
+                    compute_taps(face_z, wk, depth, ts, eps, t, flip);
                 }
                 const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
 #pragma unroll
@@ -431,7 +539,33 @@ __global__ __launch_bounds__(256) void k_backward_big(
                 if ((tid & 63) == 0 && v != 0.0f) atomicAdd(&s_red[9 + k], v);
             }
         }
+        if (TEX && lit.light && own) s_own = 1;
         __syncthreads();
+        if (TEX && lit.light) {  // the original cube, times the face's light colour; only a face that owns a pixel stores
+            if (s_own) {
+                const size_t cube = (size_t)b * lit.tex_faces + (flip ? fn - lit.tex_faces : fn);
+                const float *lc = lit.light + (size_t)gi * 3;
+                const float *tex = lit.textures ? lit.textures + cube * n_tex : nullptr;
+                float *dst = grad_textures + cube * n_tex;
+                for (int k = tid; k < n_tex; k += 256) {
+                    const int q = k / 3, c = k - 3 * q;
+                    int u = k;
+                    float a;
+                    if (TEX == 2) {  // k = 3 * corner + c, the corner's texel as in the TS2 gather
+                        u = 3 * (flip ? q : (q & 1) * 4 + (q & 2) + (q >> 2)) + c;
+                        a = s_red[9 + k];
+                    } else {
+                        a = (float)s_tex[k];
+                    }
+                    dst[u] = a * lc[c];
+                    if (tex && a != 0.0f) atomicAdd(&s_red[33 + c], a * tex[u]);
+                }
+                if (lit.grad_light) {
+                    __syncthreads();
+                    if (tid < 3) lit.grad_light[(size_t)gi * 3 + tid] = s_red[33 + tid];
+                }
+            }
+        } else {
         if (TEX == 1) {
             float *dst = grad_textures + (size_t)gi * n_tex;
             for (int k = tid; k < n_tex; k += 256) dst[k] = (float)s_tex[k];
@@ -440,6 +574,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
             const int pn = tid / 3, c = tid - 3 * pn;
             const int isc = (pn & 1) * 4 + ((pn >> 1) & 1) * 2 + ((pn >> 2) & 1);
             grad_textures[(size_t)gi * 24 + 3 * isc + c] = s_red[9 + tid];
+        }
         }
         if (DEPTH && tid < 9) grad_faces[(size_t)gi * 9 + tid] += s_red[tid];
         __syncthreads();
@@ -592,7 +727,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
                               const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F,
                               int S, int ts, double eps, int flags, const int *vis_list, const int *vis_count,
                               hipStream_t st, const float *g_depth, float *grad_faces, int *depth_done,
-                              const double *k6_scratch, const int *slot_of, int *k6_finalized)
+                              const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit)
 {
     if (depth_done) *depth_done = 0;
     if (k6_finalized) *k6_finalized = 0;
@@ -601,6 +736,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     if (!sampling_weight_map && (!weight_map || !depth_map)) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
     if (ts < 2 || ts > 1024) return NR_E_SIZE;
+    if (lit.light && (ts > 13 || sampling_weight_map)) return NR_E_SIZE;  // the per-face gathers only
     const int fix = (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0;
     const float *zbase = faces_z_ref ? faces_z_ref : faces;  // :389 reads batch 0 of the GLOBAL batch (see nr_hip.h)
     const int n = B * F;
@@ -616,7 +752,12 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     const bool fold = vis_list && k6_scratch && slot_of && grad_faces && ts <= 13;
     if (!fold) k6_scratch = nullptr, slot_of = nullptr;
     if (fold && k6_finalized) *k6_finalized = 1;
-    if (vis_list) {
+    if (lit.light) {
+        // original cubes: a face and its reversed copy share one, so only the one that owns a pixel stores; the rest is zero
+        int e = fill_bytes(grad_textures, 0, (size_t)B * lit.tex_faces * n_tex * sizeof(float), st);
+        if (e == 0 && lit.grad_light) e = fill_bytes(lit.grad_light, 0, (size_t)n * 3 * sizeof(float), st);
+        if (e != 0) return e;
+    } else if (vis_list) {
         // only visible faces are visited: everything else is zero
         const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != 0) return e;
@@ -627,12 +768,12 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
             hipLaunchKernelGGL((k_backward_textures_face<true, true>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
-                               slot_of);
+                               slot_of, lit);
         else
             hipLaunchKernelGGL((k_backward_textures_face<true, false>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, (const float *)nullptr,
-                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of);
+                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of, lit);
     } else if (ts <= 13) {
         const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
         const int per = 256 / L;
@@ -642,12 +783,12 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
             hipLaunchKernelGGL((k_backward_textures_face<false, true>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
-                               slot_of);
+                               slot_of, lit);
         else
             hipLaunchKernelGGL((k_backward_textures_face<false, false>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, (const float *)nullptr,
-                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of);
+                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of, lit);
     }
     if (ts <= 8) {
         // faces the gathers above left out (more than BIG_PX candidates): a workgroup each
@@ -658,7 +799,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     hipLaunchKernelGGL((k_backward_big<T, D>), grid, dim3(256), lds, st, face_index_map, sampling_weight_map,          \
                        sampling_index_map, (const float *)nullptr, faces, zbase, weight_map, depth_map, grad_rgb_map, \
                        grad_textures, n, F, S, ts, eps, fix, vis_list, vis_count, D ? g_depth : (const float *)nullptr, \
-                       D ? grad_faces : (float *)nullptr, (const unsigned char *)nullptr)
+                       D ? grad_faces : (float *)nullptr, (const unsigned char *)nullptr, lit)
         if (st2) { if (g_depth) NR_BIG(2, true); else NR_BIG(2, false); }
         else { if (g_depth) NR_BIG(1, true); else NR_BIG(1, false); }
 #undef NR_BIG
@@ -689,7 +830,7 @@ int nr::run_backward_depth_map(const float *faces, const float *depth_map, const
     const dim3 grid_big = big_grid(vis_list != nullptr, B, F);
     hipLaunchKernelGGL((k_backward_big<0, true>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
                        (const int32_t *)nullptr, face_inv_map, faces, faces, weight_map, depth_map, (const float *)nullptr,
-                       (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces, visible);
+                       (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces, visible, FaceLight());
     return launch_status();
 }
 

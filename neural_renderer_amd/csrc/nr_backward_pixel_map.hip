@@ -2301,8 +2301,24 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
                                  int32_t F, int32_t S, int32_t ts, double eps, int32_t flags,
                                  const uint8_t *visible_faces, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return nr_backward_rasterize_lit(nullptr, faces, faces_z_ref, face_index_map, weight_map, depth_map, rgb_map, alpha_map,
+                                     grad_rgb_map, grad_alpha_map, grad_depth_map, grad_faces, grad_textures, B, F, S, ts,
+                                     eps, flags, visible_faces, workspace, workspace_bytes, stream);
+}
+
+NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *faces, const float *faces_z_ref,
+                                     const int32_t *face_index_map, const float *weight_map, const float *depth_map,
+                                     const float *rgb_map, const float *alpha_map, const float *grad_rgb_map,
+                                     const float *grad_alpha_map, const float *grad_depth_map, float *grad_faces,
+                                     float *grad_textures, int32_t B, int32_t F, int32_t S, int32_t ts, double eps,
+                                     int32_t flags, const uint8_t *visible_faces, void *workspace, size_t workspace_bytes,
+                                     void *stream)
+{
     if (!faces || !face_index_map || !grad_faces) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
+    FaceLight fl;  // per-face light colours: only the texture gather sees them (the geometry gradients do not)
+    if (int e = face_light_args(grad_rgb_map && grad_textures ? lit : nullptr, F, true, fl)) return e;
+    if (fl.light && ts > 13) return NR_E_SIZE;
     hipStream_t st = (hipStream_t)stream;
     const bool use_rgb = grad_rgb_map != nullptr, use_alpha = grad_alpha_map != nullptr, use_depth = grad_depth_map != nullptr;
     const int *vis_list = nullptr, *vis_count = nullptr;
@@ -2341,7 +2357,7 @@ NR_API int nr_backward_rasterize(const float *faces, const float *faces_z_ref, c
         if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, faces_z_ref, weight_map, depth_map,
                                            grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
                                            use_depth ? grad_depth_map : nullptr, grad_faces, &depth_done, k6_scratch,
-                                           k6_slot_of, &finalized))
+                                           k6_slot_of, &finalized, fl))
             return rc;
         if (k6_scratch && !finalized) run_bpm_finalize(k6_scratch, k6_slot_of, grad_faces, B, F, st);  // (not expected)
     }

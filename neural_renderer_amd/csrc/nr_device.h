@@ -156,6 +156,25 @@ __device__ __forceinline__ bool cand_pixel(const Cand &c, int i, int S, int &x, 
 }
 
 // --------------------------------------------------------------------------------------------------
+// Per-face light colours (nr_face_light in include/nr_hip.h): instead of textures that were multiplied by the
+// light colour of their face and duplicated for the fill_back copy in front of the rasterizer (lighting.py:50-51,
+// renderer.py:79: 2 x B x Nf x ts^3 x 3 floats written, read, and the same again for the gradient), the kernels read the
+// ORIGINAL cubes [B, tex_faces, ts^3, 3] and multiply the sampled colour by light[b, f, :].  Face f >= tex_faces is the
+// reversed copy of face f - tex_faces and reads its cube with the first and the third axis exchanged.
+struct FaceLight {
+    const float *light = nullptr;     // [B, F, 3]; NULL = off: textures are [B, F, ts^3, 3], sampled as they are
+    int tex_faces = 0;                // Nf (F == Nf or F == 2 * Nf)
+    const float *textures = nullptr;  // backward only: the cubes, for the gradient of `light`
+    float *grad_light = nullptr;      // backward only: [B, F, 3] or NULL
+};
+
+// texel (i, j, k) -> (k, j, i) of a ts^3 cube, flattened (renderer.py:79)
+__device__ __forceinline__ int transpose_texel(int t, int ts)
+{
+    const int k = t % ts, j = (t / ts) % ts, i = t / (ts * ts);
+    return (k * ts + j) * ts + i;
+}
+
 // texture taps shared by F3 (forward) and B2 (backward recompute): rasterize.py:398-425
 struct Taps {
     int isc[8];
@@ -166,9 +185,10 @@ struct Taps {
 // survive the float32 rounding of :402, or eps = 0) the "upper" corner of that dimension has index ts and weight exactly 0;
 // its flattened index can then leave the face's cube (isc >= ts^3).  The reference multiplies whatever lies there by 0 /
 // adds 0 to it; consumers here skip such taps instead of touching memory outside the cube.
-// z: the face's three vertex depths
+// z: the face's three vertex depths; flip: flatten the taps of the cube with axes 0 and 2 exchanged (FaceLight: the
+// reversed copy of a face reads the original cube transposed)
 __device__ __forceinline__ void compute_taps(const float *__restrict__ z, const float *__restrict__ weight,
-                                             float depth, int ts, double eps, Taps &t)
+                                             float depth, int ts, double eps, Taps &t, bool flip = false)
 {
     float tif[3];
     int ti[3];
@@ -196,7 +216,7 @@ __device__ __forceinline__ void compute_taps(const float *__restrict__ z, const 
                 idx[k] = ti[k] + 1;
             }
         }
-        t.isc[pn] = idx[0] * ts * ts + idx[1] * ts + idx[2];
+        t.isc[pn] = (flip ? idx[2] : idx[0]) * ts * ts + idx[1] * ts + (flip ? idx[0] : idx[2]);
         t.w[pn] = w;
     }
 }
@@ -281,7 +301,10 @@ int run_backward_textures(const int32_t *face_index_map, const float *sampling_w
                           const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F, int S,
                           int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st,
                           const float *g_depth_fused, float *grad_faces_fused, int *depth_done,
-                          const double *k6_scratch, const int *slot_of, int *k6_finalized);
+                          const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit = FaceLight());
+// lit.light given: grad_textures is [B, lit.tex_faces, ts^3, 3] (zero-filled here; a face stores only when it owns a
+// pixel -- of a face and its reversed copy at most one does), lit.grad_light receives [B, F, 3]
+int face_light_args(const nr_face_light *lit, int F, bool backward, FaceLight &out);  // nr_forward.hip
 int run_backward_depth_map(const float *faces, const float *depth_map, const int32_t *face_index_map,
                            const float *face_inv_map, const float *weight_map, const float *grad_depth_map,
                            float *grad_faces, int B, int F, int S, const int *vis_list, const int *vis_count,

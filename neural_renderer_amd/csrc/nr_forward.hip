@@ -479,7 +479,8 @@ __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, f
                                             int32_t *__restrict__ sampling_index_map,
                                             float *__restrict__ sampling_weight_map,
                                             const float *__restrict__ background, int bg_per_batch,
-                                            float *__restrict__ alpha_map, int F, int ts, double eps, int fix_batch_z)
+                                            float *__restrict__ alpha_map, int F, int ts, double eps, int fix_batch_z,
+                                            const FaceLight &lit)
 {
     if (alpha_map) alpha_map[i] = (fi >= 0) ? 1.0f : 0.0f;  // :449
     if (!rgb_map) return;
@@ -489,9 +490,14 @@ __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, f
         // :389 (Q1): the reference reads batch element 0's geometry here; zbase = that element's faces (of the GLOBAL batch)
         const float *face = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fi * 9;
         const float *texture = textures + ((size_t)b * F + fi) * ts * ts * ts * 3;   // :390
+        bool flip = false;
+        if (lit.light) {  // the cube of the original face; its reversed copy reads it transposed (nr_device.h: FaceLight)
+            flip = fi >= lit.tex_faces;
+            texture = textures + ((size_t)b * lit.tex_faces + (flip ? fi - lit.tex_faces : fi)) * ts * ts * ts * 3;
+        }
         const float w[3] = {w0, w1, w2};
         const float fz[3] = {face[2], face[5], face[8]};
-        compute_taps(fz, w, depth, ts, eps, t);
+        compute_taps(fz, w, depth, ts, eps, t, flip);
         rgb[0] = rgb[1] = rgb[2] = 0.0f;
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {
@@ -500,6 +506,12 @@ __device__ __forceinline__ void shade_pixel(size_t i, int b, int fi, float w0, f
             rgb[0] += t.w[pn] * tx[0];
             rgb[1] += t.w[pn] * tx[1];
             rgb[2] += t.w[pn] * tx[2];
+        }
+        if (lit.light) {  // lighting.py:50-51 applied to the sample instead of to every texel
+            const float *lc = lit.light + ((size_t)b * F + fi) * 3;
+            rgb[0] *= lc[0];
+            rgb[1] *= lc[1];
+            rgb[2] *= lc[2];
         }
         // :463 with mask = 1: rgb * 1 + 0 * bg (kept literal: it maps -0 to +0 and NaN backgrounds to NaN)
         const float *bg = background + (bg_per_batch ? 3 * b : 0);
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, 
                                                float *__restrict__ sampling_weight_map,
                                                const float *__restrict__ background, int bg_per_batch,
                                                float *__restrict__ alpha_map, int F, int S, int ts, double eps,
-                                               int fix_batch_z, size_t n_pixels)
+                                               int fix_batch_z, size_t n_pixels, FaceLight lit)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, 
     float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, depth = 0.0f;
     if (rgb_map && fi >= 0) { w0 = weight_map[3 * i]; w1 = weight_map[3 * i + 1]; w2 = weight_map[3 * i + 2]; depth = depth_map[i]; }
     shade_pixel(i, b, fi, w0, w1, w2, depth, faces, zbase, textures, rgb_map, sampling_index_map, sampling_weight_map,
-                background, bg_per_batch, alpha_map, F, ts, eps, fix_batch_z);
+                background, bg_per_batch, alpha_map, F, ts, eps, fix_batch_z, lit);
 }
 
 __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces,
@@ -559,7 +571,8 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
                                                  const float *__restrict__ zbase, const float *__restrict__ textures,
                                                  float *__restrict__ rgb_map, const float *__restrict__ background,
                                                  int bg_per_batch, float *__restrict__ alpha_map, int ts, double eps,
-                                                 int fix_batch_z, int epoch, int *__restrict__ queue_counters)
+                                                 int fix_batch_z, int epoch, int *__restrict__ queue_counters,
+                                                 FaceLight lit)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // epoch mode: nobody fills the workspace for the next call, so the two queue counters go back to -1 here (the raster
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
     }
     if (rgb_map || alpha_map)
         shade_pixel(i, b, fn, w0, w1, w2, zp, faces, zbase, textures, rgb_map, nullptr, nullptr, background, bg_per_batch,
-                    alpha_map, F, ts, eps, fix_batch_z);
+                    alpha_map, F, ts, eps, fix_batch_z, lit);
 }
 
 }  // namespace
@@ -647,7 +660,7 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
                 unsigned char *visible_faces, int B, int F, int S, double near, double far, void *workspace,
                 size_t workspace_bytes, hipStream_t st, const float *faces_z_ref, const float *textures, float *rgb_map,
                 const float *background, int bg_per_batch, float *alpha_map, int ts, double eps, int fix_batch_z,
-                int flags = 0)
+                int flags = 0, const FaceLight &lit = FaceLight())
 {
     if (!faces || !face_index_map) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
@@ -685,7 +698,7 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, zbuf, face_index_map,
                        weight_map, depth_map, face_inv_map, visible_faces, F, S, near, far, P,
                        faces_z_ref ? faces_z_ref : faces, textures, rgb_map, background, bg_per_batch, alpha_map, ts, eps,
-                       fix_batch_z, epoch, n_large);
+                       fix_batch_z, epoch, n_large, lit);
     return launch_status();
 }
 }  // namespace
@@ -707,13 +720,44 @@ NR_API int nr_forward_rasterize(const float *faces, const float *faces_z_ref, co
                                 int32_t B, int32_t F, int32_t S, int32_t ts, double near, double far, double eps,
                                 int32_t flags, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return nr_forward_rasterize_lit(nullptr, faces, faces_z_ref, textures, face_index_map, weight_map, depth_map, rgb_map,
+                                    alpha_map, visible_faces, background, bg_per_batch, B, F, S, ts, near, far, eps, flags,
+                                    workspace, workspace_bytes, stream);
+}
+
+// host-side check of an nr_face_light (see include/nr_hip.h) -> the kernels' FaceLight
+int nr::face_light_args(const nr_face_light *lit, int F, bool backward, FaceLight &out)
+{
+    out = FaceLight();
+    if (!lit) return 0;
+    if (!lit->light) return NR_E_NULL;
+    if (lit->texture_faces < 1 || (lit->texture_faces != F && 2 * (int64_t)lit->texture_faces != F)) return NR_E_SIZE;
+    out.light = lit->light;
+    out.tex_faces = lit->texture_faces;
+    if (backward) {
+        out.textures = lit->textures;
+        out.grad_light = lit->grad_light;
+        if (out.grad_light && !out.textures) return NR_E_NULL;
+    }
+    return 0;
+}
+
+NR_API int nr_forward_rasterize_lit(const nr_face_light *lit, const float *faces, const float *faces_z_ref,
+                                    const float *textures, int32_t *face_index_map, float *weight_map, float *depth_map,
+                                    float *rgb_map, float *alpha_map, uint8_t *visible_faces, const float *background,
+                                    int32_t bg_per_batch, int32_t B, int32_t F, int32_t S, int32_t ts, double near,
+                                    double far, double eps, int32_t flags, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
     if (rgb_map) {
         if (!textures || !background) return NR_E_NULL;
         if (ts < 2 || ts > 1024) return NR_E_SIZE;
     }
+    FaceLight fl;
+    if (int e = face_light_args(rgb_map ? lit : nullptr, F, false, fl)) return e;
     return run_forward(faces, face_index_map, weight_map, depth_map, nullptr, visible_faces, B, F, S, near, far,
                        workspace, workspace_bytes, (hipStream_t)stream, faces_z_ref, textures, rgb_map, background,
-                       bg_per_batch, alpha_map, ts, eps, (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, flags);
+                       bg_per_batch, alpha_map, ts, eps, (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, flags, fl);
 }
 
 NR_API int nr_forward_texture_sampling(const float *faces, const float *faces_z_ref, const float *textures,
@@ -734,7 +778,7 @@ NR_API int nr_forward_texture_sampling(const float *faces, const float *faces_z_
     hipLaunchKernelGGL(k_shade, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces,
                        faces_z_ref ? faces_z_ref : faces, textures, face_index_map, weight_map, depth_map, rgb_map,
                        sampling_index_map, sampling_weight_map, background, bg_per_batch, alpha_map, F, S, ts, eps,
-                       (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, n);
+                       (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, n, FaceLight());
     return launch_status();
 }
 

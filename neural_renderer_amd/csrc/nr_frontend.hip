@@ -141,18 +141,12 @@ __device__ __forceinline__ void face_light(const FrontendParams &P, const float 
     }
 }
 
-__device__ __forceinline__ int transpose_texel(int t, int ts)
-{
-    const int k = t % ts, j = (t / ts) % ts, i = t / (ts * ts);  // (i, j, k) -> (k, j, i): renderer.py:79
-    return (k * ts + j) * ts + i;
-}
-
 __global__ __launch_bounds__(FE_THREADS) void k_frontend_forward(const float *__restrict__ vertices,
                                                                  const int32_t *__restrict__ faces_idx,
                                                                  const float *__restrict__ textures,
                                                                  const float *__restrict__ eye, float *__restrict__ faces_out,
                                                                  float *__restrict__ textures_out, int Nv, int Nf, int ts,
-                                                                 FrontendParams P)
+                                                                 FrontendParams P, float *__restrict__ light_out)
 {
     const int b = blockIdx.y;
     const int f = (blockIdx.x * FE_THREADS + threadIdx.x) / FE_LANES;
@@ -185,6 +179,17 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_forward(const float *__
         }
     }
 
+    if (light_out && lane == 0) {  // the colours only: the rasterizer multiplies its samples by them (nr_hip.h: nr_face_light)
+        float n[3], dotn, lf[3], lb[3];
+        face_light(P, w[0], w[1], w[2], n, dotn, lf, lb);
+        float *of = light_out + ((size_t)b * Fout + f) * 3;
+        float *ob = light_out + ((size_t)b * Fout + Nf + f) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            of[c] = lf[c];
+            if (P.fill_back) ob[c] = lb[c];
+        }
+    }
     if (textures) {
         float n[3], dotn, lf[3], lb[3];
         face_light(P, w[0], w[1], w[2], n, dotn, lf, lb);
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_backward(
     const float *__restrict__ vertices, const int32_t *__restrict__ faces_idx, const float *__restrict__ textures,
     const float *__restrict__ eye, const float *__restrict__ g_faces, const float *__restrict__ g_tex_out,
     float *__restrict__ grad_vertices, float *__restrict__ grad_textures, double *__restrict__ cam_acc, int Nv, int Nf, int ts,
-    FrontendParams P)
+    FrontendParams P, const float *__restrict__ g_light)
 {
     __shared__ double s_acc[FE_THREADS / 64][12];
     const int b = blockIdx.y;
@@ -240,15 +245,22 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_backward(
         float gw[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // gradient w.r.t. the face's three world-space vertices
 
         // ---- textures / lighting ----
-        if (textures && g_tex_out) {
+        if ((textures && g_tex_out) || g_light) {
             float n[3], dotn, lf[3], lb[3];
             face_light(P, w[0], w[1], w[2], n, dotn, lf, lb);
-            const int T = ts * ts * ts;
+            const int T = g_light ? 0 : ts * ts * ts;
             const float *tex = textures + ((size_t)b * Nf + f) * T * 3;
             const float *gf = g_tex_out + ((size_t)b * Fout + f) * T * 3;
             const float *gb = g_tex_out + ((size_t)b * Fout + Nf + f) * T * 3;
             float *gt = grad_textures ? grad_textures + ((size_t)b * Nf + f) * T * 3 : nullptr;
             float glf[3] = {0, 0, 0}, glb[3] = {0, 0, 0};
+            if (g_light && lane == 0) {  // the colours' gradient arrives summed (the other lanes add zeros below)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    glf[c] = g_light[((size_t)b * Fout + f) * 3 + c];
+                    if (P.fill_back) glb[c] = g_light[((size_t)b * Fout + Nf + f) * 3 + c];
+                }
+            }
             for (int t = lane; t < T; t += FE_LANES) {
                 const int u = P.fill_back ? transpose_texel(t, ts) : 0;
 #pragma unroll
@@ -481,25 +493,44 @@ NR_API int nr_frontend_forward(const float *vertices, const int32_t *faces_idx, 
     if (rc) return rc;
     const dim3 grid((unsigned)(((size_t)Nf * FE_LANES + FE_THREADS - 1) / FE_THREADS), (unsigned)B);
     hipLaunchKernelGGL(k_frontend_forward, grid, dim3(FE_THREADS), 0, (hipStream_t)stream, vertices, faces_idx, textures, eye,
-                       faces_out, textures_out, Nv, Nf, ts, P);
+                       faces_out, textures_out, Nv, Nf, ts, P, (float *)nullptr);
     return launch_status();
 }
 
-NR_API int nr_frontend_backward(const float *vertices, const int32_t *faces_idx, const float *textures, const float *eye,
-                                const float *grad_faces, const float *grad_textures_out, float *grad_vertices,
-                                float *grad_textures, float *grad_eye, int32_t B, int32_t Nv, int32_t Nf, int32_t ts,
-                                int32_t idx_per_batch, int32_t eye_per_batch, int32_t fill_back, const nr_camera *camera,
-                                const nr_light *light, void *workspace, size_t workspace_bytes, void *stream)
+NR_API int nr_frontend_forward_light(const float *vertices, const int32_t *faces_idx, const float *eye, float *faces_out,
+                                     float *light_out, int32_t B, int32_t Nv, int32_t Nf, int32_t idx_per_batch,
+                                     int32_t eye_per_batch, int32_t fill_back, const nr_camera *camera,
+                                     const nr_light *light, void *stream)
+{
+    if (!vertices || !faces_idx || !eye || !faces_out || !light_out) return NR_E_NULL;
+    int rc = frontend_sizes(B, Nv, Nf, 0, false);
+    if (rc) return rc;
+    FrontendParams P;
+    rc = fill_params(P, camera, light, idx_per_batch, eye_per_batch, fill_back, true);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(((size_t)Nf * FE_LANES + FE_THREADS - 1) / FE_THREADS), (unsigned)B);
+    hipLaunchKernelGGL(k_frontend_forward, grid, dim3(FE_THREADS), 0, (hipStream_t)stream, vertices, faces_idx,
+                       (const float *)nullptr, eye, faces_out, (float *)nullptr, Nv, Nf, 0, P, light_out);
+    return launch_status();
+}
+
+namespace {
+int frontend_backward(const float *vertices, const int32_t *faces_idx, const float *textures, const float *eye,
+                      const float *grad_faces, const float *grad_textures_out, const float *grad_light,
+                      float *grad_vertices, float *grad_textures, float *grad_eye, int32_t B, int32_t Nv, int32_t Nf,
+                      int32_t ts, int32_t idx_per_batch, int32_t eye_per_batch, int32_t fill_back,
+                      const nr_camera *camera, const nr_light *light, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!vertices || !faces_idx || !eye || !grad_faces) return NR_E_NULL;
     if (!grad_vertices && !grad_textures && !grad_eye) return NR_E_MODE;
     if (grad_eye && !grad_vertices) return NR_E_MODE;  // the camera sums are produced by the vertex pass
     if (grad_textures && !(textures && grad_textures_out)) return NR_E_MODE;
     if (grad_textures_out && !textures) return NR_E_MODE;
+    const bool lit = textures != nullptr || grad_light != nullptr;
     int rc = frontend_sizes(B, Nv, Nf, ts, textures != nullptr);
     if (rc) return rc;
     FrontendParams P;
-    rc = fill_params(P, camera, light, idx_per_batch, eye_per_batch, fill_back, textures != nullptr);
+    rc = fill_params(P, camera, light, idx_per_batch, eye_per_batch, fill_back, lit);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     double *cam_acc = nullptr;
@@ -519,7 +550,7 @@ NR_API int nr_frontend_backward(const float *vertices, const int32_t *faces_idx,
     }
     const dim3 grid((unsigned)(((size_t)Nf * FE_LANES + FE_THREADS - 1) / FE_THREADS), (unsigned)B);
     hipLaunchKernelGGL(k_frontend_backward, grid, dim3(FE_THREADS), 0, st, vertices, faces_idx, textures, eye, grad_faces,
-                       grad_textures_out, grad_vertices, grad_textures, cam_acc, Nv, Nf, ts, P);
+                       grad_textures_out, grad_vertices, grad_textures, cam_acc, Nv, Nf, ts, P, grad_light);
     rc = launch_status();
     if (rc) return rc;
     if (grad_eye) {
@@ -527,4 +558,28 @@ NR_API int nr_frontend_backward(const float *vertices, const int32_t *faces_idx,
         rc = launch_status();
     }
     return rc;
+}
+}  // namespace
+
+NR_API int nr_frontend_backward(const float *vertices, const int32_t *faces_idx, const float *textures, const float *eye,
+                                const float *grad_faces, const float *grad_textures_out, float *grad_vertices,
+                                float *grad_textures, float *grad_eye, int32_t B, int32_t Nv, int32_t Nf, int32_t ts,
+                                int32_t idx_per_batch, int32_t eye_per_batch, int32_t fill_back, const nr_camera *camera,
+                                const nr_light *light, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return frontend_backward(vertices, faces_idx, textures, eye, grad_faces, grad_textures_out, nullptr, grad_vertices,
+                             grad_textures, grad_eye, B, Nv, Nf, ts, idx_per_batch, eye_per_batch, fill_back, camera, light,
+                             workspace, workspace_bytes, stream);
+}
+
+NR_API int nr_frontend_backward_light(const float *vertices, const int32_t *faces_idx, const float *eye,
+                                      const float *grad_faces, const float *grad_light, float *grad_vertices,
+                                      float *grad_eye, int32_t B, int32_t Nv, int32_t Nf, int32_t idx_per_batch,
+                                      int32_t eye_per_batch, int32_t fill_back, const nr_camera *camera,
+                                      const nr_light *light, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (grad_light && !light) return NR_E_NULL;
+    return frontend_backward(vertices, faces_idx, nullptr, eye, grad_faces, nullptr, grad_light, grad_vertices, nullptr,
+                             grad_eye, B, Nv, Nf, 0, idx_per_batch, eye_per_batch, fill_back, camera, light, workspace,
+                             workspace_bytes, stream);
 }

@@ -191,6 +191,60 @@ class _FrontEnd(torch.autograd.Function):
         return (grad_v if ctx.needs_input_grad[0] else None), grad_t, grad_e, None, None, None, None
 
 
+class _FrontEndLight(torch.autograd.Function):
+    """forward(ctx, vertices, eye, faces_idx, camera, light, fill_back) -> (faces [B,F,3,3], light colours [B,F,3]):
+    the front-end for the rasterizer's `face_light` mode (include/nr_hip.h: nr_frontend_forward_light) -- no textures pass
+    through; their gradient comes straight out of the rasterizer."""
+
+    @staticmethod
+    def forward(ctx, vertices, eye, faces_idx, camera, light, fill_back):
+        lib = _lib.load()
+        dev = vertices.device
+        v = vertices.detach().contiguous()
+        idx = faces_idx.detach().to(torch.int32).contiguous()
+        e = eye.detach().contiguous()
+        B, Nv = v.shape[:2]
+        Nf = idx.shape[1]
+        F = Nf * 2 if fill_back else Nf
+        faces_out = torch.empty((B, F, 3, 3), dtype=torch.float32, device=dev)
+        light_out = torch.empty((B, F, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nr_frontend_forward_light(
+                v.data_ptr(), idx.data_ptr(), e.data_ptr(), faces_out.data_ptr(), light_out.data_ptr(), B, Nv, Nf, 1,
+                int(e.dim() == 2), int(fill_back), camera, light, torch.cuda.current_stream(dev).cuda_stream),
+                'nr_frontend_forward_light')
+        ctx.save_for_backward(v, idx, e)
+        ctx.params = (camera, light, bool(fill_back), B, Nv, Nf)
+        ctx.set_materialize_grads(False)
+        return faces_out, light_out
+
+    @staticmethod
+    def backward(ctx, g_faces, g_light):
+        lib = _lib.load()
+        v, idx, e = ctx.saved_tensors
+        camera, light, fill_back, B, Nv, Nf = ctx.params
+        dev = v.device
+        need_v, need_e = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_v or need_e):
+            return None, None, None, None, None, None
+        F = Nf * 2 if fill_back else Nf
+        if g_faces is None:
+            g_faces = torch.zeros((B, F, 3, 3), dtype=torch.float32, device=dev)
+        g_faces = g_faces.contiguous()
+        if g_light is not None:
+            g_light = g_light.contiguous()
+        grad_v = torch.empty((B, Nv, 3), dtype=torch.float32, device=dev)  # the camera sums come out of the vertex pass
+        grad_e = torch.empty_like(e) if need_e else None
+        ws_bytes = lib.nr_frontend_workspace_bytes(B) if need_e else 0
+        ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nr_frontend_backward_light(
+                v.data_ptr(), idx.data_ptr(), e.data_ptr(), g_faces.data_ptr(), _lib.ptr(g_light), grad_v.data_ptr(),
+                _lib.ptr(grad_e), B, Nv, Nf, 1, int(e.dim() == 2), int(fill_back), camera, light, ws.data_ptr(), ws_bytes,
+                torch.cuda.current_stream(dev).cuda_stream), 'nr_frontend_backward_light')
+        return (grad_v if need_v else None), grad_e, None, None, None, None
+
+
 _EYE_CACHE = {}
 
 
@@ -214,3 +268,11 @@ def project_and_light(renderer, vertices, faces, textures=None):
     light = _light_struct(renderer) if textures is not None else None
     eye = _eye_tensor(renderer.eye, vertices.device)
     return _FrontEnd.apply(vertices, textures, eye, faces, camera, light, bool(renderer.fill_back))
+
+
+def project_and_light_colors(renderer, vertices, faces):
+    """-> (faces [B,F,3,3], light colours [B,F,3]) for the rasterizer's face_light mode; call only when fusable(...)."""
+    _util.check_face_indices(faces, vertices.shape[1], vertices.device)
+    eye = _eye_tensor(renderer.eye, vertices.device)
+    return _FrontEndLight.apply(vertices, eye, faces, _camera_struct(renderer), _light_struct(renderer),
+                                bool(renderer.fill_back))

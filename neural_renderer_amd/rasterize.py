@@ -105,11 +105,13 @@ def _forward_workspace(lib, dev, stream, B, F, S):
 
 
 class _RasterizeFunction(torch.autograd.Function):
-    """forward(ctx, faces, textures, cfg) -> (rgb_map [B,S,S,3] | None, alpha_map [B,S,S] | None,
-    depth_map [B,S,S] | None); backward(ctx, g_rgb, g_alpha, g_depth) -> (grad_faces, grad_textures, None)."""
+    """forward(ctx, faces, textures, cfg, light) -> (rgb_map [B,S,S,3] | None, alpha_map [B,S,S] | None,
+    depth_map [B,S,S] | None); backward(ctx, g_rgb, g_alpha, g_depth) -> (grad_faces, grad_textures, None, grad_light).
+    `light` [B,F,3] (or None): per-face light colours, textures are then the original cubes [B,Nf,...] with F = Nf or 2 Nf
+    (include/nr_hip.h: nr_face_light)."""
 
     @staticmethod
-    def forward(ctx, faces, textures, cfg):
+    def forward(ctx, faces, textures, cfg, light=None):
         lib = _lib.load()
         if not faces.is_cuda:
             raise NotImplementedError('neural_renderer_amd has no CPU rasterizer (neither has the reference: '
@@ -123,12 +125,24 @@ class _RasterizeFunction(torch.autograd.Function):
         B, F = faces_c.shape[:2]
         S = int(cfg['image_size'])
         ts = 0
-        textures_c = None
+        textures_c = light_c = None
+        Nf = F
+        if not return_rgb:
+            light = None
         if return_rgb:
             if textures is None:
                 raise ValueError('textures are required when return_rgb is set')
+            if light is not None:
+                if light.dtype != torch.float32 or tuple(light.shape) != (B, F, 3):
+                    raise ValueError('face_light must be float32 [batch size, num of faces, 3], got %s %s'
+                                     % (light.dtype, tuple(light.shape)))
+                if textures.dim() == 6 and textures.shape[1] * 2 == F:
+                    Nf = F // 2  # fill_back: face Nf + f is the reversed copy of face f
+                if textures.dim() == 6 and textures.shape[2] > 13:
+                    raise ValueError('face_light needs texture_size <= 13')
+                light_c = light.detach().contiguous()
             if (textures.dtype != torch.float32 or textures.dim() != 6 or textures.shape[0] != B or
-                    textures.shape[1] != F or textures.shape[2] < 2 or textures.shape[2] != textures.shape[3] or
+                    textures.shape[1] != Nf or textures.shape[2] < 2 or textures.shape[2] != textures.shape[3] or
                     textures.shape[3] != textures.shape[4] or textures.shape[5] != 3):
                 raise ValueError('textures must be float32 [batch size, num of faces, ts, ts, ts, 3] with ts >= 2, '
                                  'got %s %s' % (textures.dtype, tuple(textures.shape)))  # rasterize.py:78-90
@@ -170,13 +184,17 @@ class _RasterizeFunction(torch.autograd.Function):
             # faces without a pixel)
             visible = torch.empty((B, F), dtype=torch.uint8, device=dev)
             # visibility + shading behind one call (rasterize.py:499-502)
-            _lib.check(lib.nr_forward_rasterize(
-                faces_c.data_ptr(), _lib.ptr(z_ref), _lib.ptr(textures_c), face_index_map.data_ptr(),
+            lit = None
+            if light_c is not None:
+                lit = _lib.FaceLight(light_c.data_ptr(), Nf, None, None)
+            _lib.check(lib.nr_forward_rasterize_lit(
+                lit, faces_c.data_ptr(), _lib.ptr(z_ref), _lib.ptr(textures_c), face_index_map.data_ptr(),
                 _lib.ptr(weight_map), _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(alpha_map), _lib.ptr(visible),
                 _lib.ptr(background), bg_per_batch, B, F, S, ts, float(cfg['near']), float(cfg['far']),
                 float(cfg['eps']), flags | ws_flags, workspace.data_ptr(), ws_bytes, stream), 'nr_forward_rasterize')
 
-        ctx.cfg = dict(cfg, keep=None, B=B, F=F, S=S, ts=ts, flags=flags)
+        ctx.cfg = dict(cfg, keep=None, B=B, F=F, S=S, ts=ts, flags=flags, Nf=Nf)
+        ctx.lit = (light_c, textures_c) if light_c is not None else None
         keep = cfg.get('keep')
         if keep is not None:  # the maps the reference leaves on the Function instance (rasterize.py:39-58); no copies
             keep.update(faces=faces_c, textures=textures_c, face_index_map=face_index_map, weight_map=weight_map,
@@ -206,7 +224,8 @@ class _RasterizeFunction(torch.autograd.Function):
         use_alpha = cfg['return_alpha'] and g_alpha is not None
         use_depth = cfg['return_depth'] and g_depth is not None
         if not (use_rgb or use_alpha or use_depth):
-            return None, None, None
+            return None, None, None, None
+        grad_light = None
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             if use_rgb:
@@ -217,13 +236,21 @@ class _RasterizeFunction(torch.autograd.Function):
                 g_depth = g_depth.contiguous()
             grad_faces = torch.empty_like(faces_c)  # stored by the library (zeros when neither rgb nor alpha)
             grad_textures = None
-            if use_rgb and ctx.needs_input_grad[1]:
+            lit = None
+            if use_rgb and ctx.lit is not None:
+                if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+                    # one gather produces both (the colours' gradient is a by-product of the texel sums)
+                    grad_textures = torch.empty((B, cfg['Nf'], ts, ts, ts, 3), dtype=torch.float32, device=dev)
+                    if ctx.needs_input_grad[3]:
+                        grad_light = torch.empty((B, F, 3), dtype=torch.float32, device=dev)
+                lit = _lib.FaceLight(ctx.lit[0].data_ptr(), cfg['Nf'], ctx.lit[1].data_ptr(), _lib.ptr(grad_light))
+            elif use_rgb and ctx.needs_input_grad[1]:
                 grad_textures = torch.empty((B, F, ts, ts, ts, 3), dtype=torch.float32, device=dev)
             ws_bytes = lib.nr_backward_workspace_bytes(B, F, S, int(use_rgb), int(use_alpha))
             workspace = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
             # K6 -> K7 -> K8 (rasterize.py:881-883) behind one call
-            _lib.check(lib.nr_backward_rasterize(
-                faces_c.data_ptr(), _lib.ptr(ctx.z_ref), face_index_map.data_ptr(), _lib.ptr(weight_map),
+            _lib.check(lib.nr_backward_rasterize_lit(
+                lit, faces_c.data_ptr(), _lib.ptr(ctx.z_ref), face_index_map.data_ptr(), _lib.ptr(weight_map),
                 _lib.ptr(depth_map), _lib.ptr(rgb_map) if use_rgb else None, _lib.ptr(alpha_map) if use_alpha else None,
                 _lib.ptr(g_rgb) if use_rgb else None, _lib.ptr(g_alpha) if use_alpha else None,
                 _lib.ptr(g_depth) if use_depth else None, grad_faces.data_ptr(), _lib.ptr(grad_textures),
@@ -233,7 +260,9 @@ class _RasterizeFunction(torch.autograd.Function):
         if owner is not None:  # rasterize.py:41-51: the gradient buffers stay readable on the instance
             owner.grad_rgb_map, owner.grad_alpha_map, owner.grad_depth_map = g_rgb, g_alpha, g_depth
             owner.grad_faces, owner.grad_textures = grad_faces, grad_textures
-        return grad_faces, grad_textures, None
+        if not ctx.needs_input_grad[1]:
+            grad_textures = None
+        return grad_faces, grad_textures, None, grad_light
 
 
 def _capture(fn, dev):
@@ -484,7 +513,10 @@ class Rasterize(object):
         self.face_inv_map = self.sampling_index_map = self.sampling_weight_map = None
         self.batch_size = self.num_faces = self.texture_size = None
 
-    def __call__(self, faces, textures=None):
+    def __call__(self, faces, textures=None, face_light=None):
+        """`face_light` (not in the reference; include/nr_hip.h nr_face_light): [B,F,3] colours that multiply the sampled
+        colour of each face; `textures` are then the cubes of the original faces ([B,F,...], or [B,F/2,...] when the second
+        half of `faces` are fill_back's reversed copies)."""
         keep = {}
         cfg = dict(keep=keep, owner=weakref.ref(self), image_size=self.image_size, near=self.near, far=self.far, eps=self.eps,
                    background_color=self.background_color if self.background_color is not None
@@ -493,8 +525,8 @@ class Rasterize(object):
                    return_depth=bool(self.return_depth), fix_batch_z=bool(self.fix_batch_z),
                    exact_gradient=bool(self.exact_gradient), faces_z_ref=self.faces_z_ref)
         if not self.return_rgb:
-            textures = None
-        entry = _graph_entry(faces, textures, cfg) if self.graph_replay else None
+            textures = face_light = None
+        entry = _graph_entry(faces, textures, cfg) if self.graph_replay and face_light is None else None
         if entry is not None and torch.is_grad_enabled() and (faces.requires_grad or (textures is not None and textures.requires_grad)):
             # the usual case: every requested output receives a gradient
             entry.prepare_backward((bool(self.return_rgb), bool(self.return_alpha), bool(self.return_depth),
@@ -505,7 +537,7 @@ class Rasterize(object):
                         rgb_map=rgb, alpha_map=alpha, batch_size=entry.dims[0], num_faces=entry.dims[1],
                         texture_size=entry.dims[3] if self.return_rgb else None)
         else:
-            rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg)
+            rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg, face_light)
         for k, v in keep.items():
             setattr(self, k, v)
         self.face_index_map = fi
@@ -526,12 +558,14 @@ def rasterize_rgbad(
         return_depth=True,
         faces_z_ref=None,
         graph_replay=None,
+        face_light=None,
 ):
     """RGB, alpha and depth images from faces (and textures for RGB) -- reference rasterize.py:900-977.
 
     Returns a dict with 'rgb' [B, 3, image_size, image_size], 'alpha' and 'depth' [B, image_size, image_size]
-    (None when not requested).  `faces_z_ref` (not in the reference): see Rasterize.faces_z_ref."""
-    inputs = [faces] if textures is None else [faces, textures]
+    (None when not requested).  `faces_z_ref` (not in the reference): see Rasterize.faces_z_ref; `face_light` (not in the
+    reference): see Rasterize.__call__."""
+    inputs = [faces] if textures is None else [faces, textures, face_light]
     size = image_size * 2 if anti_aliasing else image_size  # 2x super-sampling, :945-951
     fn = Rasterize(size, near, far, eps, background_color, return_rgb, return_alpha, return_depth)
     fn.faces_z_ref = faces_z_ref
@@ -558,11 +592,12 @@ def rasterize(
         background_color=DEFAULT_BACKGROUND_COLOR,
         faces_z_ref=None,
         graph_replay=None,
+        face_light=None,
 ):
     """RGB images [B, 3, image_size, image_size] -- reference rasterize.py:980-1008."""
     return rasterize_rgbad(
         faces, textures, image_size, anti_aliasing, near, far, eps, background_color, True, False, False,
-        faces_z_ref=faces_z_ref, graph_replay=graph_replay)['rgb']
+        faces_z_ref=faces_z_ref, graph_replay=graph_replay, face_light=face_light)['rgb']
 
 
 def rasterize_silhouettes(

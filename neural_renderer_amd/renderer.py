@@ -4,6 +4,8 @@ On CUDA tensors with the usual parameter types the chain in front of the rasteri
 perspective, vertices_to_faces) runs as one fused HIP kernel per direction (frontend.py); any other input keeps the
 module-by-module path below, which mirrors the reference line by line."""
 import math
+import os
+import sys
 
 import torch
 
@@ -14,6 +16,9 @@ from .look_at import look_at
 from .perspective import perspective
 from .rasterize import rasterize, rasterize_depth, rasterize_silhouettes
 from .vertices_to_faces import vertices_to_faces
+
+# Renderer.face_light default (see the attribute): NR_FACE_LIGHT = 0 | 1 | auto
+FACE_LIGHT = {'0': False, '1': True}.get(os.environ.get('NR_FACE_LIGHT', 'auto'))
 
 
 class Renderer(object):
@@ -53,6 +58,14 @@ class Renderer(object):
         # not in the reference: replay the rasterizer from captured HIP graphs (fixed shapes; None = the module default,
         # neural_renderer_amd.use_graph_replay / NR_GRAPH_REPLAY; see rasterize.py)
         self.graph_replay = None
+        # not in the reference: render() hands the rasterizer the ORIGINAL textures plus one light colour per face instead of
+        # lit, fill_back-duplicated textures (include/nr_hip.h: nr_face_light).  Same images up to the rounding
+        # order of the light product (measured 3e-7 of the largest colour, tests/test_face_light_gpu.py), a fraction of the
+        # memory traffic on textured meshes (scripts/face_light_timing.py: config 4's shape 2.20 -> 1.12 ms per render +
+        # backward at texture_size 4, 16.3 -> 1.85 ms at 8; neutral at 2).  True / False, or None = when it pays
+        # (texture_size >= 3).  Needs the fused front-end, texture_size <= 13 and no graph replay; otherwise, and with False,
+        # the lit-texture path runs.  Default: NR_FACE_LIGHT (auto).
+        self.face_light = FACE_LIGHT
 
     def _project(self, vertices, faces):
         """camera + perspective + gather (renderer.py:40-51, :60-71, :92-103)."""
@@ -100,7 +113,24 @@ class Renderer(object):
         faces, _ = self._frontend(vertices, faces)
         return rasterize_depth(faces, self.image_size, self.anti_aliasing, graph_replay=self.graph_replay)  # renderer.py:72 (Q2)
 
+    def _use_face_light(self, vertices, faces, textures):
+        if self.face_light is False or not (torch.is_tensor(textures) and textures.dim() == 6):
+            return False
+        ts = textures.shape[2]
+        if ts > 13 or (self.face_light is None and ts < 3):
+            return False
+        # (the package attribute `rasterize` is the function; the module of that name holds the switch)
+        replay = self.graph_replay if self.graph_replay is not None else sys.modules[rasterize.__module__].GRAPH_REPLAY
+        return not replay and frontend.fusable(self, vertices, faces, textures)
+
     def render(self, vertices, faces, textures):
+        if self._use_face_light(vertices, faces, textures):
+            self.last_frontend = 'fused'
+            self.frontend_calls['fused'] += 1
+            faces, light = frontend.project_and_light_colors(self, vertices, faces)
+            return rasterize(
+                faces, textures, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,
+                self.background_color, faces_z_ref=self.faces_z_ref, face_light=light)
         faces, textures = self._frontend(vertices, faces, textures)
         return rasterize(
             faces, textures, self.image_size, self.anti_aliasing, self.near, self.far, self.rasterizer_eps,

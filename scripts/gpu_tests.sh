@@ -7,7 +7,7 @@ rm -f gpurun_out/parity_errors.jsonl
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 : > $OUT/pytest.log
 for f in tests/test_hip_parity.py tests/test_fuzz_gpu.py tests/test_full_size_gpu.py tests/test_gradient_pins_gpu.py \
-         tests/test_sharding_gpu.py tests/test_frontend_gpu.py tests/test_texture_io.py tests/test_optimizer.py \
+         tests/test_sharding_gpu.py tests/test_frontend_gpu.py tests/test_face_light_gpu.py tests/test_texture_io.py tests/test_optimizer.py \
          tests/test_examples_gpu.py tests/test_bench_contract.py tests/test_multi_rank_gpu.py tests/test_rccl_gpu.py; do
   echo "=== $f" >> $OUT/pytest.log
   timeout ${TEST_TIMEOUT:-600} python -m pytest $f -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -${TAIL:-200} >> $OUT/pytest.log
