@@ -259,7 +259,10 @@ class _RasterizeFunction(torch.autograd.Function):
         owner = cfg['owner']() if cfg.get('owner') is not None else None
         if owner is not None:  # rasterize.py:41-51: the gradient buffers stay readable on the instance
             owner.grad_rgb_map, owner.grad_alpha_map, owner.grad_depth_map = g_rgb, g_alpha, g_depth
-            owner.grad_faces, owner.grad_textures = grad_faces, grad_textures
+            # (aliases, not the returned tensors themselves: a second reference to a returned gradient makes autograd's
+            # AccumulateGrad clone it instead of adopting it -- two device copies, 41 MB per step at the headline size)
+            owner.grad_faces = grad_faces.detach()
+            owner.grad_textures = grad_textures.detach() if grad_textures is not None else None
         if not ctx.needs_input_grad[1]:
             grad_textures = None
         return grad_faces, grad_textures, None, grad_light
