@@ -16,6 +16,7 @@
 // Per-pixel terms use the reference's arithmetic; the order of the additions differs (as it does between
 // any two runs of the reference, whose atomics are unordered).
 #include "nr_device.h"
+#include <type_traits>
 
 using namespace nr;
 
@@ -123,7 +124,10 @@ __device__ __forceinline__ void walk_owned_pixels(const Cand &cd, int n_mine, in
 // (pn & 1) * 4 + ((pn >> 1) & 1) * 2 + ((pn >> 2) & 1)   (floor(tif) == 0 because tif <= 1 - eps, :402).
 // DEPTH = true additionally evaluates K8 (backward_depth_map) for the same owned pixels and adds the face's 9
 // sums onto grad_faces, so that one walk of the screen box serves both gradients (fused backward only).
-template <bool TS2, bool DEPTH>
+// LIT = true: per-face light colours (FaceLight in nr_device.h) -- a template parameter, so that the kernels of the plain
+// path are exactly what they were without it (as a run-time branch it cost them registers: K7 alone 72 -> 76 VGPRs, one
+// wave of occupancy, 62 -> 71 us).
+template <bool TS2, bool DEPTH, bool LIT>
 __global__ __launch_bounds__(256) void k_backward_textures_face(
     const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
     const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
@@ -171,8 +175,10 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     bool own = false;  // this lane evaluated a pixel of the face (lit: only such faces store, see FaceLight)
     if (!TS2) {
         for (int k = sub; k < n_tex; k += L) acc_l[k] = 0.0;
-        if (tid < 3) s_gl[tid] = 0.0f;
-        if (tid == 0) s_own = 0;
+        if (LIT) {
+            if (tid < 3) s_gl[tid] = 0.0f;
+            if (tid == 0) s_own = 0;
+        }
         __syncthreads();
     }
 
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     // flattens that copy's taps in the ORIGINAL layout (compute_taps' flip), so the sums need no transposition afterwards.
     bool flip = false;
     size_t cube = 0;  // b * Nf + original face
-    if (lit.light) {
+    if (LIT) {
         const int b = vis_list ? (int)blockIdx.y : gi / F, f = gi - b * F;
         flip = f >= lit.tex_faces;
         cube = (size_t)b * lit.tex_faces + (flip ? f - lit.tex_faces : f);
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         if (depth_map) depth = depth_map[p];
         if (DEPTH) gd = g_depth[p];
         const float g[3] = {g_rgb[3 * p], g_rgb[3 * p + 1], g_rgb[3 * p + 2]};
-        own = true;
+        if (LIT) own = true;
         Taps t;
         if (sampling_weight_map) {
 #pragma unroll
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
                 t.isc[pn] = sampling_index_map[8 * p + pn];
             }
         } else {
-            compute_taps(face_z, wk, depth, ts, eps, t, flip);
+            compute_taps(face_z, wk, depth, ts, eps, t, LIT && flip);
         }
         if (DEPTH) {  // K8 terms of this pixel (rasterize.py:824-837), as in k_backward_depth_face
             const float depth2 = depth * depth;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 
     // lit: does the face own a pixel at all?  (only then it stores: FaceLight)
     bool owned = false;
-    if (lit.light) {
+    if (LIT) {
         if (L <= 64) {
             const unsigned long long bm = __ballot(own);
             owned = L == 64 ? bm != 0ull : ((bm >> (tid & 48)) & 0xffffull) != 0ull;
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         // L == 16 here: reduce inside the 16-lane row, its last lane stores the face's 24 floats (96 B)
 #pragma unroll
         for (int k = 0; k < 24; k++) acc[k] = row16_sum_last(acc[k]);
-        if (lit.light) {
+        if (LIT) {
             if (face_ok && sub == 15 && owned) {
                 // corner pn holds texel bitrev3(pn) of the sampled cube (the static taps above); the reversed copy samples the
                 // transposed cube, whose texel bitrev3(pn) is texel pn of the original one
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 #pragma unroll
             for (int k = 0; k < 6; k++) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
         }
-    } else if (lit.light) {
+    } else if (LIT) {
         __syncthreads();
         float gl0 = 0.0f, gl1 = 0.0f, gl2 = 0.0f;
         if (face_ok && owned) {
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
 // through a wave + LDS reduction.  With no big face in the range the workgroup exits after ~150 instructions.
 // TEX: 0 no textures, 1 grad_textures through per-face LDS double accumulators (any texture_size <= 8), 2 texture_size 2 with
 // static taps (24 register sums per lane, as in the TS2 gather); DEPTH: the K8 terms.
-template <int TEX, bool DEPTH>
+template <int TEX, bool DEPTH, bool LIT>
 __global__ __launch_bounds__(256) void k_backward_big(
     const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
     const int32_t *__restrict__ sampling_index_map, const float *__restrict__ face_inv_map, const float *__restrict__ faces,
@@ -458,10 +464,10 @@ __global__ __launch_bounds__(256) void k_backward_big(
         if (DEPTH) dc = depth_constants(f, S);
         const float *fz = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fn * 9;  // :389, Q1
         const float face_z[3] = {fz[2], fz[5], fz[8]};
-        const bool flip = TEX && lit.light && fn >= lit.tex_faces;  // the reversed copy: taps in the original cube's layout
+        const bool flip = TEX && LIT && fn >= lit.tex_faces;  // the reversed copy: taps in the original cube's layout
         for (int k = tid; k < n_lds; k += 256) s_tex[k] = 0.0;
         if (tid < 36) s_red[tid] = 0.0f;
-        if (tid == 0) s_own = 0;
+        if (LIT && tid == 0) s_own = 0;
         __syncthreads();
         bool own = false;
         float dacc[9], tacc[24];
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256) void k_backward_big(
             if (!cand_pixel(cd, i, S, x, y)) continue;
             const size_t p = img + (size_t)y * S + x;
             if (face_index_map[p] != fn) continue;
-            own = true;
+            if (LIT) own = true;
             float wk[3] = {0.0f, 0.0f, 0.0f}, depth = 0.0f;
             if (weight_map) { wk[0] = weight_map[3 * p]; wk[1] = weight_map[3 * p + 1]; wk[2] = weight_map[3 * p + 2]; }
             if (depth_map) depth = depth_map[p];
@@ -539,9 +545,9 @@ __global__ __launch_bounds__(256) void k_backward_big(
                 if ((tid & 63) == 0 && v != 0.0f) atomicAdd(&s_red[9 + k], v);
             }
         }
-        if (TEX && lit.light && own) s_own = 1;
+        if (TEX && LIT && own) s_own = 1;
         __syncthreads();
-        if (TEX && lit.light) {  // the original cube, times the face's light colour; only a face that owns a pixel stores
+        if (TEX && LIT) {  // the original cube, times the face's light colour; only a face that owns a pixel stores
             if (s_own) {
                 const size_t cube = (size_t)b * lit.tex_faces + (flip ? fn - lit.tex_faces : fn);
                 const float *lc = lit.light + (size_t)gi * 3;
@@ -762,15 +768,18 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != 0) return e;
     }
+    // (the kernels take the per-face light mode as a template parameter: see k_backward_textures_face)
+    auto launch = [&](auto lit_mode) {
+    constexpr bool LITV = decltype(lit_mode)::value;
     if (ts2_static && !sampling_weight_map) {
         const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
         if (g_depth)
-            hipLaunchKernelGGL((k_backward_textures_face<true, true>), grid, dim3(256), 0, st, face_index_map,
+            hipLaunchKernelGGL((k_backward_textures_face<true, true, LITV>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
                                slot_of, lit);
         else
-            hipLaunchKernelGGL((k_backward_textures_face<true, false>), grid, dim3(256), 0, st, face_index_map,
+            hipLaunchKernelGGL((k_backward_textures_face<true, false, LITV>), grid, dim3(256), 0, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, (const float *)nullptr,
                                fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of, lit);
@@ -780,12 +789,12 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         const size_t lds = (size_t)per * n_tex * sizeof(double);
         const dim3 grid = vis_list ? dim3((unsigned)((F + per - 1) / per), (unsigned)B) : dim3((unsigned)((n + per - 1) / per));
         if (g_depth && L <= 64)
-            hipLaunchKernelGGL((k_backward_textures_face<false, true>), grid, dim3(256), lds, st, face_index_map,
+            hipLaunchKernelGGL((k_backward_textures_face<false, true, LITV>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
                                slot_of, lit);
         else
-            hipLaunchKernelGGL((k_backward_textures_face<false, false>), grid, dim3(256), lds, st, face_index_map,
+            hipLaunchKernelGGL((k_backward_textures_face<false, false, LITV>), grid, dim3(256), lds, st, face_index_map,
                                sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
                                grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, (const float *)nullptr,
                                fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of, lit);
@@ -796,7 +805,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         const bool st2 = ts2_static && !sampling_weight_map;
         const size_t lds = st2 ? 0 : n_tex * sizeof(double);
 #define NR_BIG(T, D)                                                                                                    \
-    hipLaunchKernelGGL((k_backward_big<T, D>), grid, dim3(256), lds, st, face_index_map, sampling_weight_map,          \
+    hipLaunchKernelGGL((k_backward_big<T, D, LITV>), grid, dim3(256), lds, st, face_index_map, sampling_weight_map,   \
                        sampling_index_map, (const float *)nullptr, faces, zbase, weight_map, depth_map, grad_rgb_map, \
                        grad_textures, n, F, S, ts, eps, fix, vis_list, vis_count, D ? g_depth : (const float *)nullptr, \
                        D ? grad_faces : (float *)nullptr, (const unsigned char *)nullptr, lit)
@@ -804,6 +813,8 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         else { if (g_depth) NR_BIG(1, true); else NR_BIG(1, false); }
 #undef NR_BIG
     }
+    };
+    if (lit.light) launch(std::true_type()); else launch(std::false_type());
     if (ts > 13) {
         // huge cubes: the reference's per-pixel scatter with hardware atomics
         const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
@@ -828,7 +839,7 @@ int nr::run_backward_depth_map(const float *faces, const float *depth_map, const
     hipLaunchKernelGGL(k_backward_depth_face, grid, dim3(256), 0, st, faces, depth_map, face_index_map, face_inv_map,
                        weight_map, grad_depth_map, grad_faces, n, F, S, vis_list, vis_count, visible);
     const dim3 grid_big = big_grid(vis_list != nullptr, B, F);
-    hipLaunchKernelGGL((k_backward_big<0, true>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
+    hipLaunchKernelGGL((k_backward_big<0, true, false>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
                        (const int32_t *)nullptr, face_inv_map, faces, faces, weight_map, depth_map, (const float *)nullptr,
                        (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces, visible, FaceLight());
     return launch_status();

@@ -37,6 +37,16 @@ if [ -n "$KSTATS" ]; then
   python scripts/rocpd_stats.py $OUT/stats_results.db $OUT/kernel_stats.csv > /dev/null 2>&1
   head -16 $OUT/kernel_stats.csv | cut -c1-70,100-170
 fi
+if [ -n "$STEPSEQ" ]; then
+  # the dispatch sequence of a steady-state step with in-step durations and idle gaps: raw C-ABI calls from one thread (the
+  # device's own pace) and bench.py's autograd step (host-bound under the tracer: its gaps are the tracer's launch overhead)
+  PROBE=A timeout 300 rocprofv3 --kernel-trace -d $OUT -o seqA -- python scripts/thread_gap_probe.py > $OUT/seqA.log 2>&1
+  { echo "== raw nr_forward_rasterize + nr_backward_rasterize calls, one thread (scripts/thread_gap_probe.py A)"; python scripts/step_gaps.py $OUT/seqA_results.db k_face_raster; } > $OUT/step_sequence.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace -d $OUT -o seqB -- python bench.py --steps 30 --warmup 3 --light --cpu-sample-views 0 > $OUT/seqB.log 2>&1
+  { echo "== bench.py step (autograd operator), traced"; python scripts/step_gaps.py $OUT/seqB_results.db k_face_raster; } >> $OUT/step_sequence.txt 2>&1
+  timeout 120 python scripts/thread_gap_probe.py 2>/dev/null | tail -6 >> $OUT/step_sequence.txt
+  cat $OUT/step_sequence.txt
+fi
 if [ -n "$PMC" ]; then
   ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o fetch -- python scripts/stage_times.py > $OUT/fetch.log 2>&1
   ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o write -- python scripts/stage_times.py > $OUT/write.log 2>&1
