@@ -239,6 +239,64 @@ def renderer_end_to_end(device, batch, first_view, total_views, image_size, text
     return out
 
 
+def face_light_row(device, batch=64, image_size=256, texture_size=4, iters=10):
+    """Renderer.render + backward on config 4's shape (`batch` distinct ~5k-face spheres, fill_back -> 10 240 faces, random
+    textures of `texture_size`) with lit, fill_back-duplicated textures handed to the rasterizer (the reference's data flow,
+    renderer.py:77-103) and with per-face light colours instead (Renderer.face_light): ms per step and the
+    largest difference between the two modes' images and gradients, relative to their largest value."""
+    import neural_renderer_amd as nr
+    rng = np.random.default_rng(3)
+    # a latitude / longitude sphere of 5 120 triangles (config 4: "~5k faces", 10 240 with fill_back)
+    n_lat, n_lon = 41, 64
+    th = np.pi * np.arange(1, n_lat) / n_lat
+    ph = 2 * np.pi * np.arange(n_lon) / n_lon
+    ring = np.stack([np.sin(th)[:, None] * np.cos(ph)[None], np.cos(th)[:, None] * np.ones_like(ph)[None],
+                     np.sin(th)[:, None] * np.sin(ph)[None]], axis=2).reshape(-1, 3)
+    v0 = np.concatenate(([[0.0, 1.0, 0.0]], ring, [[0.0, -1.0, 0.0]])).astype(np.float32)
+    idx = lambda i, j: 1 + i * n_lon + (j % n_lon)
+    tri = []
+    for j in range(n_lon):
+        tri.append((0, idx(0, j + 1), idx(0, j)))
+        tri.append((len(v0) - 1, idx(n_lat - 2, j), idx(n_lat - 2, j + 1)))
+        for i in range(n_lat - 2):
+            tri.append((idx(i, j), idx(i, j + 1), idx(i + 1, j)))
+            tri.append((idx(i + 1, j), idx(i, j + 1), idx(i + 1, j + 1)))
+    f0 = np.array(tri, np.int32)
+    vs = []
+    for _ in range(batch):
+        vv = v0 * (0.55 + 0.12 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+        q = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+        vs.append((vv @ q).astype(np.float32))
+    vertices0 = torch.from_numpy(np.stack(vs)).to(device)
+    faces = torch.from_numpy(f0.astype(np.int32)).to(device)[None].repeat(batch, 1, 1)
+    textures0 = torch.rand((batch, f0.shape[0], texture_size, texture_size, texture_size, 3), device=device)
+    out = {'what': 'Renderer.render + squared-sum loss, forward + backward: %d meshes x %d faces (fill_back -> %d), '
+                   'texture_size %d, %dx%d, anti_aliasing off' % (batch, f0.shape[0], 2 * f0.shape[0], texture_size,
+                                                                  image_size, image_size)}
+    keep = {}
+    for flag in (False, True):
+        r = nr.Renderer()
+        r.image_size, r.anti_aliasing, r.face_light = image_size, False, flag
+        r.eye = torch.tensor([nr.get_points_from_angles(2.732, 30., 360.0 * i / batch) for i in range(batch)],
+                             dtype=torch.float32, device=device)
+        v = vertices0.clone().requires_grad_(True)
+        t = textures0.clone().requires_grad_(True)
+
+        def step():
+            v.grad = None
+            t.grad = None
+            img = r.render(v, faces, t)
+            img.square().sum().backward()
+            return img
+
+        img = step()
+        keep[flag] = (img.detach(), v.grad.clone(), t.grad.clone())
+        out['face_light_ms' if flag else 'lit_textures_ms'] = time_step(step, device, iters, 3)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    out['max_rel_diff'] = {k: rel(keep[True][i], keep[False][i]) for i, k in enumerate(('images', 'grad_vertices', 'grad_textures'))}
+    return out
+
+
 def measure_time_protocol(device, batch_size, image_size=256, texture_size=2):
     """The reference's own timing protocol (misc/measure_time.py:12-18, 44-90) through the public Renderer with ITS
     defaults (anti-aliasing on => raster 2 x image_size, eye from get_points_from_angles(2.732, 30, azimuth)): 24 azimuths,
@@ -569,6 +627,7 @@ def main():
                 'what': 'misc/measure_time.py:12-18, 44-90 through Renderer() with the reference defaults (anti_aliasing on: raster 512 '
                         'for image_size 256); forward and backward of sum(images) timed separately, ms, mean of 23 azimuths',
                 'rows': [measure_time_protocol(dev, 1), measure_time_protocol(dev, B)]}
+            e2e['face_light'] = face_light_row(dev, B)
         cpu = None
         if args.cpu_sample_views > 0 and world == 1:
             cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,

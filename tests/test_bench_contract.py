@@ -45,6 +45,9 @@ def test_bench_json_line():
     assert [x['batch_size'] for x in rows] == [1, 4] and all(x['anti_aliasing'] and x['raster'] == 512 for x in rows)
     assert all(x[k] > 0 for x in rows for k in ('silhouette_forward_ms', 'silhouette_backward_ms', 'texture_forward_ms',
                                                  'texture_backward_ms'))
+    fl = d['renderer_end_to_end']['face_light']  # per-face light colours vs lit, duplicated textures
+    assert fl['face_light_ms'] > 0 and fl['lit_textures_ms'] > 0
+    assert fl['max_rel_diff']['images'] <= 1e-6 and fl['max_rel_diff']['grad_textures'] <= 1e-5
     st = r['stages']['per_stage']
     assert set(st) == set(d['stages_us']) - {'fused_forward_rasterize', 'fused_backward_rasterize'}
     assert all(0 < v['coverage_scaled_bytes'] <= v['algorithmic_bytes'] and v['frac'] < 1.0 for v in st.values())
