@@ -33,18 +33,19 @@ KERNEL_STAGES = [
     ('k_fill_bytes', ['forward_face_index_map', 'fused_forward_rasterize', 'fused_backward_rasterize']),
     ('k_shade', ['forward_texture_sampling']),
 ] + [(k, ['backward_pixel_map', 'fused_backward_rasterize']) for k in K6] + [
-    ('k_backward_textures_face<true, false>', ['backward_textures']),
-    ('k_backward_textures_face<false, false>', ['backward_textures']),
+    # (template argument lists are matched as prefixes: the gathers carry a third argument, the per-face light mode)
+    ('k_backward_textures_face<true, false', ['backward_textures']),
+    ('k_backward_textures_face<false, false', ['backward_textures']),
     ('k_backward_textures_atomic', ['backward_textures']),
-    ('k_backward_big<2, false>', ['backward_textures']),
-    ('k_backward_big<1, false>', ['backward_textures']),
+    ('k_backward_big<2, false', ['backward_textures']),
+    ('k_backward_big<1, false', ['backward_textures']),
     ('k_backward_depth_face', ['backward_depth_map']),
-    ('k_backward_big<0, true>', ['backward_depth_map']),
+    ('k_backward_big<0, true', ['backward_depth_map']),
     ('k_list_visible', ['backward_depth_map']),
-    ('k_backward_textures_face<true, true>', ['fused_backward_rasterize']),
-    ('k_backward_textures_face<false, true>', ['fused_backward_rasterize']),
-    ('k_backward_big<2, true>', ['fused_backward_rasterize']),
-    ('k_backward_big<1, true>', ['fused_backward_rasterize']),
+    ('k_backward_textures_face<true, true', ['fused_backward_rasterize']),
+    ('k_backward_textures_face<false, true', ['fused_backward_rasterize']),
+    ('k_backward_big<2, true', ['fused_backward_rasterize']),
+    ('k_backward_big<1, true', ['fused_backward_rasterize']),
 ]
 SETUP_KERNELS = ('k_face_raster', 'k_large_raster', 'k_resolve')  # launched once more by the set-up forward
 
