@@ -297,12 +297,14 @@ def face_light_row(device, batch=64, image_size=256, texture_size=4, iters=10):
     return out
 
 
-def measure_time_protocol(device, batch_size, image_size=256, texture_size=2):
+def measure_time_protocol(device, batch_size, image_size=256, texture_size=2, caller_thread=False):
     """The reference's own timing protocol (misc/measure_time.py:12-18, 44-90) through the public Renderer with ITS
     defaults (anti-aliasing on => raster 2 x image_size, eye from get_points_from_angles(2.732, 30, azimuth)): 24 azimuths,
     `render_silhouettes` then `render`, forward (to the first pixel on the host) and backward of sum(images) timed
     separately, first iteration dropped.  The reference stops its backward clock without synchronising (Q9: it times the
-    launch); here the clock stops after a device synchronize.  Milliseconds."""
+    launch); here the clock stops after a device synchronize.  Milliseconds.  caller_thread: with torch's autograd kept on
+    the calling thread (neural_renderer_amd.graph.backward_on_caller_thread: the hand-over to its device thread is ~100 us
+    of a host-bound backward)."""
     import neural_renderer_amd as nr
     v, f = load_teapot()
     vertices = torch.from_numpy(v).to(device)[None].repeat(batch_size, 1, 1).requires_grad_(True)
@@ -312,7 +314,13 @@ def measure_time_protocol(device, batch_size, image_size=256, texture_size=2):
     renderer = nr.Renderer()
     renderer.image_size = image_size
     out = {'batch_size': batch_size, 'image_size': image_size, 'raster': 2 * image_size if renderer.anti_aliasing else image_size,
-           'anti_aliasing': bool(renderer.anti_aliasing)}
+           'anti_aliasing': bool(renderer.anti_aliasing),
+           'autograd': 'backward on the calling thread' if caller_thread else 'torch default (device thread)'}
+    if caller_thread:
+        with nr.graph.backward_on_caller_thread():
+            out.update({k: v for k, v in measure_time_protocol(device, batch_size, image_size, texture_size).items()
+                        if k.endswith('_ms')})
+        return out
     for name, call in (('silhouette', lambda: renderer.render_silhouettes(vertices, faces)),
                        ('texture', lambda: renderer.render(vertices, faces, textures))):
         tf, tb = [], []
@@ -626,7 +634,8 @@ def main():
             e2e['reference_protocol'] = {
                 'what': 'misc/measure_time.py:12-18, 44-90 through Renderer() with the reference defaults (anti_aliasing on: raster 512 '
                         'for image_size 256); forward and backward of sum(images) timed separately, ms, mean of 23 azimuths',
-                'rows': [measure_time_protocol(dev, 1), measure_time_protocol(dev, B)]}
+                'rows': [measure_time_protocol(dev, 1), measure_time_protocol(dev, B),
+                         measure_time_protocol(dev, 1, caller_thread=True)]}
             e2e['face_light'] = face_light_row(dev, B)
         cpu = None
         if args.cpu_sample_views > 0 and world == 1:

@@ -66,6 +66,9 @@ def run():
     parser.add_argument('--steps', type=int, default=1000)
     args = parser.parse_args()
     device = torch.device('cuda', args.gpu)
+    # a one-image optimisation step is bound by the host: autograd's hand-over of the backward to its device thread is the
+    # largest single item of it (0.55 -> 0.35 ms per step of example 2 on an MI355X box), so the backward stays on this thread
+    torch.autograd.set_multithreading_enabled(False)
 
     if args.make_reference_image:
         make_reference_image(args.filename_ref, args.filename_obj, device)

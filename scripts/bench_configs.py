@@ -63,6 +63,11 @@ def run(name, faces, textures, S, modes, eps, iters=10, graph=False):
            'modes': ''.join(c for c, m in zip('rad', modes) if m), 'coverage': round(cov, 4),
            'ms_fwd_bwd': round(ms, 4), 'ms_fwd': round(ms_f, 4), 'mpixel_s': round(B * S * S / ms / 1e3, 1)}
     if graph:  # host-bound sizes only
+        # torch's autograd engine hands the backward of CUDA tensors to a device thread: ~100 us of wake-up and GIL traffic per
+        # step (scripts/host_profile.py: 283 -> 153 us of host time); a loop that is bound by the host can switch that off
+        with torch.autograd.set_multithreading_enabled(False):
+            ms_st = timeit(step, iters)
+        row.update(ms_fwd_bwd_single_threaded_autograd=round(ms_st, 4), mpixel_s_single_threaded_autograd=round(B * S * S / ms_st / 1e3, 1))
         # the same step captured as a whole by the caller (neural_renderer_amd.graph.capture): no copies.  (First: a whole-step
         # capture AFTER the operator's replay mode has run in the same process crashes on ROCm 7.2 / torch 2.10.)
         replay = nr.graph.capture(step, dev)
@@ -114,6 +119,24 @@ def main():
         ms = (time.perf_counter() - t0) / 300 * 1e3
         print(json.dumps({'config': 'C3 example2 vertex optimisation, 300 Adam steps', 'B': 1, 'S': 512, 'ms_per_step': round(ms, 4),
                           'loss_first': round(float(losses[0]), 2), 'loss_last': round(float(losses[-1]), 2)}), flush=True)
+        # the same eager loop with autograd's device thread switched off (see run())
+        model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.autograd.set_multithreading_enabled(False):
+            for _ in range(300):
+                opt.zero_grad()
+                loss = model()
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach())
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 300 * 1e3
+        print(json.dumps({'config': 'C3 example2, eager with torch.autograd.set_multithreading_enabled(False)', 'B': 1, 'S': 512,
+                          'ms_per_step': round(ms, 4), 'loss_first': round(float(losses[0]), 2),
+                          'loss_last': round(float(losses[-1]), 2)}), flush=True)
         # the same loop with the whole step (render, loss, backward, Adam) captured once in a HIP graph
         model = example2.Model(os.path.join(data, 'teapot.obj'), os.path.join(data, 'example2_ref.png')).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)

@@ -42,7 +42,7 @@ def test_bench_json_line():
     assert any('NR_FLAG_EXACT_GRADIENT' in x['row'] for x in d['extra_rows'])
     assert d['renderer_end_to_end']['frontend'] == 'fused'
     rows = d['renderer_end_to_end']['reference_protocol']['rows']  # misc/measure_time.py protocol, Renderer defaults (AA on)
-    assert [x['batch_size'] for x in rows] == [1, 4] and all(x['anti_aliasing'] and x['raster'] == 512 for x in rows)
+    assert [x['batch_size'] for x in rows] == [1, 4, 1] and all(x['anti_aliasing'] and x['raster'] == 512 for x in rows)
     assert all(x[k] > 0 for x in rows for k in ('silhouette_forward_ms', 'silhouette_backward_ms', 'texture_forward_ms',
                                                  'texture_backward_ms'))
     fl = d['renderer_end_to_end']['face_light']  # per-face light colours vs lit, duplicated textures
