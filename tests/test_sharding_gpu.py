@@ -83,3 +83,26 @@ def test_two_shards_equal_one_batch_through_the_operator():
     z_ref = nrd.broadcast_reference_faces(torch.tensor(faces[:4], device='cuda'))
     parts = [run(slice(0, 4), z_ref), run(slice(4, 8), z_ref)]
     _same(parts, full, ('rgb', 'grad_faces', 'grad_textures'))
+
+
+def test_two_shards_equal_one_batch_with_face_light():
+    """The same with per-face light colours (nr_face_light): the colours and the original cubes shard with the batch."""
+    import neural_renderer_amd as nr
+    faces, textures, g_rgb, g_alpha = _scene()
+    rng = np.random.default_rng(77)
+    light = rng.uniform(0.3, 1.4, faces.shape[:2] + (3,)).astype(np.float32)
+
+    def run(sl, z_ref):
+        ft = torch.tensor(faces[sl], device='cuda', requires_grad=True)
+        tt = torch.tensor(textures[sl], device='cuda', requires_grad=True)
+        lt = torch.tensor(light[sl], device='cuda', requires_grad=True)
+        fn = nr.Rasterize(S, 0.1, 100, 1e-3, (0.1, 0.2, 0.3), True, True, False)
+        fn.faces_z_ref = z_ref
+        rgb, alpha, _ = fn(ft, tt, lt)
+        torch.autograd.backward([rgb, alpha], [torch.tensor(g_rgb[sl], device='cuda'), torch.tensor(g_alpha[sl], device='cuda')])
+        return rgb.detach().cpu().numpy(), ft.grad.cpu().numpy(), tt.grad.cpu().numpy(), lt.grad.cpu().numpy()
+
+    full = run(slice(0, 8), None)
+    z_ref = torch.tensor(faces[0], device='cuda')
+    parts = [run(slice(0, 4), z_ref), run(slice(4, 8), z_ref)]
+    _same(parts, full, ('rgb', 'grad_faces', 'grad_textures', 'grad_light'))
