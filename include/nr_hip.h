@@ -220,8 +220,8 @@ int nr_backward_rasterize(const float *faces, const float *faces_z_ref, const in
  * Every other output is bit-identical (the geometry does not depend on textures).
  *   light [B, F, 3]; texture_faces = Nf with F == Nf or F == 2 * Nf; textures / grad_textures [B, Nf, ts,ts,ts, 3].
  *   backward: grad_textures is the gradient w.r.t. the ORIGINAL cubes (light factor included); grad_light [B, F, 3]
- *   (optional) the gradient of the colours, for nr_frontend_backward_light.  Needs texture_size <= 13 (NR_E_SIZE above:
- *   callers keep the lit-texture path for huge cubes).  lit == NULL: exactly nr_forward_rasterize / nr_backward_rasterize.
+ *   (optional) the gradient of the colours, for nr_frontend_backward_light.  lit == NULL: exactly nr_forward_rasterize /
+ *   nr_backward_rasterize.
  */
 typedef struct nr_face_light {
     const float *light;     /* DEVICE [B, F, 3] */

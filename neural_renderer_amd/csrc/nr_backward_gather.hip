@@ -629,6 +629,48 @@ __global__ __launch_bounds__(256) void k_backward_textures_atomic(
 }
 
 
+// the same with per-face light colours (FaceLight): the taps are flattened in the original cube's layout, the contribution
+// carries the face's colour, and the colour's own gradient -- g_c times the pixel's unlit sample -- goes to grad_light
+__global__ __launch_bounds__(256) void k_backward_textures_atomic_lit(
+    const int32_t *__restrict__ face_index_map, const float *__restrict__ faces, const float *__restrict__ zbase,
+    const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
+    float *__restrict__ grad_textures, int F, int S, int ts, double eps, int fix_batch_z, size_t n_pixels, FaceLight lit)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const int fi = face_index_map[i];
+    if (fi < 0) return;
+    const int b = (int)(i / ((size_t)S * S));
+    const bool flip = fi >= lit.tex_faces;
+    const size_t cube = ((size_t)b * lit.tex_faces + (flip ? fi - lit.tex_faces : fi)) * ts * ts * ts * 3;
+    Taps t;
+    const float *face = (fix_batch_z ? faces + (size_t)b * F * 9 : zbase) + (size_t)fi * 9;
+    const float w[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
+    const float fz[3] = {face[2], face[5], face[8]};
+    compute_taps(fz, w, depth_map[i], ts, eps, t, flip);
+    const float g[3] = {g_rgb[3 * i], g_rgb[3 * i + 1], g_rgb[3 * i + 2]};
+    const float *lc = lit.light + ((size_t)b * F + fi) * 3;
+    const float l3[3] = {lc[0], lc[1], lc[2]};
+    float *gt = grad_textures + cube;
+    const float *tex = lit.textures ? lit.textures + cube : nullptr;
+    float sample[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        if (t.isc[pn] >= ts * ts * ts) continue;  // outside the cube: weight 0 (compute_taps)
+        float *p = gt + t.isc[pn] * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            atomicAdd(p + c, (t.w[pn] * g[c]) * l3[c]);
+            if (tex) sample[c] += t.w[pn] * tex[t.isc[pn] * 3 + c];
+        }
+    }
+    if (lit.grad_light) {
+        float *gl = lit.grad_light + ((size_t)b * F + fi) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) atomicAdd(gl + c, g[c] * sample[c]);
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // B3: one face per group of 16 lanes; 9 register accumulators; a single lane adds the totals onto what K6
 // stored.  The per-face inverse matrix is recomputed from the vertices with the forward's arithmetic
@@ -742,7 +784,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     if (!sampling_weight_map && (!weight_map || !depth_map)) return NR_E_NULL;
     if (int e = check_sizes(B, F, S)) return e;
     if (ts < 2 || ts > 1024) return NR_E_SIZE;
-    if (lit.light && (ts > 13 || sampling_weight_map)) return NR_E_SIZE;  // the per-face gathers only
+    if (lit.light && sampling_weight_map) return NR_E_MODE;  // (the taps are recomputed in the original cube's layout)
     const int fix = (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0;
     const float *zbase = faces_z_ref ? faces_z_ref : faces;  // :389 reads batch 0 of the GLOBAL batch (see nr_hip.h)
     const int n = B * F;
@@ -815,7 +857,12 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     }
     };
     if (lit.light) launch(std::true_type()); else launch(std::false_type());
-    if (ts > 13) {
+    if (ts > 13 && lit.light) {
+        // (grad_textures and grad_light were zero-filled above)
+        const size_t np = (size_t)B * S * S;
+        hipLaunchKernelGGL(k_backward_textures_atomic_lit, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, face_index_map,
+                           faces, zbase, weight_map, depth_map, grad_rgb_map, grad_textures, F, S, ts, eps, fix, np, lit);
+    } else if (ts > 13) {
         // huge cubes: the reference's per-pixel scatter with hardware atomics
         const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != 0) return e;

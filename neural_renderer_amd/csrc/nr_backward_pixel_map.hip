@@ -2318,7 +2318,6 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     if (int e = check_sizes(B, F, S)) return e;
     FaceLight fl;  // per-face light colours: only the texture gather sees them (the geometry gradients do not)
     if (int e = face_light_args(grad_rgb_map && grad_textures ? lit : nullptr, F, true, fl)) return e;
-    if (fl.light && ts > 13) return NR_E_SIZE;
     hipStream_t st = (hipStream_t)stream;
     const bool use_rgb = grad_rgb_map != nullptr, use_alpha = grad_alpha_map != nullptr, use_depth = grad_depth_map != nullptr;
     const int *vis_list = nullptr, *vis_count = nullptr;

@@ -138,8 +138,6 @@ class _RasterizeFunction(torch.autograd.Function):
                                      % (light.dtype, tuple(light.shape)))
                 if textures.dim() == 6 and textures.shape[1] * 2 == F:
                     Nf = F // 2  # fill_back: face Nf + f is the reversed copy of face f
-                if textures.dim() == 6 and textures.shape[2] > 13:
-                    raise ValueError('face_light needs texture_size <= 13')
                 light_c = light.detach().contiguous()
             if (textures.dtype != torch.float32 or textures.dim() != 6 or textures.shape[0] != B or
                     textures.shape[1] != Nf or textures.shape[2] < 2 or textures.shape[2] != textures.shape[3] or

@@ -63,7 +63,7 @@ class Renderer(object):
         # order of the light product (measured 3e-7 of the largest colour, tests/test_face_light_gpu.py), a fraction of the
         # memory traffic on textured meshes (scripts/face_light_timing.py: config 4's shape 2.20 -> 1.12 ms per render +
         # backward at texture_size 4, 16.3 -> 1.85 ms at 8; neutral at 2).  True / False, or None = when it pays
-        # (texture_size >= 3).  Needs the fused front-end, texture_size <= 13 and no graph replay; otherwise, and with False,
+        # (texture_size >= 3).  Needs the fused front-end and no graph replay; otherwise, and with False,
         # the lit-texture path runs.  Default: NR_FACE_LIGHT (auto).
         self.face_light = FACE_LIGHT
 
@@ -117,7 +117,7 @@ class Renderer(object):
         if self.face_light is False or not (torch.is_tensor(textures) and textures.dim() == 6):
             return False
         ts = textures.shape[2]
-        if ts > 13 or (self.face_light is None and ts < 3):
+        if self.face_light is None and ts < 3:
             return False
         # (the package attribute `rasterize` is the function; the module of that name holds the switch)
         replay = self.graph_replay if self.graph_replay is not None else sys.modules[rasterize.__module__].GRAPH_REPLAY

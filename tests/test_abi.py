@@ -96,10 +96,7 @@ def test_argument_errors_do_not_need_a_gpu(lib_path):
     bad = _lib.FaceLight(1, 3, None, None)
     assert lib.nr_forward_rasterize_lit(bad, 1, None, 1, 1, 1, 1, 1, None, None, 1, 0, 1, 4, 8, 2, 0.1, 100.0, 1e-3, 0, None, 0,
                                         None) == -2
-    # ... the backward needs texture_size <= 13 and the cubes when the colours' gradient is asked for
-    ok = _lib.FaceLight(1, 4, None, None)
-    assert lib.nr_backward_rasterize_lit(ok, 1, None, 1, 1, 1, 1, None, 1, None, None, 1, 1, 1, 4, 8, 14, 1e-3, 0, None, None, 0,
-                                         None) == -2
+    # ... the backward needs the cubes when the colours' gradient is asked for
     no_cubes = _lib.FaceLight(1, 4, None, 1)
     assert lib.nr_backward_rasterize_lit(no_cubes, 1, None, 1, 1, 1, 1, None, 1, None, None, 1, 1, 1, 4, 8, 2, 1e-3, 0, None, None,
                                          0, None) == -1
