@@ -775,7 +775,8 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
                               const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F,
                               int S, int ts, double eps, int flags, const int *vis_list, const int *vis_count,
                               hipStream_t st, const float *g_depth, float *grad_faces, int *depth_done,
-                              const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit)
+                              const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit,
+                              bool prefilled)
 {
     if (depth_done) *depth_done = 0;
     if (k6_finalized) *k6_finalized = 0;
@@ -805,7 +806,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
         int e = fill_bytes(grad_textures, 0, (size_t)B * lit.tex_faces * n_tex * sizeof(float), st);
         if (e == 0 && lit.grad_light) e = fill_bytes(lit.grad_light, 0, (size_t)n * 3 * sizeof(float), st);
         if (e != 0) return e;
-    } else if (vis_list) {
+    } else if (vis_list && !prefilled) {
         // only visible faces are visited: everything else is zero
         const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != 0) return e;

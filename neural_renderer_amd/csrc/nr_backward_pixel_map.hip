@@ -1761,7 +1761,7 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
     double *__restrict__ scratch, const int *__restrict__ band_lines, const int *__restrict__ band_start,
     const int *__restrict__ lines_ok, const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int SP,
-    float eps_f, int B, int win_lines, int win_scan, int qcap)
+    float eps_f, int B, int win_lines, int win_scan, int qcap, uint4 *__restrict__ zero16, size_t n_zero16)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -1769,6 +1769,13 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     const unsigned total_wg = n_bands * 2u * (unsigned)B;
     const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_band)
     if (logical >= total_wg) return;
+    if (n_zero16) {
+        // The fused backward's zero fill of grad_textures (the K7 gather behind this kernel stores only the listed faces'
+        // cubes) rides along: every workgroup clears one slice before it looks at its band -- half of them have nothing
+        // else to do -- instead of a launch of its own between this kernel and the gather.
+        const size_t per = (n_zero16 + total_wg - 1) / total_wg, z_lo = (size_t)logical * per, z_hi = min(n_zero16, z_lo + per);
+        for (size_t k = z_lo + tid; k < z_hi; k += BAND_THREADS) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
@@ -2114,7 +2121,8 @@ template <bool RGB, bool ALPHA>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
                 const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
-                int B, int F, int S, int W, size_t lds, double eps, int win_lines, int win_scan, int qcap, hipStream_t st)
+                int B, int F, int S, int W, size_t lds, double eps, int win_lines, int win_scan, int qcap, hipStream_t st,
+                void *zero_ptr, size_t zero_bytes)
 {
     static LdsLimit limit;
     auto kern = k_bpm_fast<RGB, ALPHA>;
@@ -2122,7 +2130,7 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
-                       (float)eps, B, win_lines, win_scan, qcap);
+                       (float)eps, B, win_lines, win_scan, qcap, (uint4 *)zero_ptr, zero_bytes / 16);
     return 0;
 }
 
@@ -2141,8 +2149,10 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                                float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
                                int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
                                hipStream_t st, const int **vis_list_out, const int **vis_count_out,
-                               const double **defer_scratch, const int **defer_slot_of)
+                               const double **defer_scratch, const int **defer_slot_of, void *zero_ptr, size_t zero_bytes,
+                               int *zeroed)
 {
+    if (zeroed) *zeroed = 0;
     if (vis_list_out) *vis_list_out = nullptr;
     if (vis_count_out) *vis_count_out = nullptr;
     if (defer_scratch) *defer_scratch = nullptr;
@@ -2258,9 +2268,15 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     } else {
 #define NR_FAST(R, A)                                                                                                   \
     launch_fast<R, A>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch, \
-                      band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, win_lines, win, qcap, st)
+                      band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, win_lines, win, qcap, st,     \
+                      zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0)
+        // (a fill that rides in the band kernel: 16-byte words, and small enough that the band workgroups -- three per CU --
+        // are not the slower way to write it: config 5's 4 GB go at 7 TB/s through a fill launch)
+        const bool zero_ok = zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
+                             zero_bytes <= ((size_t)256 << 20);
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
+        if (rc == 0 && zero_ok && zeroed) *zeroed = 1;
     }
     if (rc) return rc;
     if (defer) {  // the caller finishes the listed faces (the fused gather, in the same launch as K7 / K8)
@@ -2326,12 +2342,16 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     const bool fold = use_rgb && grad_textures && ts >= 2 && ts <= 13;
     const double *k6_scratch = nullptr;
     const int *k6_slot_of = nullptr;
+    int tex_zeroed = 0;
     if (use_rgb || use_alpha) {
         if (int rc = run_backward_pixel_map(faces, face_index_map, use_rgb ? rgb_map : nullptr,
                                             use_alpha ? alpha_map : nullptr, grad_rgb_map, grad_alpha_map, grad_faces,
                                             B, F, S, eps, use_rgb, use_alpha, flags, visible_faces, workspace,
                                             workspace_bytes, st, &vis_list, &vis_count, fold ? &k6_scratch : nullptr,
-                                            fold ? &k6_slot_of : nullptr))
+                                            fold ? &k6_slot_of : nullptr,
+                                            // the zero fill of grad_textures inside the band kernel (plain path only)
+                                            fold && !fl.light ? grad_textures : nullptr,
+                                            (size_t)B * F * ts * ts * ts * 3 * sizeof(float), &tex_zeroed))
             return rc;
     } else {
         const int e = fill_bytes(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
@@ -2356,7 +2376,7 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
         if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, faces_z_ref, weight_map, depth_map,
                                            grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
                                            use_depth ? grad_depth_map : nullptr, grad_faces, &depth_done, k6_scratch,
-                                           k6_slot_of, &finalized, fl))
+                                           k6_slot_of, &finalized, fl, tex_zeroed != 0))
             return rc;
         if (k6_scratch && !finalized) run_bpm_finalize(k6_scratch, k6_slot_of, grad_faces, B, F, st);  // (not expected)
     }

@@ -289,7 +289,10 @@ int run_backward_pixel_map(const float *faces, const int32_t *face_index_map, co
                            float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
                            int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
                            hipStream_t st, const int **vis_list_out, const int **vis_count_out,
-                           const double **defer_scratch = nullptr, const int **defer_slot_of = nullptr);
+                           const double **defer_scratch = nullptr, const int **defer_slot_of = nullptr,
+                           void *zero_ptr = nullptr, size_t zero_bytes = 0, int *zeroed = nullptr);
+// zero_ptr / zero_bytes: a buffer the caller wants zero-filled before its next kernel (the fused backward's grad_textures);
+// *zeroed = 1 when the band kernel did it on the side (default kernel, 16-byte aligned, <= 256 MB), else the caller fills
 // defer_scratch / defer_slot_of (both or none): the caller will finish K6 itself for the LISTED faces -- rounding the double
 // sums of their list positions into grad_faces (run_backward_textures does, or run_bpm_finalize for all faces) -- so
 // k_bpm_finalize is not launched and the compaction kernel stores the zeros of the unlisted faces; NULLs come back when
@@ -301,7 +304,8 @@ int run_backward_textures(const int32_t *face_index_map, const float *sampling_w
                           const float *depth_map, const float *grad_rgb_map, float *grad_textures, int B, int F, int S,
                           int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st,
                           const float *g_depth_fused, float *grad_faces_fused, int *depth_done,
-                          const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit = FaceLight());
+                          const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit = FaceLight(),
+                          bool prefilled = false);  // prefilled: grad_textures is already zero (no fill launch)
 // lit.light given: grad_textures is [B, lit.tex_faces, ts^3, 3] (zero-filled here; a face stores only when it owns a
 // pixel -- of a face and its reversed copy at most one does), lit.grad_light receives [B, F, 3]
 int face_light_args(const nr_face_light *lit, int F, bool backward, FaceLight &out);  // nr_forward.hip
