@@ -1777,6 +1777,9 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
         for (size_t k = z_lo + tid; k < z_hi; k += BAND_THREADS) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
     }
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
+#ifdef NR_K6_ONLY_AXIS  // development build: the workgroups of one sweep axis only (how much slower is the column pass?)
+    if (axis != NR_K6_ONLY_AXIS) return;
+#endif
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
     const size_t bidx = ((size_t)b * 2 + axis) * n_bands + band;
