@@ -455,8 +455,10 @@ def profile_records():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # (defaults: ~50 ms of device time.  The first ~30 ms after an idle period run at ramping clocks -- 20 steps behind 3
+    # warm-up steps measured 0.383-0.395 ms per step, 100 behind 30 0.366-0.372 on the same box)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--batch', type=int, default=64, help='views per GPU')
     ap.add_argument('--image-size', type=int, default=256, help='raster size S (anti-aliasing off)')
     ap.add_argument('--texture-size', type=int, default=2)
