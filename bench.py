@@ -459,6 +459,8 @@ def main():
     # warm-up steps measured 0.383-0.395 ms per step, 100 behind 30 0.366-0.372 on the same box)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--prewarm-ms', type=float, default=250.0, help='untimed milliseconds of the same step in front of the warm-up '
+                    'steps (the device reaches its steady clocks; 0 = none)')
     ap.add_argument('--batch', type=int, default=64, help='views per GPU')
     ap.add_argument('--image-size', type=int, default=256, help='raster size S (anti-aliasing off)')
     ap.add_argument('--texture-size', type=int, default=2)
@@ -529,6 +531,20 @@ def main():
     # device synchronize (wall clock, and HIP events on the launch stream as a cross-check), then a second barrier closes the
     # bracket and the MAX over ranks is reduced.  The closing barrier is not inside the timed region: on RCCL it costs tens to
     # hundreds of microseconds, which would be charged to every N > 1 point of an 8.8 ms measurement.
+    # Clocks first: a device that idled through the set-up above runs its first few hundred ms of work at ramping clocks (20
+    # steps behind 3 warm-up steps: 0.384 ms per step; behind 80 ms of the same steps 0.374, behind 300 ms 0.369; 100 steps
+    # behind 30: 0.367).  W warm-up steps of 0.4 ms do not get there, so the same step runs untimed for --prewarm-ms before
+    # the W warm-up steps and the K timed ones (reported in `timing.prewarm`).
+    prewarm_steps, t_pre = 0, time.perf_counter()
+    if args.prewarm_ms > 0:  # (one-time costs of the very first calls -- allocations, kernel attributes -- are not device work)
+        run()
+        torch.cuda.synchronize(dev)
+        t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize(dev)
+        prewarm_steps += 10
     for _ in range(args.warmup):
         run()
     barrier()
@@ -663,6 +679,8 @@ def main():
             'timing': {'protocol': 'barrier + synchronize | K steps timed per rank up to its own synchronize (wall clock) | barrier; '
                                    'MAX over ranks; no collective inside the timed region' + (' except the requested all_gather' if gather else ''),
                        'rank0_hip_event_ms_per_step': event_ms_per_step,
+                       'prewarm': {'ms': args.prewarm_ms, 'steps': prewarm_steps,
+                                   'why': 'steady clocks before the W warm-up and K timed steps (untimed)'},
                        'backend': (dist.get_backend() if dist is not None else None)},
         }
         print(json.dumps(line))
