@@ -535,14 +535,16 @@ def main():
     # steps behind 3 warm-up steps: 0.384 ms per step; behind 80 ms of the same steps 0.374, behind 300 ms 0.369; 100 steps
     # behind 30: 0.367).  W warm-up steps of 0.4 ms do not get there, so the same step runs untimed for --prewarm-ms before
     # the W warm-up steps and the K timed ones (reported in `timing.prewarm`).
+    # (Rank-local steps only: the loop is bounded by time, so the ranks run different numbers of them -- no collective inside.)
+    pre = local_step if gather else run
     prewarm_steps, t_pre = 0, time.perf_counter()
     if args.prewarm_ms > 0:  # (one-time costs of the very first calls -- allocations, kernel attributes -- are not device work)
-        run()
+        pre()
         torch.cuda.synchronize(dev)
         t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
         for _ in range(10):
-            run()
+            pre()
         torch.cuda.synchronize(dev)
         prewarm_steps += 10
     for _ in range(args.warmup):
