@@ -71,8 +71,9 @@ extern "C" {
                                          instead of batch 0 (the reference reads batch 0: rasterize.py:389) */
 #define NR_FLAG_EXACT_GRADIENT 2      /* K6: every per-pixel term with the reference's arithmetic (IEEE division, the double
                                          `dist +- eps`), <= 2e-6 against the exactly summed reference terms, ~1.5x the K6 time.
-                                         Default (flag clear): float terms through v_rcp_f32; measured <= 4.2e-5 against the
-                                         same sums over the whole test suite (full-size configs included), bound 1e-4. */
+                                         Default (flag clear): float terms through fused multiply-adds and v_rcp_f32; measured
+                                         <= 4.7e-5 against the same sums over the whole test suite (full-size configs included),
+                                         bound 1e-4. */
 #define NR_FLAG_K6_GLOBAL 4           /* K6: force the global-memory kernel that otherwise only serves rasters whose band
                                          does not fit in LDS (a testing aid) */
 #define NR_FLAG_K6_SCAN 8             /* K6: let every band workgroup derive its lines from the image's visible-face list

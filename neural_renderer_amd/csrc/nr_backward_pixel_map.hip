@@ -1599,6 +1599,25 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
         const float cross = c.x, c0k = c.y, c1k = c.z;
         const int fnr = __float_as_int(c.w);
         float f0 = 0.0f, f1 = 0.0f;
+#ifndef NR_K6_UNFUSED
+        // (The default kernel's terms are approximate by contract -- v_rcp_f32, DESIGN 3 -- so the dot product and the two
+        // `c * t + eps` of a visit are fused multiply-adds here: 19 -> 13 VALU instructions per uncovered pixel, 23 -> 17 per
+        // covered one.  The exact kernel keeps the reference's operations one by one.)
+        auto bg_diff = [&](const float4 &g4, float ga) {
+            if (!RGB) return dba * ga;
+            float d = ALPHA ? __builtin_fmaf(dbr, g4.y, dba * g4.x) : dbr * g4.y;
+            d = __builtin_fmaf(dbg, g4.z, d);
+            d = __builtin_fmaf(dbb, g4.w, d);
+            return d;
+        };
+        auto own_diff = [&](const float4 &c4, float ca, const float4 &g4, float ga) {  // c4 / ca: the pixel's colour
+            if (!RGB) return (ca - ra) * ga;
+            float d = ALPHA ? __builtin_fmaf(c4.y - rr, g4.y, (c4.x - ra) * g4.x) : (c4.y - rr) * g4.y;
+            d = __builtin_fmaf(c4.z - rg, g4.z, d);
+            d = __builtin_fmaf(c4.w - rb, g4.w, d);
+            return d;
+        };
+#else
         auto bg_diff = [&](const float4 &g4, float ga) {
             if (!RGB) return dba * ga;
             float d = ALPHA ? dba * g4.x + dbr * g4.y : dbr * g4.y;
@@ -1613,6 +1632,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             d += (c4.w - rb) * g4.w;
             return d;
         };
+#endif
         NR_WPH(11);
 #ifdef NR_K6_NO_LOOPS  // development build: everything of the sweeps but the pixel loops
         f0 = ra + cross; f1 = dba + c0k + c1k + (float)s_from + (float)s_to + (float)fnr;
@@ -1629,13 +1649,23 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             // independent instruction chains that the scheduler interleaves -- a wave spends its time here waiting for its
             // own dependent instructions and LDS reads, not for issue slots.  y is never 0 (x and its eps have one sign), so
             // the reciprocal is finite wherever the contribution is taken (:648 / :653) and 0 * it adds nothing.
-            float d1fb = d1f0;  // (re-declared opaque per batch below: keeps the compiler from computing all FSEG values of t ahead
-                                // of the loop, which costs a register each and pushed the kernel into spilling)
+#ifndef NR_K6_UNFUSED
+            float d1fb = t_first;  // t of the piece's first pixel; pixel k has t_first + k (both of one sign: no cancellation)
+#else
+            float d1fb = d1f0;
+#endif
+            // (d1fb is re-declared opaque per batch below: keeps the compiler from computing all FSEG values of t ahead of the
+            // loop, which costs a register each and pushed the kernel into spilling)
             auto visit = [&](float diff, int k) {
                 const float dm = (diff <= 0.0f) ? 0.0f : diff;
+#ifndef NR_K6_UNFUSED
+                const float t = d1fb + (float)k;                              // (d1fb: the piece's first t, see below)
+                const float y0 = __builtin_fmaf(c0k, t, e0), y1 = __builtin_fmaf(c1k, t, e1);  // :649-650 / :654-655
+#else
                 const float t = (d1fb + (float)k) - cross;
                 const float x0 = c0k * t, x1 = c1k * t;                       // :649 / :654 (2 / S folded into c)
                 const float y0 = x0 + e0, y1 = x1 + e1;                       // :650 / :655
+#endif
                 f0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), f0);      // :651
                 f1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), f1);      // :656
             };
