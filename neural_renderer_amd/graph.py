@@ -49,7 +49,7 @@ def backward_on_caller_thread(flag=True):
     """The cheaper remedy for a host-bound loop.  torch's autograd engine hands the backward of CUDA tensors to a device
     thread; waking it and passing the GIL back and forth costs ~100 us per step (scripts/host_profile.py: 283 -> 153 us of
     host time per Rasterize forward + backward; BASELINE config 2 through the plain API 0.205 -> 0.158 ms, example 2
-    0.55 -> 0.35 ms per step -- `profiles/r03i_configs.jsonl`).  This is `torch.autograd.set_multithreading_enabled(not
+    0.55 -> 0.35 ms per step -- `profiles/r03l_configs.jsonl`).  This is `torch.autograd.set_multithreading_enabled(not
     flag)`: call it once, or use it as a context manager around the loop.  Process-wide torch behaviour, so the library never
     switches it on its own."""
     return torch.autograd.set_multithreading_enabled(not flag)

@@ -13,8 +13,8 @@ several stages (k_resolve: nr_forward_face_index_map and the fused nr_forward_ra
 nr_backward_pixel_map and the fused nr_backward_rasterize) is therefore split by dispatch order: its occurrences are
 dealt to the stages that launch it, in call order, in equal shares.  If the occurrence count does not fit that protocol
 the kernel's overall average is used for each of its stages and the record says so (`attribution: "name"`).
-The library's own fills are `nr::k_fill_bytes` launches (z-buffer: both forward stage calls; grad_textures: the fused backward)
-and are attributed like every other kernel.
+The library's own fills are `nr::k_fill_bytes` launches (the z-buffer in both forward stage calls) and are attributed like every
+other kernel; the fused backward's zero fill of grad_textures is part of k_bpm_fast (30 MB of its writes there).
 """
 import json
 import sqlite3
@@ -30,7 +30,7 @@ KERNEL_STAGES = [
     ('k_face_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
     ('k_large_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
     ('k_resolve', ['forward_face_index_map', 'fused_forward_rasterize']),
-    ('k_fill_bytes', ['forward_face_index_map', 'fused_forward_rasterize', 'fused_backward_rasterize']),
+    ('k_fill_bytes', ['forward_face_index_map', 'fused_forward_rasterize']),  # (the fused backward's fill rides in k_bpm_fast)
     ('k_shade', ['forward_texture_sampling']),
 ] + [(k, ['backward_pixel_map', 'fused_backward_rasterize']) for k in K6] + [
     # (template argument lists are matched as prefixes: the gathers carry a third argument, the per-face light mode)
