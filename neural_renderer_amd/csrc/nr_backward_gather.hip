@@ -803,7 +803,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     if (fold && k6_finalized) *k6_finalized = 1;
     if (lit.light) {
         // original cubes: a face and its reversed copy share one, so only the one that owns a pixel stores; the rest is zero
-        int e = fill_bytes(grad_textures, 0, (size_t)B * lit.tex_faces * n_tex * sizeof(float), st);
+        int e = prefilled ? 0 : fill_bytes(grad_textures, 0, (size_t)B * lit.tex_faces * n_tex * sizeof(float), st);
         if (e == 0 && lit.grad_light) e = fill_bytes(lit.grad_light, 0, (size_t)n * 3 * sizeof(float), st);
         if (e != 0) return e;
     } else if (vis_list && !prefilled) {

@@ -2303,10 +2303,15 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     launch_fast<R, A>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch, \
                       band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, win_lines, win, qcap, st,     \
                       zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0)
-        // (a fill that rides in the band kernel: 16-byte words, and small enough that the band workgroups -- three per CU --
-        // are not the slower way to write it: config 5's 4 GB go at 7 TB/s through a fill launch)
+        // (a fill that rides in the band kernel: 16-byte words, and a slice per workgroup that is small next to the
+        // workgroup's own work -- NR_K6_FOLD_KB per band workgroup: 4 KB at the headline size, 61 KB on config 4; config 5's
+        // 4 GB would be 2 MB for each of 2048 workgroups and go at 7 TB/s through a fill launch instead)
+#ifndef NR_K6_FOLD_KB
+#define NR_K6_FOLD_KB 128
+#endif
+        const size_t band_wgs = (size_t)((S + W - 1) / W) * 2 * (size_t)B;
         const bool zero_ok = zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
-                             zero_bytes <= ((size_t)256 << 20);
+                             zero_bytes <= band_wgs * ((size_t)NR_K6_FOLD_KB << 10);
         rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
 #undef NR_FAST
         if (rc == 0 && zero_ok && zeroed) *zeroed = 1;
@@ -2382,9 +2387,11 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
                                             B, F, S, eps, use_rgb, use_alpha, flags, visible_faces, workspace,
                                             workspace_bytes, st, &vis_list, &vis_count, fold ? &k6_scratch : nullptr,
                                             fold ? &k6_slot_of : nullptr,
-                                            // the zero fill of grad_textures inside the band kernel (plain path only)
-                                            fold && !fl.light ? grad_textures : nullptr,
-                                            (size_t)B * F * ts * ts * ts * 3 * sizeof(float), &tex_zeroed))
+                                            // the zero fill of grad_textures inside the band kernel (with per-face light
+                                            // colours: the cubes of the original faces)
+                                            fold ? grad_textures : nullptr,
+                                            (size_t)B * (fl.light ? fl.tex_faces : F) * ts * ts * ts * 3 * sizeof(float),
+                                            &tex_zeroed))
             return rc;
     } else {
         const int e = fill_bytes(grad_faces, 0, (size_t)B * F * 9 * sizeof(float), st);  // :851
