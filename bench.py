@@ -587,7 +587,7 @@ def main():
         traffic_rec = prof.get(dominant, {})
         step_bytes = whole_step_bytes(B, F, S, ts)
         roofline = {
-            'bound': 'hbm', 'kernel': ('k_bpm_band' if args.exact and dominant == 'backward_pixel_map' else STAGE_KERNEL.get(dominant, dominant)),
+            'bound': 'hbm', 'kernel': STAGE_KERNEL.get(dominant, dominant) + (' (exact mode)' if args.exact and dominant == 'backward_pixel_map' else ''),
             'stage': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': None,
             'traffic_from_profiles': {

@@ -1,9 +1,11 @@
 // nr_backward_pixel_map.hip -- K6, the approximate gradient of rgb / alpha w.r.t. vertex x, y
 // (reference Rasterize.backward_pixel_map_gpu, rasterize.py:517-748) + its C-ABI entry point.
 #include "nr_device.h"
+#include "nr_k6_tune.h"
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 
 using namespace nr;
 
@@ -11,7 +13,7 @@ namespace {
 
 // --------------------------------------------------------------------------------------------------
 // B1: backward_pixel_map (rasterize.py:517-748), global-memory form.  This kernel is the FALLBACK (raster sizes whose
-// bands do not fit in LDS, or NR_K6_GLOBAL=1); the default path is the band pipeline further down.
+// bands do not fit in LDS, or NR_FLAG_K6_GLOBAL); the default path is the band pipeline further down.
 //
 // Work decomposition.  The reference runs ONE thread per face through 3 edges x 2 axes x every integer
 // column/row d0 crossed by the edge x two pixel sweeps along d1 (an "in" sweep from the edge to the
@@ -234,48 +236,39 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 //          face's six double sums (indexed by list position: no fill launch), records face -> list position and counts the
 //          lines of every (axis, band): a band workgroup whose count is zero leaves at once (more than half of the bands
 //          of a teapot view: the object covers 12 % of the image).
-//   k_line_setup (default kernel only)   every line's record (crossing point, in / out pixels, sweep ranges, the two
-//          distance coefficients: rasterize.py:573-579, :606-609, :665-672), written band by band into one buffer.
-//   k_bpm_fast (default) / k_bpm_band (NR_FLAG_EXACT_GRADIENT)   one workgroup per (image, axis, band of W consecutive
-//          lines d0); workgroup ids are mapped so that all bands of an image run on one XCD (xcd_block).  It
+//   k_line_setup   every line's record (crossing point, in / out pixels, sweep ranges, the two distance coefficients:
+//          rasterize.py:573-579, :606-609, :665-672), written band by band into one buffer.
+//   k_bpm_fast<RGB, ALPHA, MODE>   one workgroup per (image, axis, band of W consecutive lines d0); workgroup ids are
+//          mapped so that all bands of an image run on one XCD (xcd_block).  It
 //          1. stages the band's W x S pixels in LDS, laid out [line][d1] so that a sweep is a contiguous LDS run
 //             whatever the axis;
-//          2. gets its line records: k_bpm_fast copies the band's slice of k_line_setup's buffer (256 at a time); k_bpm_band
-//             -- and k_bpm_fast for an image whose records exceed the buffer -- scans the image's visible faces (one per
-//             thread, 12 coalesced bytes each: the precomputed d0 ranges clipped to the band), assigns line slots with an
-//             exclusive scan and sets the lines up one per thread;
-//          3. sweeps: the in / out sweeps of all lines are cut into segments of <= SEG = 15 pixels; segment ids are
-//             dense (one packed scan of the per-line counts) and ordered by class -- all full-length segments first,
-//             the remainders after -- and one thread walks one segment (binary search id -> line), so the lanes of a
-//             wave have equal trip counts whatever the mix of short in-sweeps and border-long out-sweeps; the two
-//             partial sums of a segment are added to per-line (k_bpm_fast) or per-face LDS accumulators (ds_add_f64);
-//          4. adds the sums to a double scratch array [B][list position][3 vertices][x|y] (global_atomic_add_f64).
+//          2. takes its line records a window at a time: the band's slice of k_line_setup's buffer -- or, for an image whose
+//             records exceed the buffer (and with NR_FLAG_K6_SCAN), a scan of the image's visible faces (one per thread, 12
+//             coalesced bytes each: the precomputed d0 ranges clipped to the band) that sets the window's lines up in place;
+//          3. sweeps (fast_sweeps): the in / out sweeps of all lines are cut into pieces of <= FSEG = 15 pixels, sorted into
+//             coverage classes, numbered through by one packed scan and handed to the threads through a descriptor queue;
+//             the two partial sums of a piece are added to per-line LDS accumulators (ds_add_f64);
+//          4. adds the line sums to a double scratch array [B][list position][3 vertices][x|y] (global_atomic_add_f64).
 //   k_bpm_finalize   rounds the scratch sums to float and STORES grad_faces (z = 0; zeros for unlisted faces).
 //
-// Two kernels for the sweeps (DESIGN.md "K6 numerics"):
-//   k_bpm_band  EXACT: every per-pixel term is computed with the reference's arithmetic (IEEE division, the double
-//          `dist +- eps`), sums in double: the result is the correctly rounded sum of the reference's terms up to double
-//          round-off (<= 2e-6 against the exactly summed oracle).
-//   k_bpm_fast  the north star's tolerance (1e-4) spent where it buys time; see the comment above that kernel.
-#ifndef NR_BAND_THREADS
-#define NR_BAND_THREADS 512
-#endif
-constexpr int BAND_THREADS = NR_BAND_THREADS;
-constexpr int BAND_WIN = 256;    // line records per pass
-constexpr int ACC_SLOTS = 160;   // LDS accumulator slots per scan pass; faces beyond that add straight to global memory
-constexpr int FAST_ACC_SLOTS = 64;  // the same for the scan path of k_bpm_fast (its LDS budget also holds the segment queue)
-#ifndef NR_K6_FSEG
-#define NR_K6_FSEG 15
-#endif
-constexpr int FSEG = NR_K6_FSEG;  // pixels per piece in k_bpm_fast
-constexpr int SEG = 15;          // pixels of a sweep walked by one thread (odd: consecutive segments of a
-                                 // sweep start 15 dwords apart, i.e. on different LDS banks)
+// One kernel, two arithmetic modes for the per-pixel terms (DESIGN.md "K6 numerics"; the sweep structure -- which pixels are
+// visited, by which thread, in which class -- is the same):
+//   K6_FAST   the north star's tolerance (1e-4) spent where it buys time: fused multiply-adds, v_rcp_f32, float piece sums.
+//   K6_EXACT / K6_EXACT_POW2 (NR_FLAG_EXACT_GRADIENT)   every per-pixel term with the reference's arithmetic (its operations
+//          one by one, IEEE division, the double `dist +- eps`), all sums in double: the correctly rounded sum of the
+//          reference's terms up to double round-off (<= 2e-6 against the exactly summed oracle).  _POW2: S is a power of two
+//          (x * 2. / S is then one exact float multiply; the generic form carries a double-precision division).
+constexpr int BAND_THREADS = 512;
+constexpr int BAND_WIN = 256;    // line records per window, at most
+constexpr int FSEG = 15;         // pixels per piece (odd: consecutive pieces of a sweep start on different LDS banks;
+                                 // re-swept in round 3: 9 / 12 / 15 / 18 pixels -> stage 242 / 237 / 230 / 233 us)
+enum { K6_FAST = 0, K6_EXACT_POW2 = 1, K6_EXACT = 2 };
 
 struct __attribute__((aligned(16))) BandLine {
     int in_rng;   // from | to << 16 (from > to: empty)
     int out_rng;  // from | to << 16
     int geo;      // d1_in | ld << 16 | flags << 24   (flags: 1 has out, 2 has0, 4 has1, 8 direction > 0)
-    int tgt;      // slot | v0 << 16 | v1 << 18
+    int tgt;      // list position | v0 << 28 | v1 << 30
     float cross, c0, c1;
     int fn;
 };
@@ -530,429 +523,10 @@ __device__ __forceinline__ double signed_eps(float dist, unsigned eps_hi, unsign
     return __hiloint2double((int)((0.0f < dist) ? eps_hi : (eps_hi ^ 0x80000000u)), (int)eps_lo);
 }
 
-// list position of face fn in an image's (ascending) visible list; only the rare LDS-slot overflow path needs it
-__device__ __forceinline__ int vis_position(const int *__restrict__ list, int n, int fn)
-{
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (list[mid] < fn) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// Segment id -> (line, sweep, pixel range): shared by the two band kernels.  s_pref holds, per line of the window, the
-// exclusive prefix of full segments (low 16 bits) and partial segments (high 16 bits).
-struct SegRange {
-    int line, s_from, s_to;
-    bool mode_in;
-};
-__device__ __forceinline__ SegRange decode_segment(int sid, int total_full, int n_win, const int *s_pref,
-                                                   const int *line_words /* BandLine array */, int stride_words)
-{
-    SegRange r;
-    const bool is_full = sid < total_full;
-    const int id = is_full ? sid : sid - total_full;
-    const int shift = is_full ? 0 : 16;
-    int lo = 0, hi = n_win - 1;  // last line whose prefix (of this class) is <= id
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (((s_pref[mid] >> shift) & 0xffff) <= id) lo = mid; else hi = mid - 1;
-    }
-    r.line = lo;
-    const int in_rng = line_words[lo * stride_words], out_rng = line_words[lo * stride_words + 1];
-    const int k = id - ((s_pref[lo] >> shift) & 0xffff);
-    const int in_from = in_rng & 0xffff, in_to = in_rng >> 16;
-    const int il = in_to - in_from + 1;
-    const int n_in_full = il > 0 ? il / SEG : 0;
-    if (is_full) {
-        r.mode_in = k < n_in_full;
-        r.s_from = r.mode_in ? in_from + k * SEG : (out_rng & 0xffff) + (k - n_in_full) * SEG;
-        r.s_to = r.s_from + SEG - 1;
-    } else {
-        r.mode_in = k == 0 && il > 0 && il % SEG != 0;
-        if (r.mode_in) {
-            r.s_from = in_from + n_in_full * SEG;
-            r.s_to = in_to;
-        } else {
-            const int out_from = out_rng & 0xffff, out_to = out_rng >> 16;
-            r.s_from = out_from + ((out_to - out_from + 1) / SEG) * SEG;
-            r.s_to = out_to;
-        }
-    }
-    return r;
-}
-
-// POW2: S is a power of two (x * 2. / S is then one exact float multiply; the generic instantiation carries a
-// double-precision division whose register footprint would otherwise cap the occupancy of the common case).
-template <bool RGB, bool ALPHA, bool POW2>
-__global__ __launch_bounds__(BAND_THREADS, (RGB && ALPHA && !POW2) ? 4 : 6) void k_bpm_band(
-    const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
-    const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
-    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
-    double *__restrict__ scratch, const int *__restrict__ band_lines, int F, int S, int W, int SP, double eps, int B,
-    int win_lines)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    // XCD-aware placement (nr_device.h): bands of one image share cache lines -- 8 adjacent 4-column bands sit in the same
-    // 128-byte line of every map row, and the horizontal pass re-reads what the vertical pass just fetched -- so all
-    // 2 * n_bands workgroups of an image are given ids that land on ONE XCD (one L2).  Measured: 613 -> 477 us.
-    // (The same mapping on the forward and gather kernels changed nothing or cost 5 %: their reads are not shared.)
-    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
-    const unsigned total_wg = n_bands * 2u * (unsigned)B;
-    const unsigned logical = xcd_block(total_wg);
-    if (logical >= total_wg) return;
-    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
-    const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
-    const int nld = band_hi - band_lo + 1;
-    if (band_lines[((size_t)b * 2 + axis) * n_bands + band] == 0) return;  // step 0: no visible face has a line here
-    const int n_vis = vis_count[b];
-    const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
-
-    // ---- LDS carve-out
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    int *s_fi = (int *)carve((size_t)W * SP * 4);
-    float *s_al = ALPHA ? (float *)carve((size_t)W * SP * 4) : nullptr;
-    float *s_ga = ALPHA ? (float *)carve((size_t)W * SP * 4) : nullptr;
-    float *s_rgb = RGB ? (float *)carve((size_t)W * SP * 12) : nullptr;
-    float *s_grgb = RGB ? (float *)carve((size_t)W * SP * 12) : nullptr;
-    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * BAND_WIN);
-    int *s_rec = (int *)carve(4 * BAND_WIN);
-    int *s_pref = (int *)carve(4 * BAND_WIN);
-    int *s_recfn = (int *)carve(4 * BAND_WIN);           // face index of each line record
-    double *s_acc = (double *)carve(8 * 3 * ACC_SLOTS);  // per-face sums of the faces that have lines in this band
-    int *s_slotpos = (int *)carve(4 * ACC_SLOTS);        // list position of the face in each slot
-    int *s_tmp = (int *)carve(4 * 16);
-
-    // ---- 1. stage the band: LDS[(ld, d1)] = map[b][d0 = band_lo + ld][d1] (axis 1) or map[b][d1][d0] (axis 0)
-    const size_t img = (size_t)b * S * S;
-    if (axis) {  // a band line is an image row: contiguous in memory
-        const bool vec = (S & 3) == 0;
-        for (int ld = 0; ld < nld; ++ld) {
-            const size_t g0 = img + (size_t)(band_lo + ld) * S;
-            const int l0 = ld * SP;
-            if (vec) {
-                for (int x = 4 * tid; x < S; x += 4 * BAND_THREADS) {
-                    *reinterpret_cast<int4 *>(s_fi + l0 + x) = *reinterpret_cast<const int4 *>(fi_map + g0 + x);
-                    if (ALPHA) {
-                        *reinterpret_cast<float4 *>(s_al + l0 + x) = *reinterpret_cast<const float4 *>(alpha_map + g0 + x);
-                        *reinterpret_cast<float4 *>(s_ga + l0 + x) = *reinterpret_cast<const float4 *>(g_alpha + g0 + x);
-                    }
-                }
-                if (RGB)
-                    for (int x = 4 * tid; x < 3 * S; x += 4 * BAND_THREADS) {
-                        *reinterpret_cast<float4 *>(s_rgb + 3 * l0 + x) = *reinterpret_cast<const float4 *>(rgb_map + 3 * g0 + x);
-                        *reinterpret_cast<float4 *>(s_grgb + 3 * l0 + x) = *reinterpret_cast<const float4 *>(g_rgb + 3 * g0 + x);
-                    }
-            } else {
-                for (int x = tid; x < S; x += BAND_THREADS) {
-                    s_fi[l0 + x] = fi_map[g0 + x];
-                    if (ALPHA) { s_al[l0 + x] = alpha_map[g0 + x]; s_ga[l0 + x] = g_alpha[g0 + x]; }
-                }
-                if (RGB)
-                    for (int x = tid; x < 3 * S; x += BAND_THREADS) {
-                        s_rgb[3 * l0 + x] = rgb_map[3 * g0 + x];
-                        s_grgb[3 * l0 + x] = g_rgb[3 * g0 + x];
-                    }
-            }
-        }
-    } else {  // a band line is an image column: the band is nld adjacent columns, read row by row
-        if (nld == 4 && (S & 3) == 0) {  // one 16-byte load per (row, field), scattered to the 4 lines
-            for (int y = tid; y < S; y += BAND_THREADS) {
-                const size_t g = img + (size_t)y * S + band_lo;
-                const int4 vf = *reinterpret_cast<const int4 *>(fi_map + g);
-                s_fi[y] = vf.x; s_fi[SP + y] = vf.y; s_fi[2 * SP + y] = vf.z; s_fi[3 * SP + y] = vf.w;
-                if (ALPHA) {
-                    const float4 va = *reinterpret_cast<const float4 *>(alpha_map + g);
-                    const float4 vg = *reinterpret_cast<const float4 *>(g_alpha + g);
-                    s_al[y] = va.x; s_al[SP + y] = va.y; s_al[2 * SP + y] = va.z; s_al[3 * SP + y] = va.w;
-                    s_ga[y] = vg.x; s_ga[SP + y] = vg.y; s_ga[2 * SP + y] = vg.z; s_ga[3 * SP + y] = vg.w;
-                }
-                if (RGB) {
-                    const float4 *pr = reinterpret_cast<const float4 *>(rgb_map + 3 * g);
-                    const float4 *pg = reinterpret_cast<const float4 *>(g_rgb + 3 * g);
-                    const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], q0 = pg[0], q1 = pg[1], q2 = pg[2];
-                    const float rr[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-                    const float qq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-#pragma unroll
-                    for (int ld = 0; ld < 4; ++ld)
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) {
-                            s_rgb[(ld * SP + y) * 3 + ch] = rr[3 * ld + ch];
-                            s_grgb[(ld * SP + y) * 3 + ch] = qq[3 * ld + ch];
-                        }
-                }
-            }
-        } else {
-            // generic: thread -> (row d1, line ld) with ld fastest; advanced incrementally (no division in the loop)
-            const int step_d1 = BAND_THREADS / nld, step_ld = BAND_THREADS - step_d1 * nld;
-            int d1 = tid / nld, ld = tid - d1 * nld;
-            while (d1 < S) {
-                const size_t g = img + (size_t)d1 * S + band_lo + ld;
-                const int l = ld * SP + d1;
-                s_fi[l] = fi_map[g];
-                if (ALPHA) { s_al[l] = alpha_map[g]; s_ga[l] = g_alpha[g]; }
-                if (RGB) {
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) { s_rgb[3 * l + ch] = rgb_map[3 * g + ch]; s_grgb[3 * l + ch] = g_rgb[3 * g + ch]; }
-                }
-                d1 += step_d1;
-                ld += step_ld;
-                if (ld >= nld) { ld -= nld; ++d1; }
-            }
-        }
-    }
-    if (tid < 3 * ACC_SLOTS) s_acc[tid] = 0.0;
-    __syncthreads();
-
-    const float fs = (float)S;
-    const double s_d = (double)S, two_over_s = 2.0 / (double)S;
-
-    for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
-        // ---- 2. one visible face per thread: lines of its 3 edges inside the band
-        int fn = -1, nl = 0;
-        int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
-        if (chunk + tid < n_vis) {
-            fn = vis_list[(size_t)b * F + chunk + tid];
-            const unsigned *r = rng_ba + (size_t)(chunk + tid) * 3;
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-                const unsigned pr = r[e];
-                const int lo = max((int)(pr & 0xffffu), band_lo), hi = min((int)(pr >> 16), band_hi);
-                if (hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
-            }
-        }
-        // one scan for two prefixes: lines in the low 20 bits (<= 512 * 3 * W), faces-with-lines above
-        int total_packed = 0;
-        const int packed_off = block_excl_scan(nl | ((nl > 0) << 20), s_tmp, &total_packed);
-        const int line_off = packed_off & 0xfffff, slot = packed_off >> 20;
-        const int total_lines = total_packed & 0xfffff;
-        if (nl > 0 && slot < ACC_SLOTS) s_slotpos[slot] = chunk + tid;
-
-        for (int win = 0; win < total_lines; win += win_lines) {
-            // ---- compact records of the lines that fall into this window
-            if (nl > 0 && line_off < win + win_lines && line_off + nl > win) {
-                int k = line_off;
-#pragma unroll
-                for (int e = 0; e < 3; e++)
-                    for (int j = 0; j < e_n[e]; j++, k++)
-                        if (k >= win && k < win + win_lines) {
-                            s_rec[k - win] = slot | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
-                            s_recfn[k - win] = fn;
-                        }
-            }
-            __syncthreads();
-            const int n_win = min(total_lines - win, win_lines);
-
-            // ---- 3. line setup, one line per thread: rasterize.py:543-579, :604-609, :665-672
-            if (tid < n_win) {
-                const int rec = s_rec[tid];
-                const int slot = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
-                const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
-                // the face's vertices come from global memory again (24 B per line, L2 hits) instead of an LDS copy:
-                // the 12 KB that copy took are what lets a third workgroup fit on the CU
-                const int rfn = s_recfn[tid];
-                const float *fv = faces + ((size_t)b * F + rfn) * 9;
-                float fp[6];
-#pragma unroll
-                for (int k = 0; k < 3; k++) { fp[k] = to_pixel(fv[3 * k], fs); fp[3 + k] = to_pixel(fv[3 * k + 1], fs); }
-                const int ox = axis ? 3 : 0, oy = axis ? 0 : 3;  // p[num][dim] = pp[num][(dim + axis) % 2] (:556)
-                const float p0x = fp[ox + i0], p0y = fp[oy + i0], p1x = fp[ox + i1], p1y = fp[oy + i1];
-                const float p2x = fp[ox + i2], p2y = fp[oy + i2];
-                int direction;
-                if (axis == 0) direction = (p0x < p1x) ? -1 : 1; else direction = (p0x < p1x) ? 1 : -1;  // :559-564
-                const int d0 = band_lo + ld;
-                const float d0f = (float)d0;
-                BandLine r;
-                r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = slot | (i0 << 16) | (i1 << 18);
-                r.cross = r.c0 = r.c1 = 0.0f;
-                r.fn = rfn;
-                const float d1_cross = (p1y - p0y) / (p1x - p0x) * (d0f - p0x) + p0y;                  // :573
-                const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);     // :574
-                const int d1_out = d1_in + direction;                                                 // :575
-                if (!(d1_in < 0 || S <= d1_in) && !(d1_out < 0 || S <= d1_out)) {                     // :578-579
-                    int flags = (0 < direction) ? 8 : 0;
-                    if (p1x != d0f) flags |= 2;
-                    if (p0x != d0f) flags |= 4;
-                    r.c0 = (p1x - p0x) / (p1x - d0f);  // :649 leading factor, invariant along the sweep
-                    r.c1 = (p1x - p0x) / (d0f - p0x);  // :654
-                    if (s_fi[ld * SP + d1_in] == r.fn) {  // :604-609
-                        const int lim = (0 < direction) ? S - 1 : 0;
-                        const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
-                        r.out_rng = o_from | (o_to << 16);
-                        flags |= 1;
-                    }
-                    float d0_cross2;                      // :665-672
-                    if ((d0f - p0x) * (d0f - p2x) < 0)
-                        d0_cross2 = (p2y - p0y) / (p2x - p0x) * (d0f - p0x) + p0y;
-                    else
-                        d0_cross2 = (p1y - p2y) / (p1x - p2x) * (d0f - p2x) + p2y;
-                    const int lim2 = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
-                    const int i_from = max(min(d1_in, lim2), 0), i_to = min(max(d1_in, lim2), S - 1);
-                    r.in_rng = i_from | (i_to << 16);
-                    r.geo = d1_in | (ld << 16) | (flags << 24);
-                    r.cross = d1_cross;
-                }
-                s_line[tid] = r;
-            }
-            __syncthreads();
-
-            // ---- 4. sweeps, one SEGMENT (<= SEG pixels of one sweep) per thread.  Segment ids are dense and ordered by
-            //         class: first every FULL segment (exactly SEG pixels) of every line, then the partial ones (the
-            //         remainders, i.e. all the short in-sweeps), so that the 64 lanes of a wave walk segments of (nearly)
-            //         equal length instead of idling behind one long out-sweep piece.  One packed scan gives both
-            //         prefixes: full segments in the low 16 bits (win_lines is chosen so that win_lines * 2 * S / SEG fits),
-            //         partial ones above.
-            int n_seg = 0;
-            if (tid < n_win) {
-                const BandLine &L = s_line[tid];
-                const int il = (L.in_rng >> 16) - (L.in_rng & 0xffff) + 1, ol = (L.out_rng >> 16) - (L.out_rng & 0xffff) + 1;
-                const int full = (il > 0 ? il / SEG : 0) + (ol > 0 ? ol / SEG : 0);
-                const int part = (il > 0 && il % SEG != 0) + (ol > 0 && ol % SEG != 0);
-                n_seg = full | (part << 16);
-            }
-            int total_seg = 0;
-            const int seg_off = block_excl_scan(n_seg, s_tmp, &total_seg);
-            if (tid < n_win) s_pref[tid] = seg_off;
-            __syncthreads();
-            const int total_full = total_seg & 0xffff, total_all = total_full + (total_seg >> 16);
-            for (int sid = tid; sid < total_all; sid += BAND_THREADS) {
-                const SegRange sr = decode_segment(sid, total_full, n_win, s_pref, reinterpret_cast<const int *>(s_line),
-                                                   (int)(sizeof(BandLine) / 4));
-                const BandLine *L = &s_line[sr.line];
-                const int4 h = *reinterpret_cast<const int4 *>(L);
-                const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
-                const bool mode_in = sr.mode_in;
-                const int flags = (h.z >> 24) & 0xff;
-                const int ld = (h.z >> 16) & 0xff;
-                const int d1_in = h.z & 0xffff;
-                // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
-                const int lref = ld * SP + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
-                float ref_a = 0, ref_r = 0, ref_g = 0, ref_b = 0;
-                if (ALPHA) ref_a = s_al[lref];
-                if (RGB) { ref_r = s_rgb[3 * lref]; ref_g = s_rgb[3 * lref + 1]; ref_b = s_rgb[3 * lref + 2]; }
-                const float cross = c.x, c0 = c.y, c1 = c.z;
-                const int fnr = __float_as_int(c.w);
-                // every term bit-identical to the reference's (IEEE division, double `dist +- eps`), summed in double
-                double d0acc = 0.0, d1acc = 0.0;
-                const float two_over_s_f = (float)two_over_s;  // exact when S is a power of two
-                const unsigned eps_hi = (unsigned)__double2hiint(eps), eps_lo = (unsigned)__double2loint(eps);
-                const bool has0 = (flags & 2) != 0, has1 = (flags & 4) != 0;
-                for (int d1 = sr.s_from; d1 <= sr.s_to; ++d1) {  // one pixel visit: :630-657 (out) / :697-728 (in)
-                    const int l = ld * SP + d1;
-                    if (mode_in && s_fi[l] != fnr) continue;  // :707 (the out sweep does not test ownership)
-                    float diff = 0.0f;
-                    if (ALPHA) diff += (s_al[l] - ref_a) * s_ga[l];
-                    if (RGB) {
-                        diff += (s_rgb[3 * l] - ref_r) * s_grgb[3 * l];
-                        diff += (s_rgb[3 * l + 1] - ref_g) * s_grgb[3 * l + 1];
-                        diff += (s_rgb[3 * l + 2] - ref_b) * s_grgb[3 * l + 2];
-                    }
-                    if (diff <= 0.0f) continue;  // :647 / :717
-                    const float t = (float)d1 - cross;
-                    if (has0) {  // :648-652 (x * 2. / S: an exact scaling when S is a power of two)
-                        const float ct = c0 * t;
-                        float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
-                        dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
-                        d0acc -= (double)(diff / dist);
-                    }
-                    if (has1) {  // :653-657
-                        const float ct = c1 * t;
-                        float dist = POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
-                        dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));
-                        d1acc -= (double)(diff / dist);
-                    }
-                }
-                const int slot = h.w & 0xffff, v0 = (h.w >> 16) & 3, v1 = (h.w >> 18) & 3;
-                if (slot < ACC_SLOTS) {
-                    if (d0acc != 0.0) atomicAdd(&s_acc[3 * slot + v0], d0acc);
-                    if (d1acc != 0.0) atomicAdd(&s_acc[3 * slot + v1], d1acc);
-                } else if (d0acc != 0.0 || d1acc != 0.0) {  // more faces with lines in this pass than LDS slots
-                    const int pos = vis_position(vis_list + (size_t)b * F, n_vis, fnr);
-                    double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
-                    if (d0acc != 0.0) atomicAdd(dst + 2 * v0, d0acc);
-                    if (d1acc != 0.0) atomicAdd(dst + 2 * v1, d1acc);
-                }
-            }
-            __syncthreads();
-        }
-
-        // ---- 5. per-face sums of this chunk -> global double scratch [list position][vertex][x|y]
-        {
-            const int n_slots = min(total_packed >> 20, ACC_SLOTS);
-            if (tid < 3 * n_slots) {
-                const int sl = tid / 3, v = tid - 3 * sl;
-                const double a = s_acc[tid];
-                if (a != 0.0) atomicAdd(scratch + ((size_t)b * F + s_slotpos[sl]) * 6 + 2 * v + (1 - axis), a);
-                s_acc[tid] = 0.0;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // --------------------------------------------------------------------------------------------------
-// The tolerance-mode band kernel (default).  Same pipeline and same line setup as k_bpm_band (which pixels are visited must
-// not depend on the mode).  The sweeps of this kernel are bound by LDS bandwidth (64 lanes reading 64 unrelated pixels:
-// ~2-3 bank conflicts per access), so what it optimises is bytes per visit:
-//   * LDS pixel data in three arrays [line][d1]: the face index (4 B), the GRADIENTS (g_alpha, g_r, g_g, g_b: 16 B, one
-//     ds_read_b128) and the COLOURS (alpha, r, g, b: 16 B).  Seven of eight visits of an out sweep land on pixels no face
-//     covers, whose colour is the image's background (K5, rasterize.py:440-465: uncovered pixels of rgb_map hold the
-//     background colour, of alpha_map 0 -- the maps this entry point is documented to take): for those the colour is not
-//     read at all, it is a per-band constant picked up during staging.  20 bytes per visit instead of 36;
-//   * diff = sum_c (I_c - ref_c) * g_c with the reference's own operations and order (:631-638, :709-716: bit-identical,
-//     so `diff <= 0` decides exactly as the reference does), then per vertex dist = c * 2/S * t, +- eps by its sign in float,
-//     diff * v_rcp_f32(dist), float sums over the <= 15 terms of a segment, double from there on.
-// Deviation: a term differs from the reference's (IEEE division, double `dist +- eps`) by ~1-2 ulp; a face gradient is a sum
-// of up to thousands of such terms of both signs, so after cancellation the deviation against the exactly summed reference
-// terms is 1e-7 .. 1e-5 of the largest gradient (tests bound it by the north star's 1e-4) -- the same metric puts the
-// reference's OWN serial float summation at 1e-5 .. 1e-3 from the exact sum.
-// When a contribution is not taken (:648 / :653: d0 equals the vertex) its coefficient is +-Inf / NaN; the lane then
-// accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
-#ifdef NR_K6_PHASES  // development build: cycles spent per phase, summed over workgroups (scripts/k6_phases.py)
-__device__ unsigned long long g_k6_phase[24];
-// per-wave accounting inside fast_sweeps (slots 8..): 8 classify+scan, 9 barrier wait, 10 fill, 11 decode, 12 U loop, 13 M loop,
-// 14 G loop, 15 flush, 16 wave-rounds U, 17 M, 18 G, 19 idle wave-rounds
-// (accumulated per wave in LDS, one set of global atomics per wave when fast_sweeps returns: a global atomic per stamp
-// from every wave of the chip serialises on one address and slows the kernel 30x)
-#define NR_WPH_BEGIN()                                                              \
-    __shared__ unsigned s_wph[BAND_THREADS / 64][12];                               \
-    if ((threadIdx.x & 63) < 12) s_wph[threadIdx.x >> 6][threadIdx.x & 63] = 0u;    \
-    unsigned long long wph_t = clock64()
-#define NR_WPH(k)                                                                   \
-    do {                                                                            \
-        const unsigned long long wnow = clock64();                                  \
-        if ((threadIdx.x & 63) == 0) s_wph[threadIdx.x >> 6][(k) - 8] += (unsigned)(wnow - wph_t); \
-        wph_t = wnow;                                                               \
-    } while (0)
-#define NR_WCOUNT(k) do { if ((threadIdx.x & 63) == 0) s_wph[threadIdx.x >> 6][(k) - 8] += 1u; } while (0)
-#define NR_WPH_END()                                                                \
-    do {                                                                            \
-        if ((threadIdx.x & 63) < 12 && s_wph[threadIdx.x >> 6][threadIdx.x & 63])   \
-            atomicAdd(&g_k6_phase[8 + (threadIdx.x & 63)], (unsigned long long)s_wph[threadIdx.x >> 6][threadIdx.x & 63]); \
-    } while (0)
-#define NR_PHASE_BEGIN() unsigned long long ph_t = clock64()
-#define NR_PHASE(k)                                                                 \
-    do {                                                                            \
-        __syncthreads();                                                            \
-        if (threadIdx.x == 0) {                                                     \
-            const unsigned long long now = clock64();                               \
-            atomicAdd(&g_k6_phase[k], now - ph_t);                                  \
-            ph_t = now;                                                             \
-        }                                                                           \
-    } while (0)
-#else
-#define NR_PHASE_BEGIN() do {} while (0)
-#define NR_PHASE(k) do {} while (0)
-#define NR_WPH_BEGIN() do {} while (0)
-#define NR_WPH(k) do {} while (0)
-#define NR_WCOUNT(k) do {} while (0)
-#define NR_WPH_END() do {} while (0)
-#endif
-
-// One line record of the fast kernel (rasterize.py:543-579, :604-609, :665-672; the reference's arithmetic: the crossing
+// The line records of the band kernel.  Which pixels a sweep visits is decided here, with the reference's arithmetic, and
+// must not depend on the arithmetic mode of the terms.
+// One line record (rasterize.py:543-579, :604-609, :665-672; the reference's arithmetic: the crossing
 // points decide WHICH pixels are visited, which must not depend on the mode).  fv: the face's 9 floats; (e, axis, d0): the
 // line; ld = d0 - first line of its band; owner_of(d1): face index of pixel (d0, d1) along the axis.
 // in two steps, so that a caller can have the ownership reads of several lines in flight before it finishes any of them
@@ -982,10 +556,10 @@ __device__ __forceinline__ LineHead fast_line_head(const float *__restrict__ fv,
     return h;
 }
 
-// owner: face index of the line's in pixel (d0, d1_in) (only read when h.live)
-__device__ __forceinline__ BandLine fast_line_finish(const LineHead &h, int ld, int S, int rfn, int tgt, int owner)
+// owner: face index of the line's in pixel (d0, d1_in) (only read when h.live); k2s: what the two distance coefficients are
+// multiplied by up front -- 2 / S for the tolerance mode (:649 `* 2. / is` folded in), 1 for the exact one
+__device__ __forceinline__ BandLine fast_line_finish(const LineHead &h, int ld, int S, int rfn, int tgt, int owner, float k2s)
 {
-    const float k2s = 2.0f / (float)S;
     const float p0x = h.p0x, p0y = h.p0y, p1x = h.p1x, p1y = h.p1y, p2x = h.p2x, p2y = h.p2y, d0f = h.d0f;
     const int direction = h.direction, d1_in = h.d1_in, d1_out = h.d1_out;
     BandLine r;
@@ -996,7 +570,7 @@ __device__ __forceinline__ BandLine fast_line_finish(const LineHead &h, int ld, 
         int flags = (0 < direction) ? 8 : 0;
         if (p1x != d0f) flags |= 2;
         if (p0x != d0f) flags |= 4;
-        r.c0 = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor x 2 / S
+        r.c0 = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor, invariant along the sweep (x 2 / S: see k2s)
         r.c1 = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
         if (owner == rfn) {                      // :604-609
             const int lim = (0 < direction) ? S - 1 : 0;
@@ -1020,10 +594,10 @@ __device__ __forceinline__ BandLine fast_line_finish(const LineHead &h, int ld, 
 
 template <typename OwnerOf>
 __device__ __forceinline__ BandLine make_fast_line(const float *__restrict__ fv, int e, int axis, int d0, int ld, int S,
-                                                   int rfn, int tgt, OwnerOf owner_of)
+                                                   int rfn, int tgt, OwnerOf owner_of, float k2s)
 {
     const LineHead h = fast_line_head(fv, e, axis, d0, S);
-    return fast_line_finish(h, ld, S, rfn, tgt, h.live ? owner_of(h.d1_in) : -1);
+    return fast_line_finish(h, ld, S, rfn, tgt, h.live ? owner_of(h.d1_in) : -1, k2s);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1037,7 +611,8 @@ __device__ __forceinline__ BandLine make_fast_line(const float *__restrict__ fv,
 //   irrelevant: every record is accumulated independently.  tgt = list position | v0 << 28 | v1 << 30.
 //   The band table (lines per band, where each band starts) is the sum of the rows k_compact_par left per chunk: every
 //   workgroup adds them up for itself, the image's first one also publishes the table for the band kernel.
-// Images whose lines exceed the buffer's capacity (lines_ok[b] == 0) are skipped here and take the scan path of k_bpm_fast.
+// Images whose lines exceed the buffer's capacity (lines_ok[b] == 0) are skipped here and take the scan path of k_bpm_fast
+// (every backward test forces that path as well: tests/test_hip_parity.py check_backward, NR_FLAG_K6_SCAN).
 constexpr int LS_UNROLL = 4;  // lines per thread and round of k_line_setup
 constexpr int LS_FACES = 32;  // list positions per workgroup (measured with a thread per item: 64 -> 43 us, 32 -> 29 us, 16 -> 29 us)
 
@@ -1082,7 +657,7 @@ __global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ fa
                                                     int n_sum, int *__restrict__ band_lines, int *__restrict__ band_start,
                                                     int *__restrict__ band_cursor, int *__restrict__ lines_ok,
                                                     BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W,
-                                                    int n_bands)
+                                                    int n_bands, float k2s)
 {
     extern __shared__ int s_cnt[];  // [2 * n_bands] this workgroup's lines per band, then its fill cursors; [2 * n_bands] bases;
     int *s_base = s_cnt + 2 * n_bands;  // [2 * n_bands] where the image's bands start in its buffer
@@ -1212,7 +787,7 @@ __global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ fa
             const int band = d0v[u] / W, ld = d0v[u] - band * W;
             const int tgt = (pos0 + p * pstep) | (e << 28) | (((e + 1) % 3) << 30);
             const int bi = axis * n_bands + band;
-            buf_b[s_base[bi] + atomicAdd(s_cnt + bi, 1)] = fast_line_finish(h[u], ld, S, s_fn[p], tgt, own[u]);
+            buf_b[s_base[bi] + atomicAdd(s_cnt + bi, 1)] = fast_line_finish(h[u], ld, S, s_fn[p], tgt, own[u], k2s);
         }
     }
 }
@@ -1250,7 +825,7 @@ __global__ __launch_bounds__(256) void k_band_scan(const int *__restrict__ band_
     band_prefix(band_lines + o, 2 * n_bands, band_start + o, band_cursor + o, lines_ok + blockIdx.x, force_scan ? 0 : cap);
 }
 
-// the same table from the chunk rows of k_compact_par when no k_line_setup follows (exact kernel, NR_FLAG_K6_SCAN): every
+// the same table from the chunk rows of k_compact_par when no k_line_setup follows (NR_FLAG_K6_SCAN): every
 // image is told to take the scan path
 __global__ __launch_bounds__(256) void k_band_total(const int *__restrict__ chunk_band, int n_sum, int *__restrict__ band_lines,
                                                     int *__restrict__ band_start, int *__restrict__ lines_ok, int n_bands)
@@ -1366,34 +941,35 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
 }
 
 // --------------------------------------------------------------------------------------------------
-// Step 4 of k_bpm_fast: the sweeps of the n_win line records in s_line, one SEGMENT (<= FSEG pixels of one sweep) per thread
-// and round.  Three classes of segments, each walked by its own loop:
+// Step 3 of k_bpm_fast: the sweeps of the n_win line records in s_line, one PIECE (<= FSEG pixels of one sweep) per thread
+// and round.  Pieces are sorted into classes, each walked by its own loop:
 //   U  exactly FSEG pixels of an OUT sweep, none of them covered by a face (7 of 8 pixels of an out sweep are background, and
 //      they come in long runs behind the silhouette): `I - ref` is the constant (background - reference colour), the visit
 //      reads the four gradients and nothing else; unrolled over its 15 pixels with compile-time LDS offsets;
-//   M  exactly FSEG pixels of an OUT sweep with covered pixels among them (the coverage bits say which): those read their
-//      colour as well;
+//   M  exactly FSEG pixels of an OUT sweep between the first and the last covered pixel of the sweep (the coverage bits say
+//      where): every pixel's colour is read as well -- an uncovered one holds the background colour (K5);
 //   G  everything else: the pieces (<= FSEG pixels) of the in sweeps -- ownership test :707, per-pixel sign of `+- eps` -- and
-//      the remainder of the out sweep, the general loop.
-// The out classes take the sign of `+- eps` once per segment: t = d1 - d1_cross keeps its sign beyond the crossing point,
-// hence so do c0 * t and c1 * t (:650 / :655).  (Measured on the headline scene, r03: with every segment on the general loop
-// a visit costs ~27 VALU instructions; a wave whose 64 lanes walk unrelated segments executes the covered-pixel block in
-// practically every step although 1 lane in 8 needs it, so sorting the segments by coverage is what makes the cheap loop
-// cheap: U 18 instructions per visit.)
-// Segment -> thread without a search: the thread that owns line `tid` of the window classifies the line's segments (coverage
-// bits of the band, px.cov), one packed scan numbers the segments of each class through (U first, then M, then G, every class
+//      the remainder of the out sweep, the general loop; short pieces (<= G_SHORT pixels) are numbered apart from long ones.
+// Piece -> thread without a search: the thread that owns line `tid` of the window classifies the line's pieces (coverage
+// bits of the band, px.cov), one packed scan numbers the pieces of each class through (U first, then M, then G, every class
 // starting on a multiple of 64 so that a wave never mixes classes), the owners write a (line | piece << 8) descriptor per
-// segment into a queue, and after one barrier every thread walks the ids tid, tid + 512, ... of the queue.  The queue takes
-// what the line window leaves of the workgroup's LDS (fast_band_config: ~3000 descriptors, a window's worth); a window with
-// more segments goes through it in rounds.  (The binary search over the lines' prefix sums that this replaces cost ~100
-// instructions and 9 dependent LDS round trips per segment; per-round queues of 512 entries cost a barrier and an owner
-// pass per round.)
-// The two sums of a segment go to acc[acc_index(line, tgt, k)] (ds_add_f64), k = 0 / 1 for the edge's first / second vertex;
-// acc_index returns a negative value for "no LDS slot" and spill() then takes the sum.
-#ifndef NR_K6_FB
-#define NR_K6_FB 3  // pixels of an unrolled segment whose LDS reads are requested together (FSEG is a multiple)
-#endif
-static_assert(FSEG % NR_K6_FB == 0, "batches must tile a segment");
+// piece into a queue, and after one barrier every thread walks the ids tid, tid + 512, ... of the queue.  The queue takes
+// what the line window leaves of the workgroup's LDS (fast_band_config: ~2500 descriptors, a window's worth); a window with
+// more pieces goes through it in rounds.  (The binary search over the lines' prefix sums that this replaced in round 3 cost
+// ~100 instructions and 9 dependent LDS round trips per piece.)
+// The two sums of a piece go to acc[2 * line + k] (ds_add_f64), k = 0 / 1 for the edge's first / second vertex.
+//
+// Arithmetic of a visit (rasterize.py:630-657 out sweep, :697-728 in sweep) by MODE:
+//   K6_FAST   diff = sum_c (I_c - ref_c) * g_c in the reference's order, accumulated with fused multiply-adds; dist =
+//      fma(c * 2/S, t, +-eps) in float, the sign of `+- eps` taken once per piece in U / M (t = d1 - d1_cross keeps its sign
+//      beyond the crossing point, hence so do c0 * t and c1 * t, :650 / :655); diff * v_rcp_f32(dist); float sums over the
+//      <= 15 terms of a piece and over the <= 16 pieces of a run of lanes, double from there on.  No branch in U / M:
+//      dm = diff <= 0 ? 0 : diff (:647: a NaN diff is not `<= 0` and goes through).  nr_k6_tune.h holds the knobs.
+//   K6_EXACT*   the reference's operations one by one (products and sums rounded separately, `x * 2. / is` and `dist +- eps`
+//      in double as its literals make them, IEEE division), every sum in double.
+// When a contribution is not taken (:648 / :653: d0 equals the vertex) its coefficient is +-Inf / NaN; the lane then
+// accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
+static_assert(FSEG % k6::FB == 0, "batches must tile a piece");
 constexpr int G_SHORT = 4;  // class G pieces up to this many pixels are numbered apart from the longer ones
 
 // DPP moves inside a row of 16 lanes: value of the lane D places below / one place above; a lane without such a neighbour
@@ -1401,11 +977,41 @@ constexpr int G_SHORT = 4;  // class G pieces up to this many pixels are numbere
 template <int D>
 __device__ __forceinline__ int dpp_row_shr(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x110 + D, 0xf, 0xf, false); }
 template <int D>
-__device__ __forceinline__ float dpp_row_shr_f(float v)  // (0 where there is no such neighbour)
+__device__ __forceinline__ float dpp_row_shr_v(float v)  // (0 where there is no such neighbour)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, false));
 }
+template <int D>
+__device__ __forceinline__ double dpp_row_shr_v(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + D, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + D, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int dpp_row_shl1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x101, 0xf, 0xf, false); }
+
+// The pieces of one line sit on neighbouring lanes (consecutive ids), and all of them add to the same two sums: 64 lanes on
+// ~10 addresses make the LDS serialise an atomic per lane.  So the sums of each run of equal keys are formed with DPP moves
+// first (a segmented scan inside the 16-lane rows; a run that crosses a row is flushed in two parts); on return only the last
+// lane of a run holds a non-zero pair.  In float for the tolerance mode (<= 16 piece sums, a tree of depth 4; in double the
+// moves and selects come in pairs: stage 249 vs 239 us at raster 256 in round 3), in double for the exact one.  Which pieces
+// share a run depends on the order of the line records, so two calls of the tolerance mode agree to ~1e-6 of the largest
+// gradient, not to the bit.  (All 64 lanes execute this: the id loop keeps the wave together.)
+template <typename T>
+__device__ __forceinline__ void run_sums(int key, T &p0, T &p1)
+{
+    const int k1 = dpp_row_shr<1>(-1, key), k2 = dpp_row_shr<2>(-1, key), k4 = dpp_row_shr<4>(-1, key),
+              k8 = dpp_row_shr<8>(-1, key);
+    T q0 = dpp_row_shr_v<1>(p0), q1 = dpp_row_shr_v<1>(p1);
+    if (k1 == key) { p0 += q0; p1 += q1; }
+    q0 = dpp_row_shr_v<2>(p0); q1 = dpp_row_shr_v<2>(p1);
+    if (k2 == key) { p0 += q0; p1 += q1; }
+    q0 = dpp_row_shr_v<4>(p0); q1 = dpp_row_shr_v<4>(p1);
+    if (k4 == key) { p0 += q0; p1 += q1; }
+    q0 = dpp_row_shr_v<8>(p0); q1 = dpp_row_shr_v<8>(p1);
+    if (k8 == key) { p0 += q0; p1 += q1; }
+    if (dpp_row_shl1(-1, key) == key) p0 = p1 = T(0);  // not the last lane of its run
+}
 
 // inclusive prefix sum over the 64 lanes with DPP moves only (no LDS crossbar round trips): Hillis-Steele inside each row of 16
 // lanes, then the row totals are passed on (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
@@ -1443,14 +1049,14 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
     return woff + inc - v;
 }
 
-template <bool RGB, bool ALPHA, typename AccIndex, typename Spill>
-__device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_line, int n_win, int SP, float eps_f,
-                                            double *acc, AccIndex acc_index, Spill spill, void *s_queue, int qcap, bool wide,
-                                            unsigned long long *s_tmp)
+template <bool RGB, bool ALPHA, int MODE>
+__device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_line, int n_win, int SP, double eps, int S,
+                                            double *acc, void *s_queue, int qcap, bool wide, unsigned long long *s_tmp)
 {
+    constexpr bool EXACT = MODE != K6_FAST;
+    constexpr int FB = k6::FB;
     const int tid = threadIdx.x;
-    NR_WPH_BEGIN();
-    // ---- owner of line `tid`: its segments by class.  The covered pixels of an out sweep lie next to the edge it starts
+    // ---- owner of line `tid`: its pieces by class.  The covered pixels of an out sweep lie next to the edge it starts
     // from (the rest of the object), the background behind them: the full pieces from the one with the first covered pixel
     // to the one with the last are class M (pmin .. pmin + nM - 1; an uncovered gap between two covered stretches -- the
     // teapot's handle -- rides along), the others class U.  One pass over the line's coverage words finds both ends.
@@ -1473,11 +1079,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
         rem = ol > 0 ? ol % FSEG : 0;
         nG = nIn + (rem > 0);
         nS = (rin > 0 && rin <= G_SHORT) + (rem > 0 && rem <= G_SHORT);
-#ifdef NR_K6_NO_CLASSIFY
-        if (false) {
-#else
         if (nF > 0) {
-#endif
             const int ld = (geo >> 16) & 0xff;
             const unsigned *cw = px.cov + ld * px.CW;
             // the pieces' pixels [out_from, last], clipped to the covered span of the band line
@@ -1523,16 +1125,23 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
               idL = LA + (int)(offs >> 48);
     unsigned short *q16 = reinterpret_cast<unsigned short *>(s_queue);
     unsigned *q32 = reinterpret_cast<unsigned *>(s_queue);
-    NR_WPH(8);
+    // arithmetic constants of the mode
+    const float eps_f = (float)eps;                                                      // K6_FAST
+    const unsigned eps_hi = (unsigned)__double2hiint(eps), eps_lo = (unsigned)__double2loint(eps);  // K6_EXACT*
+    const double s_d = (double)S;
+    const float two_over_s_f = (float)(2.0 / (double)S);  // exact when S is a power of two
+    // one term of the exact mode: :649-651 / :654-656 (x * 2. / S: an exact scaling when S is a power of two)
+    auto exact_term = [&](float diff, float c, float t) {
+        const float ct = c * t;
+        float dist = MODE == K6_EXACT_POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
+        dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
+        return diff / dist;
+    };
     // rounds of qcap ids (qcap: a multiple of BAND_THREADS; most windows fit in one round)
     for (int lo = 0; lo < total_ids; lo += qcap) {
         const int hi = min(lo + qcap, total_ids);
         if (lo > 0) __syncthreads();  // the previous round's readers are done
-#ifdef NR_K6_NO_FILL
-        if (false) {
-#else
-        if (owner) {                  // descriptors (line | piece << 8) of this owner's segments with ids in [lo, hi)
-#endif
+        if (owner) {                  // descriptors (line | piece << 8) of this owner's pieces with ids in [lo, hi)
             auto put = [&](int id, int seg) {
                 if (wide) q32[id - lo] = (unsigned)my_line | ((unsigned)seg << 8);
                 else q16[id - lo] = (unsigned short)(my_line | (seg << 8));
@@ -1545,259 +1154,255 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                 if (id >= lo && id < hi) put(id, j);
             }
         }
-        NR_WPH(10);
         __syncthreads();
-        NR_WPH(9);
-#ifdef NR_K6_NO_IDS  // development build: classification, scan and queue only
-    if (false)
-#endif
-    for (int id = lo + tid; rfl(id) < hi; id += BAND_THREADS) {  // (wave-uniform trip count: all 64 lanes stay together)
-        const int wid = rfl(id);     // ids of a wave are 64 consecutive numbers from a multiple of 64: one class per wave
-        const int cls = wid < MA ? 0 : (wid < SA ? 1 : 2);
-        const int cls_end = min(hi, cls == 0 ? TU : (cls == 1 ? MA + TM : (wid < LA ? SA + TS : total_ids)));
-        NR_WCOUNT(16 + cls);
-        if (wid >= cls_end) continue;  // a wave of padding ids
-        // a lane on a padding id behind its class walks piece 0 of line 0 (valid LDS addresses) and throws the result away
-        const bool valid = id < cls_end;
-        const unsigned desc = valid ? (wide ? q32[id - lo] : (unsigned)q16[id - lo]) : 0u;
-        const int line = (int)(desc & 0xffu), seg = (int)(desc >> 8);
-        const BandLine *L = &s_line[line];
-        const int4 h = *reinterpret_cast<const int4 *>(L);
-        const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
-        const int flags = (h.z >> 24) & 0xff;
-        const int ld = (h.z >> 16) & 0xff, base = ld * SP;
-        const int d1_in = h.z & 0xffff;
-        const int out_from = h.y & 0xffff, out_to = h.y >> 16;
-        // class G: which sweep and which pixels
-        bool mode_in = false;
-        int s_from = out_from + seg * FSEG, s_to = s_from + FSEG - 1;
-        if (cls == 2) {
-            const int in_from = h.x & 0xffff, in_to = h.x >> 16;
-            const int il = in_to - in_from + 1;
-            const int n_in = il > 0 ? (il + FSEG - 1) / FSEG : 0;
-            mode_in = seg < n_in;
-            if (mode_in) { s_from = in_from + seg * FSEG; s_to = min(s_from + FSEG - 1, in_to); }
-            else { s_from = out_from + ((out_to - out_from + 1) / FSEG) * FSEG; s_to = out_to; }
-        }
-        // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
-        const int lref = base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
-        float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
-        float ba = 0.0f, br = 0.0f, bgn = 0.0f, bb = 0.0f;  // colour of an uncovered pixel
-        if (RGB) {
-            const float4 q = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)lref);
-            ra = q.x; rr = q.y; rg = q.z; rb = q.w;
-            const float4 w = *reinterpret_cast<const float4 *>(px.bg);
-            ba = w.x; br = w.y; bgn = w.z; bb = w.w;
-        } else {
-            ra = px.c[lref];
-            ba = px.bg[0];
-        }
-        // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its leading
-        // `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the background colour
-        // (K5), whose difference to the reference colour is a constant of the segment.
-        const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;
-        const float cross = c.x, c0k = c.y, c1k = c.z;
-        const int fnr = __float_as_int(c.w);
-        float f0 = 0.0f, f1 = 0.0f;
-#ifndef NR_K6_UNFUSED
-        // (The default kernel's terms are approximate by contract -- v_rcp_f32, DESIGN 3 -- so the dot product and the two
-        // `c * t + eps` of a visit are fused multiply-adds here: 19 -> 13 VALU instructions per uncovered pixel, 23 -> 17 per
-        // covered one.  The exact kernel keeps the reference's operations one by one.)
-        auto bg_diff = [&](const float4 &g4, float ga) {
-            if (!RGB) return dba * ga;
-            float d = ALPHA ? __builtin_fmaf(dbr, g4.y, dba * g4.x) : dbr * g4.y;
-            d = __builtin_fmaf(dbg, g4.z, d);
-            d = __builtin_fmaf(dbb, g4.w, d);
-            return d;
-        };
-        auto own_diff = [&](const float4 &c4, float ca, const float4 &g4, float ga) {  // c4 / ca: the pixel's colour
-            if (!RGB) return (ca - ra) * ga;
-            float d = ALPHA ? __builtin_fmaf(c4.y - rr, g4.y, (c4.x - ra) * g4.x) : (c4.y - rr) * g4.y;
-            d = __builtin_fmaf(c4.z - rg, g4.z, d);
-            d = __builtin_fmaf(c4.w - rb, g4.w, d);
-            return d;
-        };
-#else
-        auto bg_diff = [&](const float4 &g4, float ga) {
-            if (!RGB) return dba * ga;
-            float d = ALPHA ? dba * g4.x + dbr * g4.y : dbr * g4.y;
-            d += dbg * g4.z;
-            d += dbb * g4.w;
-            return d;
-        };
-        auto own_diff = [&](const float4 &c4, float ca, const float4 &g4, float ga) {  // c4 / ca: the pixel's colour
-            if (!RGB) return (ca - ra) * ga;
-            float d = ALPHA ? (c4.x - ra) * g4.x + (c4.y - rr) * g4.y : (c4.y - rr) * g4.y;
-            d += (c4.z - rg) * g4.z;
-            d += (c4.w - rb) * g4.w;
-            return d;
-        };
-#endif
-        NR_WPH(11);
-#ifdef NR_K6_NO_LOOPS  // development build: everything of the sweeps but the pixel loops
-        f0 = ra + cross; f1 = dba + c0k + c1k + (float)s_from + (float)s_to + (float)fnr;
-        if (false)
-#endif
-        if (cls < 2) {
-            // ---- U / M: FSEG pixels of an out sweep, unrolled; one address register per array, compile-time offsets
-            const int l0 = base + s_from;
-            const float d1f0 = (float)s_from;
-            const float t_first = d1f0 - cross;
-            const float e0 = (0.0f < c0k * t_first) ? eps_f : -eps_f, e1 = (0.0f < c1k * t_first) ? eps_f : -eps_f;
-            const float *gp = px.g + (RGB ? 4 : 1) * (size_t)l0, *cp = px.c + (RGB ? 4 : 1) * (size_t)l0;
-            // One visit without a branch (:647: a NaN diff is not `<= 0` and goes through): the visits of a batch are
-            // independent instruction chains that the scheduler interleaves -- a wave spends its time here waiting for its
-            // own dependent instructions and LDS reads, not for issue slots.  y is never 0 (x and its eps have one sign), so
-            // the reciprocal is finite wherever the contribution is taken (:648 / :653) and 0 * it adds nothing.
-#ifndef NR_K6_UNFUSED
-            float d1fb = t_first;  // t of the piece's first pixel; pixel k has t_first + k (both of one sign: no cancellation)
-#else
-            float d1fb = d1f0;
-#endif
-            // (d1fb is re-declared opaque per batch below: keeps the compiler from computing all FSEG values of t ahead of the
-            // loop, which costs a register each and pushed the kernel into spilling)
-            auto visit = [&](float diff, int k) {
-                const float dm = (diff <= 0.0f) ? 0.0f : diff;
-#ifndef NR_K6_UNFUSED
-                const float t = d1fb + (float)k;                              // (d1fb: the piece's first t, see below)
-                const float y0 = __builtin_fmaf(c0k, t, e0), y1 = __builtin_fmaf(c1k, t, e1);  // :649-650 / :654-655
-#else
-                const float t = (d1fb + (float)k) - cross;
-                const float x0 = c0k * t, x1 = c1k * t;                       // :649 / :654 (2 / S folded into c)
-                const float y0 = x0 + e0, y1 = x1 + e1;                       // :650 / :655
-#endif
-                f0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), f0);      // :651
-                f1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), f1);      // :656
-            };
-            if (cls == 0) {
-                // U: gradients only; the next batch's LDS reads are in flight while this one is evaluated
-                float4 gc[NR_K6_FB], gn[NR_K6_FB];
-                float ac[NR_K6_FB], an[NR_K6_FB];
-#pragma unroll
-                for (int j = 0; j < NR_K6_FB; ++j) {
-                    gc[j] = gn[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    ac[j] = an[j] = 0.0f;
-                    if (RGB) gc[j] = *reinterpret_cast<const float4 *>(gp + 4 * j);
-                    else ac[j] = gp[j];
+        for (int id = lo + tid; rfl(id) < hi; id += BAND_THREADS) {  // (wave-uniform trip count: all 64 lanes stay together)
+            const int wid = rfl(id);     // ids of a wave are 64 consecutive numbers from a multiple of 64: one class per wave
+            const int cls = wid < MA ? 0 : (wid < SA ? 1 : 2);
+            const int cls_end = min(hi, cls == 0 ? TU : (cls == 1 ? MA + TM : (wid < LA ? SA + TS : total_ids)));
+            if (wid >= cls_end) continue;  // a wave of padding ids
+            // a lane on a padding id behind its class walks piece 0 of line 0 (valid LDS addresses) and throws the result away
+            const bool valid = id < cls_end;
+            const unsigned desc = valid ? (wide ? q32[id - lo] : (unsigned)q16[id - lo]) : 0u;
+            const int line = (int)(desc & 0xffu), seg = (int)(desc >> 8);
+            const BandLine *L = &s_line[line];
+            const int4 h = *reinterpret_cast<const int4 *>(L);
+            const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
+            const int flags = (h.z >> 24) & 0xff;
+            const int ld = (h.z >> 16) & 0xff, base = ld * SP;
+            const int d1_in = h.z & 0xffff;
+            const int out_from = h.y & 0xffff, out_to = h.y >> 16;
+            // class G: which sweep and which pixels
+            bool mode_in = false;
+            int s_from = out_from + seg * FSEG, s_to = s_from + FSEG - 1;
+            if (cls == 2) {
+                const int in_from = h.x & 0xffff, in_to = h.x >> 16;
+                const int il = in_to - in_from + 1;
+                const int n_in = il > 0 ? (il + FSEG - 1) / FSEG : 0;
+                mode_in = seg < n_in;
+                if (mode_in) { s_from = in_from + seg * FSEG; s_to = min(s_from + FSEG - 1, in_to); }
+                else { s_from = out_from + ((out_to - out_from + 1) / FSEG) * FSEG; s_to = out_to; }
+            }
+            // reference colour: the OUT sweep compares with the in pixel, the IN sweep with the out pixel
+            const int lref = base + (mode_in ? d1_in + ((flags & 8) ? 1 : -1) : d1_in);
+            float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
+            float ba = 0.0f, br = 0.0f, bgn = 0.0f, bb = 0.0f;  // colour of an uncovered pixel
+            if (RGB) {
+                const float4 q = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)lref);
+                ra = q.x; rr = q.y; rg = q.z; rb = q.w;
+                const float4 w = *reinterpret_cast<const float4 *>(px.bg);
+                ba = w.x; br = w.y; bgn = w.z; bb = w.w;
+            } else {
+                ra = px.c[lref];
+                ba = px.bg[0];
+            }
+            // diff = sum_c (I_c - ref_c) * g_c with the reference's operations in its order (:631-638 / :709-716; its leading
+            // `0 +` only turns a -0 into +0, which no later step can tell apart).  An uncovered pixel has the background colour
+            // (K5), whose difference to the reference colour is a constant of the piece.
+            const float dba = ba - ra, dbr = br - rr, dbg = bgn - rg, dbb = bb - rb;
+            const float cross = c.x, c0k = c.y, c1k = c.z;
+            const int fnr = __float_as_int(c.w);
+            // (tolerance mode: the dot product as fused multiply-adds -- 19 -> 13 VALU instructions per uncovered pixel with
+            // the fused `c * t + eps` below, 23 -> 17 per covered one; `diff <= 0` may then decide differently from :647 where
+            // diff is within ~3 roundings of 0, about a term of the size of a rounding.  The exact mode keeps the products and
+            // sums apart.)
+            constexpr bool FUSE = !EXACT && k6::FUSED_DIFF;
+            auto bg_diff = [&](const float4 &g4, float ga) {
+                if (!RGB) return dba * ga;
+                float d;
+                if constexpr (FUSE) {
+                    d = ALPHA ? __builtin_fmaf(dbr, g4.y, dba * g4.x) : dbr * g4.y;
+                    d = __builtin_fmaf(dbg, g4.z, d);
+                    d = __builtin_fmaf(dbb, g4.w, d);
+                } else {
+                    d = ALPHA ? dba * g4.x + dbr * g4.y : dbr * g4.y;
+                    d += dbg * g4.z;
+                    d += dbb * g4.w;
                 }
-#pragma unroll
-                for (int kb = 0; kb < FSEG; kb += NR_K6_FB) {
-                    asm volatile("" : "+v"(d1fb));
-                    if (kb + NR_K6_FB < FSEG) {
-#pragma unroll
-                        for (int j = 0; j < NR_K6_FB; ++j) {
-                            if (RGB) gn[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + NR_K6_FB + j));
-                            else an[j] = gp[kb + NR_K6_FB + j];
+                return d;
+            };
+            auto own_diff = [&](const float4 &c4, float ca, const float4 &g4, float ga) {  // c4 / ca: the pixel's colour
+                if (!RGB) return (ca - ra) * ga;
+                float d;
+                if constexpr (FUSE) {
+                    d = ALPHA ? __builtin_fmaf(c4.y - rr, g4.y, (c4.x - ra) * g4.x) : (c4.y - rr) * g4.y;
+                    d = __builtin_fmaf(c4.z - rg, g4.z, d);
+                    d = __builtin_fmaf(c4.w - rb, g4.w, d);
+                } else {
+                    d = ALPHA ? (c4.x - ra) * g4.x + (c4.y - rr) * g4.y : (c4.y - rr) * g4.y;
+                    d += (c4.z - rg) * g4.z;
+                    d += (c4.w - rb) * g4.w;
+                }
+                return d;
+            };
+            // the reciprocal of the tolerance mode (nr_k6_tune.h: one Newton step brings v_rcp_f32's 1 ulp to ~0.5)
+            auto recip = [&](float y) {
+                float r = __builtin_amdgcn_rcpf(y);
+                if constexpr (k6::NEWTON) r = __builtin_fmaf(__builtin_fmaf(-y, r, 1.0f), r, r);
+                return r;
+            };
+            // the piece's two sums: double in the exact mode (and with NR_K6_BATCH_DOUBLE), float otherwise
+            constexpr bool DSUM = EXACT || k6::BATCH_DOUBLE;
+            typename std::conditional<DSUM, double, float>::type f0 = 0, f1 = 0;
+            if (cls < 2) {
+                // ---- U / M: FSEG pixels of an out sweep, unrolled; one address register per array, compile-time offsets
+                const int l0 = base + s_from;
+                const float d1f0 = (float)s_from;
+                const float t_first = d1f0 - cross;
+                const float e0 = (0.0f < c0k * t_first) ? eps_f : -eps_f, e1 = (0.0f < c1k * t_first) ? eps_f : -eps_f;
+                const float *gp = px.g + (RGB ? 4 : 1) * (size_t)l0, *cp = px.c + (RGB ? 4 : 1) * (size_t)l0;
+                // One visit without a branch: the visits of a batch are independent instruction chains that the scheduler
+                // interleaves.  Tolerance mode: y is never 0 (x and its eps have one sign), so the reciprocal is finite
+                // wherever the contribution is taken (:648 / :653) and 0 * it adds nothing.
+                // d1fb: t of the piece's first pixel (fused dist: pixel k has t_first + k, both of one sign: no
+                // cancellation) or its d1.  It is re-declared opaque per batch below: that keeps the compiler from computing
+                // all FSEG values of t ahead of the loop, which costs a register each and pushed the kernel into spilling.
+                constexpr bool T_INCR = !EXACT && k6::FUSED_DIST;
+                float d1fb = T_INCR ? t_first : d1f0;
+                float b0 = 0.0f, b1 = 0.0f;  // (NR_K6_BATCH_DOUBLE: float sums of one batch)
+                auto visit = [&](float diff, int k) {
+                    if constexpr (EXACT) {
+                        const float t = (d1fb + (float)k) - cross;
+                        const float q0 = exact_term(diff, c0k, t), q1 = exact_term(diff, c1k, t);
+                        const bool skip = diff <= 0.0f;                            // :647 (a NaN diff goes through)
+                        f0 -= (double)(skip ? 0.0f : q0);                          // :651
+                        f1 -= (double)(skip ? 0.0f : q1);                          // :656
+                    } else {
+                        const float dm = (diff <= 0.0f) ? 0.0f : diff;
+                        float y0, y1;
+                        if constexpr (T_INCR) {
+                            const float t = d1fb + (float)k;
+                            y0 = __builtin_fmaf(c0k, t, e0); y1 = __builtin_fmaf(c1k, t, e1);  // :649-650 / :654-655
+                        } else {
+                            const float t = (d1fb + (float)k) - cross;
+                            y0 = c0k * t + e0; y1 = c1k * t + e1;
+                        }
+                        if constexpr (k6::BATCH_DOUBLE) {
+                            b0 = __builtin_fmaf(-dm, recip(y0), b0);
+                            b1 = __builtin_fmaf(-dm, recip(y1), b1);
+                        } else {
+                            f0 = __builtin_fmaf(-dm, recip(y0), f0);                   // :651
+                            f1 = __builtin_fmaf(-dm, recip(y1), f1);                   // :656
                         }
                     }
+                };
+                auto end_batch = [&]() {
+                    if constexpr (!EXACT && k6::BATCH_DOUBLE) { f0 += (double)b0; f1 += (double)b1; b0 = b1 = 0.0f; }
+                };
+                if (cls == 0) {
+                    // U: gradients only; the next batch's LDS reads are in flight while this one is evaluated
+                    float4 gc[FB], gn[FB];
+                    float ac[FB], an[FB];
 #pragma unroll
-                    for (int j = 0; j < NR_K6_FB; ++j) visit(bg_diff(gc[j], ac[j]), kb + j);
+                    for (int j = 0; j < FB; ++j) {
+                        gc[j] = gn[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        ac[j] = an[j] = 0.0f;
+                        if (RGB) gc[j] = *reinterpret_cast<const float4 *>(gp + 4 * j);
+                        else ac[j] = gp[j];
+                    }
 #pragma unroll
-                    for (int j = 0; j < NR_K6_FB; ++j) { gc[j] = gn[j]; ac[j] = an[j]; }
-                    __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting every batch's reads to the top)
+                    for (int kb = 0; kb < FSEG; kb += FB) {
+                        asm volatile("" : "+v"(d1fb));
+                        if (kb + FB < FSEG) {
+#pragma unroll
+                            for (int j = 0; j < FB; ++j) {
+                                if (RGB) gn[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + FB + j));
+                                else an[j] = gp[kb + FB + j];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < FB; ++j) visit(bg_diff(gc[j], ac[j]), kb + j);
+                        end_batch();
+#pragma unroll
+                        for (int j = 0; j < FB; ++j) { gc[j] = gn[j]; ac[j] = an[j]; }
+                        __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting every batch's reads to the top)
+                    }
+                } else {
+                    // M: every pixel's colour as well -- an uncovered one holds the background colour (K5), so the same
+                    // expression serves both
+#pragma unroll
+                    for (int kb = 0; kb < FSEG; kb += FB) {
+                        asm volatile("" : "+v"(d1fb));
+                        float4 g4[FB], c4[FB];
+                        float ga[FB], ca[FB];
+#pragma unroll
+                        for (int j = 0; j < FB; ++j) {
+                            g4[j] = c4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            ga[j] = ca[j] = 0.0f;
+                            if (RGB) {
+                                g4[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + j));
+                                c4[j] = *reinterpret_cast<const float4 *>(cp + 4 * (kb + j));
+                            } else {
+                                ga[j] = gp[kb + j];
+                                ca[j] = cp[kb + j];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < FB; ++j) visit(own_diff(c4[j], ca[j], g4[j], ga[j]), kb + j);
+                        end_batch();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else {
-                // M: every pixel's colour as well -- an uncovered one holds the background colour (K5), so the same
-                // expression serves both
-#pragma unroll
-                for (int kb = 0; kb < FSEG; kb += NR_K6_FB) {
-                    asm volatile("" : "+v"(d1fb));
-                    float4 g4[NR_K6_FB], c4[NR_K6_FB];
-                    float ga[NR_K6_FB], ca[NR_K6_FB];
-#pragma unroll
-                    for (int j = 0; j < NR_K6_FB; ++j) {
-                        g4[j] = c4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        ga[j] = ca[j] = 0.0f;
-                        if (RGB) {
-                            g4[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + j));
-                            c4[j] = *reinterpret_cast<const float4 *>(cp + 4 * (kb + j));
-                        } else {
-                            ga[j] = gp[kb + j];
-                            ca[j] = cp[kb + j];
-                        }
+                // ---- G: a piece of an in sweep or the remainder of an out sweep, the general loop
+                const int own_mask = mode_in ? -1 : 0;
+                float d1f = (float)s_from;
+                float b0 = 0.0f, b1 = 0.0f;
+                for (int l = base + s_from; l <= base + s_to; ++l, d1f += 1.0f) {
+                    // face index, gradients and colour are requested together (one LDS round trip)
+                    const int fi = px.fi[l];
+                    float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c4 = g4;
+                    float ga = 0.0f, ca = 0.0f;
+                    if (RGB) { g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l); c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l); }
+                    else { ga = px.g[l]; ca = px.c[l]; }
+                    const float diff = own_diff(c4, ca, g4, ga);  // (an uncovered pixel holds the background colour)
+                    // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
+                    // control flow on the sweep kind
+                    if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) continue;
+                    const float t = d1f - cross;
+                    if constexpr (EXACT) {
+                        f0 -= (double)exact_term(diff, c0k, t);                               // :649-651
+                        f1 -= (double)exact_term(diff, c1k, t);                               // :654-656
+                    } else {
+                        const float x0 = c0k * t, x1 = c1k * t;                               // :649 / :654 (2 / S folded into c)
+                        const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                 // :650 / :655
+                        const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
+                        b0 = __builtin_fmaf(-diff, recip(y0), b0);                            // :651
+                        b1 = __builtin_fmaf(-diff, recip(y1), b1);                            // :656
                     }
-#pragma unroll
-                    for (int j = 0; j < NR_K6_FB; ++j) visit(own_diff(c4[j], ca[j], g4[j], ga[j]), kb + j);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (!EXACT) { f0 += b0; f1 += b1; }
             }
-        } else {
-            // ---- G: a piece of an in sweep or the remainder of an out sweep, the general loop
-            const int own_mask = mode_in ? -1 : 0;
-            float d1f = (float)s_from;
-            for (int l = base + s_from; l <= base + s_to; ++l, d1f += 1.0f) {
-                // face index, gradients and colour are requested together (one LDS round trip)
-                const int fi = px.fi[l];
-                float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c4 = g4;
-                float ga = 0.0f, ca = 0.0f;
-                if (RGB) { g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l); c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l); }
-                else { ga = px.g[l]; ca = px.c[l]; }
-                const float diff = own_diff(c4, ca, g4, ga);  // (an uncovered pixel holds the background colour)
-                // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
-                // control flow on the sweep kind
-                if ((((fi ^ fnr) & own_mask) != 0) | (diff <= 0.0f)) continue;
-                const float t = d1f - cross;
-                const float x0 = c0k * t, x1 = c1k * t;                                   // :649 / :654 (2 / S folded into c)
-                const float y0 = x0 + ((0.0f < x0) ? eps_f : -eps_f);                     // :650 / :655
-                const float y1 = x1 + ((0.0f < x1) ? eps_f : -eps_f);
-                f0 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y0), f0);                // :651
-                f1 = __builtin_fmaf(-diff, __builtin_amdgcn_rcpf(y1), f1);                // :656
-            }
+            // :648 / :653: a contribution whose vertex sits on the line is not taken (its coefficient was Inf / NaN)
+            using RunT = typename std::conditional<EXACT || k6::RUNSUM_DOUBLE, double, float>::type;
+            RunT p0 = (valid && (flags & 2)) ? (RunT)f0 : RunT(0), p1 = (valid && (flags & 4)) ? (RunT)f1 : RunT(0);
+            const int key = valid ? line : -1 - (tid & 63);  // (a padding lane: a run of its own)
+            run_sums(key, p0, p1);
+            const double a0 = (double)p0, a1 = (double)p1;
+            if (a0 != 0.0) atomicAdd(&acc[2 * line], a0);
+            if (a1 != 0.0) atomicAdd(&acc[2 * line + 1], a1);
         }
-        NR_WPH(12 + cls);
-        float p0 = (valid && (flags & 2)) ? f0 : 0.0f, p1 = (valid && (flags & 4)) ? f1 : 0.0f;  // :648 / :653
-        const int key = valid ? line : -1 - (tid & 63);  // (a padding lane: a run of its own)
-#ifndef NR_K6_NO_RUNSUM
-        // The pieces of one line sit on neighbouring lanes (consecutive ids), and all of them add to the same two sums: 64
-        // lanes on ~10 addresses make the LDS serialise an atomic per lane.  So the sums of each run of equal lines are formed
-        // with DPP moves first (a segmented scan inside the 16-lane rows; a run that crosses a row is flushed in two parts),
-        // and only the last lane of a run issues the atomic.  The run sums are float like the segment sums they add up (<= 16
-        // of them, a tree of depth 4; in double the moves and selects come in pairs and the step costs what it saves at raster
-        // 256: stage 249 vs 239 us, 946 vs 897 at raster 512); everything behind them stays double.  Which pieces share a run
-        // depends on the order of the line records, so two calls agree to ~1e-6 of the largest gradient, not to the bit.
-        // (All 64 lanes execute this: the loop keeps the wave together.)
-        {
-            const int k1 = dpp_row_shr<1>(-1, key), k2 = dpp_row_shr<2>(-1, key), k4 = dpp_row_shr<4>(-1, key),
-                      k8 = dpp_row_shr<8>(-1, key);
-            float q0 = dpp_row_shr_f<1>(p0), q1 = dpp_row_shr_f<1>(p1);
-            if (k1 == key) { p0 += q0; p1 += q1; }
-            q0 = dpp_row_shr_f<2>(p0); q1 = dpp_row_shr_f<2>(p1);
-            if (k2 == key) { p0 += q0; p1 += q1; }
-            q0 = dpp_row_shr_f<4>(p0); q1 = dpp_row_shr_f<4>(p1);
-            if (k4 == key) { p0 += q0; p1 += q1; }
-            q0 = dpp_row_shr_f<8>(p0); q1 = dpp_row_shr_f<8>(p1);
-            if (k8 == key) { p0 += q0; p1 += q1; }
-            if (dpp_row_shl1(-1, key) == key) p0 = p1 = 0.0f;  // not the last lane of its run
-        }
-#endif
-        const double a0 = (double)p0, a1 = (double)p1;
-#ifdef NR_K6_NO_FLUSH  // development build
-        if (a0 == 12345.0 && a1 == 54321.0)
-#endif
-        {
-        if (a0 != 0.0) { const int i0 = acc_index(line, h.w, 0); if (i0 >= 0) atomicAdd(&acc[i0], a0); else spill(h.w, fnr, 0, a0); }
-        if (a1 != 0.0) { const int i1 = acc_index(line, h.w, 1); if (i1 >= 0) atomicAdd(&acc[i1], a1); else spill(h.w, fnr, 1, a1); }
-        }
-        NR_WPH(15);
     }
-    }
-    NR_WPH_END();
 }
 
-template <bool RGB, bool ALPHA>
-__global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
+// The band kernel.  (launch bounds: three workgroups per CU; the generic exact form carries a double division: two)
+template <bool RGB, bool ALPHA, int MODE>
+__global__ __launch_bounds__(BAND_THREADS, MODE == K6_EXACT ? 4 : 6) void k_bpm_fast(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
     double *__restrict__ scratch, const int *__restrict__ band_lines, const int *__restrict__ band_start,
     const int *__restrict__ lines_ok, const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int SP,
-    float eps_f, int B, int win_lines, int win_scan, int qcap, uint4 *__restrict__ zero16, size_t n_zero16)
+    double eps, float k2s, int B, int win_lines, int qcap, uint4 *__restrict__ zero16, size_t n_zero16)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
+    // XCD-aware placement (nr_device.h): bands of one image share cache lines -- 8 adjacent 4-column bands sit in the same
+    // 128-byte line of every map row, and the horizontal pass re-reads what the vertical pass just fetched -- so all
+    // 2 * n_bands workgroups of an image are given ids that land on ONE XCD (one L2).  Measured in round 1: 613 -> 477 us.
+    // (The same mapping on the forward and gather kernels changed nothing or cost 5 %: their reads are not shared.)
     const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
     const unsigned total_wg = n_bands * 2u * (unsigned)B;
-    const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_band)
+    const unsigned logical = xcd_block(total_wg);
     if (logical >= total_wg) return;
     if (n_zero16) {
         // The fused backward's zero fill of grad_textures (the K7 gather behind this kernel stores only the listed faces'
@@ -1807,15 +1412,11 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
         for (size_t k = z_lo + tid; k < z_hi; k += BAND_THREADS) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
     }
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
-#ifdef NR_K6_ONLY_AXIS  // development build: the workgroups of one sweep axis only (how much slower is the column pass?)
-    if (axis != NR_K6_ONLY_AXIS) return;
-#endif
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
     const size_t bidx = ((size_t)b * 2 + axis) * n_bands + band;
     const int n_band_lines = band_lines[bidx];
     if (n_band_lines == 0) return;  // step 0: no visible face has a line here
-    NR_PHASE_BEGIN();
 
     size_t off = 0;
     auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
@@ -1829,17 +1430,14 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
     px.cov = (unsigned *)carve((size_t)W * px.CW * 4);
     px.span = (int *)carve(4 * 2 * 4);  // (W <= 4 lines)
     const bool wide = S > 255 * FSEG;  // piece numbers beyond 8 bits: 32-bit descriptors
-    // The rest of the workgroup's LDS is split between the line window (32 B record + the private part of the path: two
-    // double sums per line, or the scan path's compaction records and accumulator slots) and the segment queue by the host
-    // (fast_band_config).  (A per-band split inside the kernel -- equal windows, as few as let a window's segments through the
-    // queue in one round -- was measured and lost to the fixed split, 258 vs 242 us: it trades windows of 224 lines with two
-    // rounds for twice as many windows.)
-    const int WIN = min(win_lines, win_scan);  // (win_lines: the cap that keeps a window's segment counts in 16 bits)
-    win_lines = WIN;
-    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * WIN);
-    void *s_queue = carve((size_t)qcap * (wide ? 4 : 2));  // segment descriptors of a window (or of a round of it)
+    // The rest of the workgroup's LDS is split between the line window (32 B record + two double sums per line) and the piece
+    // queue by the host (fast_band_config).  (A per-band split inside the kernel -- equal windows, as few as let a window's
+    // pieces through the queue in one round -- was measured and lost to the fixed split, 258 vs 242 us: it trades windows of
+    // 224 lines with two rounds for twice as many windows.)
+    BandLine *s_line = (BandLine *)carve(sizeof(BandLine) * win_lines);
+    double *s_lacc = (double *)carve(16 * (size_t)win_lines);  // [win_lines][2] sums of each line for its edge's two vertices
+    void *s_queue = carve((size_t)qcap * (wide ? 4 : 2));     // piece descriptors of a window (or of a round of it)
     int *s_tmp = (int *)carve(4 * 16);
-    unsigned char *rest = smem + off;  // the two paths below lay out what is left differently
 
     // ---- 1. stage the band
     const size_t img = (size_t)b * S * S;
@@ -1856,123 +1454,83 @@ __global__ __launch_bounds__(BAND_THREADS, 6) void k_bpm_fast(
         px.span[2 * tid] = first;
         px.span[2 * tid + 1] = last;
     }
-    NR_PHASE(1);
 
-    if (lines_ok[b]) {
-        // ================= records path: the band's line records were written by k_line_setup =================
-        double *s_lacc = (double *)rest;  // [WIN][2] sums of each line for its edge's two vertices
-        const BandLine *recs = line_buf + (size_t)b * cap + band_start[bidx];
-        for (int win = 0; win < n_band_lines; win += win_lines) {
-            const int n_win = min(n_band_lines - win, win_lines);
+    // ---- 2. - 4. window by window.  Records path: the band's line records were written by k_line_setup.  Scan path (an image
+    // with more lines than the record buffer holds, or NR_FLAG_K6_SCAN): the image's visible faces are scanned in chunks of
+    // one face per thread and the lines of the chunk that fall into this band are set up in place.  The scan path keeps
+    // nothing in registers across the sweeps -- it recomputes its chunk's line counts for every window -- so that the kernel's
+    // register budget is the records path's.
+    const bool use_rec = lines_ok[b] != 0;
+    const BandLine *recs = line_buf + (size_t)b * cap + band_start[bidx];
+    const int n_vis = use_rec ? 0 : vis_count[b];
+    const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
+    int chunk = 0, win = 0;  // (scan path) first list position of the chunk; (both) first line of the next window
+    for (;;) {
+        int n_win;
+        if (use_rec) {
+            if (win >= n_band_lines) break;
+            n_win = min(n_band_lines - win, win_lines);
             if (tid < n_win) s_line[tid] = recs[win + tid];
             if (tid < 2 * n_win) s_lacc[tid] = 0.0;
-            __syncthreads();
-            NR_PHASE(5);
-#ifndef NR_K6_NO_SWEEPS
-            fast_sweeps<RGB, ALPHA>(px, s_line, n_win, SP, eps_f, s_lacc, [](int line, int, int k) { return 2 * line + k; },
-                                    [](int, int, int, double) {}, s_queue, qcap, wide, reinterpret_cast<unsigned long long *>(s_tmp));
-#endif
-            __syncthreads();
-            NR_PHASE(6);
-            if (tid < 2 * n_win) {  // line sums -> global double scratch [list position][vertex][x|y]
-                const double a = s_lacc[tid];
-                if (a != 0.0) {
-                    const int tgt = s_line[tid >> 1].tgt;
-                    const int pos = tgt & 0x0fffffff, v = (tid & 1) ? (tgt >> 30) & 3 : (tgt >> 28) & 3;
-                    atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * v + (1 - axis), a);
+            win += win_lines;
+        } else {
+            if (chunk >= n_vis) break;
+            // one visible face per thread: lines of its 3 edges inside the band
+            int nl = 0;
+            int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
+            if (chunk + tid < n_vis) {
+                const unsigned *r = rng_ba + (size_t)(chunk + tid) * 3;
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    const unsigned pr = r[e];
+                    const int lo = max((int)(pr & 0xffffu), band_lo), hi = min((int)(pr >> 16), band_hi);
+                    if (hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
                 }
             }
-            __syncthreads();
-            NR_PHASE(7);
-        }
-        return;
-    }
-
-    // ================= scan path (an image with more lines than the record buffer holds): as k_bpm_band =================
-    int *s_rec = (int *)rest;
-    int *s_recfn = s_rec + WIN;
-    double *s_acc = (double *)(s_recfn + WIN);          // WIN is a multiple of 4: 8-byte aligned
-    int *s_slotpos = (int *)(s_acc + 3 * FAST_ACC_SLOTS);
-    if (tid < 3 * FAST_ACC_SLOTS) s_acc[tid] = 0.0;
-    __syncthreads();
-    const int n_vis = vis_count[b];
-    const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
-    for (int chunk = 0; chunk < n_vis; chunk += BAND_THREADS) {
-        // ---- 2. one visible face per thread: lines of its 3 edges inside the band
-        int fn = -1, nl = 0;
-        int e_lo[3] = {0, 0, 0}, e_n[3] = {0, 0, 0};
-        if (chunk + tid < n_vis) {
-            fn = vis_list[(size_t)b * F + chunk + tid];
-            const unsigned *r = rng_ba + (size_t)(chunk + tid) * 3;
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-                const unsigned pr = r[e];
-                const int lo = max((int)(pr & 0xffffu), band_lo), hi = min((int)(pr >> 16), band_hi);
-                if (hi >= lo) { e_lo[e] = lo; e_n[e] = hi - lo + 1; nl += e_n[e]; }
+            int total_lines = 0;
+            const int line_off = block_excl_scan(nl, s_tmp, &total_lines);
+            if (win >= total_lines) {  // (uniform) this chunk is done
+                chunk += BAND_THREADS;
+                win = 0;
+                continue;
             }
-        }
-        int total_packed = 0;
-        const int packed_off = block_excl_scan(nl | ((nl > 0) << 20), s_tmp, &total_packed);
-        const int line_off = packed_off & 0xfffff, slot = packed_off >> 20;
-        const int total_lines = total_packed & 0xfffff;
-        if (nl > 0 && slot < FAST_ACC_SLOTS) s_slotpos[slot] = chunk + tid;
-        NR_PHASE(2);
-
-        for (int win = 0; win < total_lines; win += win_lines) {
+            n_win = min(total_lines - win, win_lines);
+            // (list position | edge << 28, line) of the window's lines, parked where the line sums will be
+            int2 *s_rec = reinterpret_cast<int2 *>(s_lacc);
             if (nl > 0 && line_off < win + win_lines && line_off + nl > win) {
                 int k = line_off;
 #pragma unroll
                 for (int e = 0; e < 3; e++)
                     for (int j = 0; j < e_n[e]; j++, k++)
-                        if (k >= win && k < win + win_lines) {
-                            s_rec[k - win] = slot | (e << 16) | ((e_lo[e] + j - band_lo) << 18);
-                            s_recfn[k - win] = fn;
-                        }
+                        if (k >= win && k < win + win_lines) s_rec[k - win] = make_int2((chunk + tid) | (e << 28), e_lo[e] + j - band_lo);
             }
             __syncthreads();
-            const int n_win = min(total_lines - win, win_lines);
-            NR_PHASE(3);
-
-            // ---- 3. line setup, one line per thread
-            if (tid < n_win) {
-                const int rec = s_rec[tid];
-                const int slot_l = rec & 0xffff, e = (rec >> 16) & 3, ld = rec >> 18;
-                const int rfn = s_recfn[tid];
+            int2 rec = make_int2(0, 0);
+            if (tid < n_win) rec = s_rec[tid];
+            __syncthreads();
+            if (tid < n_win) {  // line setup, one line per thread
+                const int pos = rec.x & 0x0fffffff, e = (rec.x >> 28) & 3, ld = rec.y;
+                const int rfn = vis_list[(size_t)b * F + pos];
                 s_line[tid] = make_fast_line(faces + ((size_t)b * F + rfn) * 9, e, axis, band_lo + ld, ld, S, rfn,
-                                             slot_l | (e << 16) | (((e + 1) % 3) << 18),
-                                             [&](int d1) { return px.fi[ld * SP + d1]; });
+                                             pos | (e << 28) | (((e + 1) % 3) << 30),
+                                             [&](int d1) { return px.fi[ld * SP + d1]; }, k2s);
             }
-            __syncthreads();
-            NR_PHASE(4);
-#ifndef NR_K6_NO_SWEEPS
-            fast_sweeps<RGB, ALPHA>(
-                px, s_line, n_win, SP, eps_f, s_acc,
-                [](int, int tgt, int k) {
-                    const int sl = tgt & 0xffff;
-                    return sl < FAST_ACC_SLOTS ? 3 * sl + ((tgt >> (k ? 18 : 16)) & 3) : -1;
-                },
-                [&](int tgt, int fnr, int k, double a) {  // more faces with lines in this pass than LDS slots
-                    const int pos = vis_position(vis_list + (size_t)b * F, n_vis, fnr);
-                    atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * ((tgt >> (k ? 18 : 16)) & 3) + (1 - axis), a);
-                },
-                s_queue, qcap, wide, reinterpret_cast<unsigned long long *>(s_tmp));
-#endif
-            __syncthreads();
-            NR_PHASE(6);
+            if (tid < 2 * n_win) s_lacc[tid] = 0.0;
+            win += win_lines;
         }
-
-        // ---- 5. per-face sums of this chunk -> global double scratch
-        {
-            const int n_slots = min(total_packed >> 20, FAST_ACC_SLOTS);
-            if (tid < 3 * n_slots) {
-                const int sl = tid / 3, v = tid - 3 * sl;
-                const double a = s_acc[tid];
-                if (a != 0.0) atomicAdd(scratch + ((size_t)b * F + s_slotpos[sl]) * 6 + 2 * v + (1 - axis), a);
-                s_acc[tid] = 0.0;
+        __syncthreads();
+        fast_sweeps<RGB, ALPHA, MODE>(px, s_line, n_win, SP, eps, S, s_lacc, s_queue, qcap, wide,
+                                      reinterpret_cast<unsigned long long *>(s_tmp));
+        __syncthreads();
+        if (tid < 2 * n_win) {  // line sums -> global double scratch [list position][vertex][x|y]
+            const double a = s_lacc[tid];
+            if (a != 0.0) {
+                const int tgt = s_line[tid >> 1].tgt;
+                const int pos = tgt & 0x0fffffff, v = (tid & 1) ? (tgt >> 30) & 3 : (tgt >> 28) & 3;
+                atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * v + (1 - axis), a);
             }
         }
         __syncthreads();
-        NR_PHASE(7);
     }
 }
 
@@ -2047,47 +1605,18 @@ ListsLayout lists_layout(int B, int F)
     return L;
 }
 
-#ifndef NR_LDS_BUDGET
-#define NR_LDS_BUDGET (53 * 1024)
-#endif
-constexpr size_t LDS_BUDGET = NR_LDS_BUDGET;  // three workgroups per 160 KB CU, allocation granules of 512 bytes included (3 x 53.5 KB would not fit)
-// LDS of k_bpm_band (exact kernel): band width (lines per workgroup) for the given raster size and modes; 0 = does not fit
-// (global fallback)
-int band_width(int S, bool rgb, bool alpha, size_t *lds_bytes, int w_max = 4)
-{
-    const size_t per_px = 4 + (alpha ? 8 : 0) + (rgb ? 24 : 0);
-    const size_t SP = (size_t)S + 4;
-    // W is capped at 4: wider bands mean fewer, longer-running workgroups whose staging / scan / sweep phases overlap
-    // less (measured, alpha-only headline scene: W = 8 -> 975 us, W = 4 -> 586 us)
-    for (int W = w_max; W >= 1; W >>= 1) {
-        const size_t fixed = (sizeof(BandLine) + 12) * (size_t)BAND_WIN + 8 * 3 * ACC_SLOTS + 4 * ACC_SLOTS + 64 + 8 * 16;
-        const size_t need = (size_t)W * SP * per_px + fixed;
-        if (need <= LDS_BUDGET || (W == 1 && need <= 160 * 1024)) {
-            *lds_bytes = need;
-            return W;
-        }
-    }
-    return 0;
-}
-
 // LDS of k_bpm_fast: pixel arrays [W][SP] (face index 4 B, gradients and colours 16 B each -- 4 B each for alpha alone),
-// coverage bits, and what is left is split between the line window (32 B record + 16 B for the records path's two double
-// sums per line, or the scan path's compaction records and accumulator slots) and the segment queue (2 or 4 B per
-// descriptor).  Returns W (0: the raster does not fit, global fallback).
+// coverage bits, and what is left is split between the line window (32 B record + two double sums per line) and the piece
+// queue (2 or 4 B per descriptor).  Returns W (0: the raster does not fit, global fallback).
 int fast_band_config(int S, bool rgb, int w_max, size_t *lds_bytes, int *win, int *qcap)
 {
     const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 255 * FSEG ? 4 : 2;
-    // segments per line the split is made for: measured, stage times in us, raster 256: S/22 (192 lines, 3072 descriptors)
+    // pieces per line the split is made for: measured, stage times in us, raster 256: S/22 (192 lines, 3072 descriptors)
     // 240, S/32 (224, 2560) 230, S/48 (256, 2048: two rounds per window) 267; raster 512: S/22 (160, 4096) 906, S/32 (192,
     // 3584) 891, S/48 (224, 2560) 766 -- a band of a 512 x 512 teapot view has ~185 lines: one window instead of two
-#ifndef NR_K6_SPL_DIV
-#define NR_K6_SPL_DIV (S <= 320 ? 32 : 48)
-#endif
-    const size_t segs_per_line = (size_t)S / NR_K6_SPL_DIV + 3;
-    auto lines_bytes = [&](int ww) {
-        const size_t a = 16 * (size_t)ww, b = 8 * (size_t)ww + 28 * (size_t)FAST_ACC_SLOTS;
-        return sizeof(BandLine) * (size_t)ww + (a > b ? a : b);
-    };
+    const size_t segs_per_line = (size_t)S / (S <= 320 ? 32 : 48) + 3;
+    const size_t LDS_BUDGET = k6::LDS_BUDGET;
+    auto lines_bytes = [&](int ww) { return (sizeof(BandLine) + 16) * (size_t)ww; };
     for (int W = w_max; W >= 1; W >>= 1) {
         const size_t px = (size_t)W * SP * per_px + (size_t)W * (((SP + 31) / 32 + 3) / 4 * 4) * 4 + 16 /* bg */ + 32 /* spans */ + 64 /* scan */ +
                           8 * 16 /* alignment slack */;
@@ -2135,35 +1664,21 @@ struct LdsLimit {
     }
 };
 
-template <bool RGB, bool ALPHA, bool POW2>
-int launch_band(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
-                const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
-                const int *band_lines, int B, int F, int S, int W, size_t lds, double eps, int win_lines, hipStream_t st)
-{
-    static LdsLimit limit;  // one per instantiation
-    auto kern = k_bpm_band<RGB, ALPHA, POW2>;
-    if (int rc = limit.ensure((const void *)kern, lds)) return rc;
-    const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
-    const dim3 grid(xcd_grid(total_wg));  // 1-D: the kernel maps ids to (image, axis, band) per XCD
-    hipLaunchKernelGGL(kern, grid, dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha, vis_list,
-                       vis_count, rng, scratch, band_lines, F, S, W, S + 4, eps, B, win_lines);
-    return 0;
-}
-
-template <bool RGB, bool ALPHA>
+template <bool RGB, bool ALPHA, int MODE>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
                 const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
-                int B, int F, int S, int W, size_t lds, double eps, int win_lines, int win_scan, int qcap, hipStream_t st,
+                int B, int F, int S, int W, size_t lds, double eps, float k2s, int win_lines, int qcap, hipStream_t st,
                 void *zero_ptr, size_t zero_bytes)
 {
-    static LdsLimit limit;
-    auto kern = k_bpm_fast<RGB, ALPHA>;
+    static LdsLimit limit;  // one per instantiation
+    auto kern = k_bpm_fast<RGB, ALPHA, MODE>;
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
+    // 1-D grid: the kernel maps ids to (image, axis, band) per XCD
     hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
-                       (float)eps, B, win_lines, win_scan, qcap, (uint4 *)zero_ptr, zero_bytes / 16);
+                       eps, k2s, B, win_lines, qcap, (uint4 *)zero_ptr, zero_bytes / 16);
     return 0;
 }
 
@@ -2204,12 +1719,9 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     int win = BAND_WIN, qcap = 0;
     // Narrower bands when the launch would have few band workgroups (small batches): the chip holds 768 of them at a time and
     // half of a teapot view's bands are empty; 16 views: stage 113 -> 104 us with W = 2, 4 views 70 -> 50, 1 view 66 -> 40 (W = 1).
-#ifndef NR_K6_WMAX
-#define NR_K6_WMAX 4
-#endif
-    int w_max = NR_K6_WMAX;
+    int w_max = k6::WMAX;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
-    const int W = exact ? band_width(S, rgb, alpha, &lds, w_max) : fast_band_config(S, rgb, w_max, &lds, &win, &qcap);
+    const int W = fast_band_config(S, rgb, w_max, &lds, &win, &qcap);
     if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
         const dim3 grid((unsigned)n), block(WAVE);
         if (rgb && alpha)
@@ -2249,9 +1761,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     }
     int *band_start = (int *)(ws + L.start_off), *band_cursor = (int *)(ws + L.cursor_off), *lines_ok = (int *)(ws + L.ok_off);
     BandLine *line_buf = (BandLine *)(ws + L.lines_off);
-    // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
-    // the records path serves the default kernel; the exact kernel and NR_FLAG_K6_SCAN keep the in-kernel face scan
-    const bool use_records = !exact && !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 3072;  // grid.y and 72 KB of LDS in k_line_setup
+    // line records from k_line_setup, unless NR_FLAG_K6_SCAN asks for the in-kernel face scan (tests) or the launch is
+    // outside k_line_setup's shape (grid.y, 72 KB of LDS)
+    const bool use_records = !(flags & NR_FLAG_K6_SCAN) && B <= 65535 && n_bands <= 3072;
+    // the distance coefficients of a record: x 2 / S up front in the tolerance mode, as the reference has them in the exact one
+    const float k2s = exact ? 1.0f : 2.0f / (float)S;
     const size_t cap = use_records ? L.cap : 0;  // capacity 0: every image is told to take the scan path
     int n_sum = 0;  // chunk rows per image that the consumer adds up (0: the band table is ready)
     // (k_compact_par keeps its chunk's 2 * n_bands line counters in LDS: 32 KB at most)
@@ -2273,9 +1787,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                            lds_counters ? (size_t)2 * n_bands * sizeof(int) : 0, st, vflags, chunk_count, vis_list, vis_count,
                            slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W, lds_counters,
                            defer ? grad_faces : (float *)nullptr);
-        if (!exact)
-            hipLaunchKernelGGL(k_band_scan, dim3((unsigned)B), dim3(256), 0, st, band_lines, band_start, band_cursor, lines_ok,
-                               n_bands, cap, 0);
+        hipLaunchKernelGGL(k_band_scan, dim3((unsigned)B), dim3(256), 0, st, band_lines, band_start, band_cursor, lines_ok,
+                           n_bands, cap, 0);
     }
     if (use_records) {
         static LdsLimit ls_limit;
@@ -2283,37 +1796,33 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         hipLaunchKernelGGL(k_line_setup, dim3((unsigned)((F + LS_FACES - 1) / LS_FACES), (unsigned)B), dim3(256),
                            (size_t)6 * n_bands * sizeof(int), st, faces, face_index_map, vis_list, vis_count, rng,
                            (const int *)(ws + L.cband_off), n_sum, band_lines, band_start, band_cursor, lines_ok, line_buf, L.cap, F,
-                           S, W, n_bands);
+                           S, W, n_bands, k2s);
     }
-    // lines per window: the packed segment scans keep the count of full segments in 16 bits (<= win * 2 * S / SEG)
-    int win_lines = max(1, min(BAND_WIN, (int)(65535ll * (exact ? SEG : FSEG) / (2ll * S))));
-    if (!exact) win_lines = max(4, win_lines & ~3);  // (k_bpm_fast lays 8-byte data out behind win_lines ints)
+    // lines per window: the packed piece scan keeps each class count in 16 bits (<= win * 2 * S / FSEG pieces)
+    const int win_lines = min(win, max(4, min(BAND_WIN, (int)(65535ll * FSEG / (2ll * S))) & ~3));
     int rc;
-    if (exact) {
-        const bool pow2 = (S & (S - 1)) == 0;
-#define NR_BAND(R, A)                                                                                                  \
-    (pow2 ? launch_band<R, A, true>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list,  \
-                                    vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st)                       \
-          : launch_band<R, A, false>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, \
-                                     vis_count, rng, scratch, band_lines, B, F, S, W, lds, eps, win_lines, st))
-        rc = (rgb && alpha) ? NR_BAND(true, true) : (rgb ? NR_BAND(true, false) : NR_BAND(false, true));
-#undef NR_BAND
-    } else {
-#define NR_FAST(R, A)                                                                                                   \
-    launch_fast<R, A>(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch, \
-                      band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, win_lines, win, qcap, st,     \
-                      zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0)
+    {
         // (a fill that rides in the band kernel: 16-byte words, and a slice per workgroup that is small next to the
-        // workgroup's own work -- NR_K6_FOLD_KB per band workgroup: 4 KB at the headline size, 61 KB on config 4; config 5's
+        // workgroup's own work -- k6::FOLD_KB per band workgroup: 4 KB at the headline size, 61 KB on config 4; config 5's
         // 4 GB would be 2 MB for each of 2048 workgroups and go at 7 TB/s through a fill launch instead)
-#ifndef NR_K6_FOLD_KB
-#define NR_K6_FOLD_KB 128
-#endif
         const size_t band_wgs = (size_t)((S + W - 1) / W) * 2 * (size_t)B;
         const bool zero_ok = zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
-                             zero_bytes <= band_wgs * ((size_t)NR_K6_FOLD_KB << 10);
-        rc = (rgb && alpha) ? NR_FAST(true, true) : (rgb ? NR_FAST(true, false) : NR_FAST(false, true));
-#undef NR_FAST
+                             zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10);
+        const int mode = !exact ? K6_FAST : ((S & (S - 1)) == 0 ? K6_EXACT_POW2 : K6_EXACT);
+        auto launch = [&](auto r, auto a, auto m) {
+            return launch_fast<decltype(r)::value, decltype(a)::value, decltype(m)::value>(
+                faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
+                band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, k2s, win_lines, qcap, st,
+                zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
+        };
+        using T = std::true_type;
+        using N = std::false_type;
+        auto by_mode = [&](auto r, auto a) {
+            if (mode == K6_FAST) return launch(r, a, std::integral_constant<int, K6_FAST>());
+            if (mode == K6_EXACT_POW2) return launch(r, a, std::integral_constant<int, K6_EXACT_POW2>());
+            return launch(r, a, std::integral_constant<int, K6_EXACT>());
+        };
+        rc = (rgb && alpha) ? by_mode(T(), T()) : (rgb ? by_mode(T(), N()) : by_mode(N(), T()));
         if (rc == 0 && zero_ok && zeroed) *zeroed = 1;
     }
     if (rc) return rc;
@@ -2428,15 +1937,3 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     return 0;
 }
 
-#ifdef NR_K6_PHASES
-// development build only (not declared in include/nr_hip.h): cycles per phase of k_bpm_fast summed over workgroups
-NR_API int nr_debug_k6_phases(unsigned long long *out8, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_k6_phase), 24 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) {
-        unsigned long long z[24] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_k6_phase), z, sizeof(z));
-    }
-    return (int)e;
-}
-#endif

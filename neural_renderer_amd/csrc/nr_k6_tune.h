@@ -1,0 +1,48 @@
+// nr_k6_tune.h -- the numerics / shape knobs of K6's default (tolerance-mode) kernel in one place.
+//
+// The product build takes the defaults below.  Development builds (neural_renderer_amd._build.build_variant, timed side
+// by side through NR_HIP_LIB) override single knobs with -D...; nothing else in the library is conditional on macros.
+// What each knob costs and buys is measured in profiles/r04_k6_numerics.jsonl (LAB-NOTEBOOK, round 4).
+#pragma once
+
+#ifndef NR_K6_NEWTON       // one Newton step on each v_rcp_f32 of a visit (2 fma): the reciprocal to ~0.5 ulp instead of 1
+#define NR_K6_NEWTON 0
+#endif
+#ifndef NR_K6_FUSED_DIFF   // diff = sum (I - ref) * g accumulated with fused multiply-adds (0: the reference's roundings)
+#define NR_K6_FUSED_DIFF 1
+#endif
+#ifndef NR_K6_FUSED_DIST   // dist = fma(c, t, +-eps) (0: c * t rounded, then +- eps: the reference's two roundings)
+#define NR_K6_FUSED_DIST 1
+#endif
+#ifndef NR_K6_BATCH_DOUBLE // the float sums of a batch of NR_K6_FB visits are added to DOUBLE piece sums (0: float piece sums)
+#define NR_K6_BATCH_DOUBLE 0
+#endif
+#ifndef NR_K6_RUNSUM_DOUBLE  // the DPP run sums in front of the LDS atomics in double (0: float)
+#define NR_K6_RUNSUM_DOUBLE 0
+#endif
+#ifndef NR_K6_FB           // pixels of an unrolled piece whose LDS reads are requested together (FSEG is a multiple;
+#define NR_K6_FB 3         // 1 / 3 / 5 -> stage 229 / 230 / 252 us, 3 needs the fewest registers)
+#endif
+#ifndef NR_K6_WMAX         // widest band (lines per workgroup)
+#define NR_K6_WMAX 4
+#endif
+#ifndef NR_K6_FOLD_KB      // largest slice of the fused backward's grad_textures fill that a band workgroup takes along
+#define NR_K6_FOLD_KB 128
+#endif
+#ifndef NR_K6_LDS_BUDGET   // three workgroups per 160 KB CU, allocation granules of 512 bytes included (3 x 53.5 KB would not fit)
+#define NR_K6_LDS_BUDGET (53 * 1024)
+#endif
+
+namespace nr {
+namespace k6 {
+constexpr bool NEWTON = NR_K6_NEWTON != 0;
+constexpr bool FUSED_DIFF = NR_K6_FUSED_DIFF != 0;
+constexpr bool FUSED_DIST = NR_K6_FUSED_DIST != 0;
+constexpr bool BATCH_DOUBLE = NR_K6_BATCH_DOUBLE != 0;
+constexpr bool RUNSUM_DOUBLE = NR_K6_RUNSUM_DOUBLE != 0;
+constexpr int FB = NR_K6_FB;
+constexpr int WMAX = NR_K6_WMAX;
+constexpr int FOLD_KB = NR_K6_FOLD_KB;
+constexpr unsigned long LDS_BUDGET = NR_K6_LDS_BUDGET;
+}  // namespace k6
+}  // namespace nr

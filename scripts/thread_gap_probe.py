@@ -20,7 +20,7 @@ import neural_renderer_amd as nr
 from neural_renderer_amd import _lib
 
 dev = torch.device('cuda', 0)
-B, S, ts = 64, 256, 2
+B, S, ts = int(os.environ.get('B', 64)), int(os.environ.get('S', 256)), 2
 faces, textures = bench.build_scene(dev, B, 0, B, S, ts)
 F = faces.shape[1]
 lib = _lib.load()

@@ -276,10 +276,11 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
             # same terms either way; what can differ is the order of the line records, hence which segment sums share a float
             # run sum before the double atomics (and the order of K8's float adds): a few 1e-7 of the largest gradient
             assert H.rel_err(abi.host(gf2), gf) <= SAME_TERMS
-            if not flags & EXACT:  # the default kernel's second way to its line records (in-kernel face scan): same terms again
-                gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
-                                      use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
-                assert H.rel_err(abi.host(gf3), gf) <= SAME_TERMS
+            # the band kernel's second way to its line records (in-kernel face scan, the fallback of images whose records
+            # exceed the buffer): same terms again, in both arithmetic modes
+            gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
+                                  use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
+            assert H.rel_err(abi.host(gf3), gf) <= SAME_TERMS
     if rgb:
         gt = abi.host(gt)
         assert not np.isnan(gt).any(), 'grad_textures has unwritten elements'
@@ -366,7 +367,7 @@ def test_big_faces_every_gather_path(ts, eps):
 @pytest.mark.parametrize('S', [384, 512, 768, 1024])
 def test_band_width_classes(S):
     """Raster sizes whose K6 bands are 2 lines (512, 384: the anti-aliased default of Renderer) or 1 line (768, 1024) wide,
-    powers of two and not: every staging / band-width path of k_bpm_band against the oracle."""
+    powers of two and not: every staging / band-width path of the band kernel against the oracle."""
     rng = np.random.default_rng(300 + S)
     faces = H.random_scene(rng, 1, 400, spread=0.7, size=0.15)
     textures = rng.uniform(0, 1, (1, 400, 2, 2, 2, 3)).astype(np.float32)
