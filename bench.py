@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- rasterize fwd+bwd Mpixels/s on teapot.obj, 256x256, batch 64 per GPU (BASELINE.json metric).
+"""bench.py -- rasterize fwd+bwd Mpixels/s on teapot.obj, 256x256, batch 64 (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -8,8 +8,11 @@
 A step = one pass of the rasterizer hot path (Rasterize forward + backward through the product's autograd
 operator, i.e. the C-ABI entry points nr_forward_rasterize / nr_backward_rasterize) over one batch of 64 views of the
 teapot at raster size 256 with RGB + alpha + depth outputs all enabled.  Inputs (projected faces, lit textures, upstream
-gradients) are resident in HBM before the timed region.  The batch-of-views dimension shards across GPUs without any
-collective ("weak" scaling: 64 views per GPU); rank 0 prints ONE JSON line.
+gradients) are resident in HBM before the timed region.  With --gpus R the 64-view batch is SPLIT: rank r renders views
+[r 64/R, (r+1) 64/R) of the same 64 azimuths (BASELINE.md "Multi-GPU rows"; neural_renderer_amd.distributed.
+shard_bounds), with no collective inside forward + backward -- "strong" scaling, `config.views_per_gpu` = 64/R.  The
+64-views-PER-GPU job of rounds 1-3 (R x 64 views, "weak" scaling) is timed in the same run and reported as the
+`weak_scaling` object of the line.  Rank 0 prints ONE JSON line.
 
 Objects on the line besides the contract's keys:
   roofline      the dominant stage's algorithmic HBM bytes / its measured average launch duration (HIP events on the launch
@@ -23,6 +26,11 @@ Objects on the line besides the contract's keys:
                 max-rel errors of the gradients, all 64 views
   extra_rows    the same step with anti-aliasing on (raster 512, the Renderer default) and with the all-ones upstream
                 gradient of the reference's misc/measure_time.py:60
+  shard_rows    (1-GPU run) the step at the per-GPU shard sizes of a 2 / 4 / 8-GPU run -- 32 / 16 / 8 views -- on this one GPU:
+                through the autograd operator (torch defaults), with the backward kept on the calling thread, and through the
+                operator's chainer.Function protocol (forward_gpu / backward_gpu: no autograd graph); `predicted_strong_scaling`
+                is what these times mean for the 64-view job on R GPUs (no collective in the path)
+  weak_scaling  (N > 1) 64 views per GPU instead of 64 / N: the job of the earlier rounds' N > 1 points
 """
 import argparse
 import json
@@ -72,14 +80,16 @@ def build_scene(device, batch, first_view, total_views, image_size, texture_size
     return faces.contiguous(), textures.contiguous()
 
 
-def upstream_gradients(faces, textures, S, eps, seed, all_ones=False):
+def upstream_gradients(faces, textures, S, eps, seed, all_ones=False, z_ref=None):
     """g = 2 (image - ref) with a seeded uniform reference (dense, both signs); all_ones: the gradient of
     sum(images) as in the reference's misc/measure_time.py:60 (K6's `diff_grad <= 0` branch then skips half the work)."""
     import neural_renderer_amd as nr
     dev = faces.device
     gen = torch.Generator(device='cpu').manual_seed(seed)
     with torch.no_grad():
-        rgb0, alpha0, depth0 = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)(faces, textures)
+        fn = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+        fn.faces_z_ref = z_ref
+        rgb0, alpha0, depth0 = fn(faces, textures)
         if all_ones:
             return torch.ones_like(rgb0), torch.ones_like(alpha0), torch.ones_like(depth0)
         g_rgb = (2 * (rgb0 - torch.rand(rgb0.shape, generator=gen).to(dev))).contiguous()
@@ -346,6 +356,58 @@ def measure_time_protocol(device, batch_size, image_size=256, texture_size=2, ca
     return out
 
 
+def shard_rows(device, total_views, S, ts, eps, steps, gpus=(2, 4, 8)):
+    """The step at the per-GPU shard sizes of a 2 / 4 / 8-GPU run on THIS GPU: views [0, b) of the `total_views` azimuths with
+    global view 0 as the texture-depth reference, i.e. rank 0's share of the strong-scaling job.  Three ways to call it (ms
+    per step, wall clock, K steps up to a device synchronize):
+      autograd               Rasterize(...)(faces, textures) + torch.autograd.backward, torch's default autograd settings
+      autograd_caller_thread the same inside neural_renderer_amd.graph.backward_on_caller_thread() (no hand-over of the
+                             backward to autograd's device thread)
+      function_protocol      fn.forward_gpu(inputs); fn.backward_gpu(inputs, grad_outputs): the chainer.Function protocol of
+                             the reference (rasterize.py:467, :849), no autograd graph -- what Chainer itself calls"""
+    import neural_renderer_amd as nr
+    rows = []
+    for b in [total_views // r for r in gpus if total_views % r == 0 and total_views // r >= 1]:
+        faces, textures = build_scene(device, b, 0, total_views, S, ts)
+        faces.requires_grad_(True)
+        textures.requires_grad_(True)
+        z_ref = faces.detach()[0].contiguous().clone()
+        grads = upstream_gradients(faces, textures, S, eps, 99 + b, z_ref=z_ref)
+
+        def autograd_step():
+            faces.grad = None
+            textures.grad = None
+            fn = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+            fn.faces_z_ref = z_ref
+            torch.autograd.backward(list(fn(faces, textures)), list(grads))
+
+        fd, td = faces.detach(), textures.detach()
+
+        def protocol_step():
+            fn = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+            fn.faces_z_ref = z_ref
+            fn.forward_gpu((fd, td))
+            fn.backward_gpu((fd, td), grads)
+
+        n = max(steps, 50)
+        row = {'views': b, 'of_total_views': total_views, 'gpus_this_shard_belongs_to': total_views // b}
+        for _ in range(30):
+            autograd_step()
+        # (median of five runs of n steps: host-bound loops jitter with the host's thread wake-ups)
+        runs = sorted(time_step(autograd_step, device, n, 5) for _ in range(5))
+        row['ms_autograd'], row['ms_autograd_min_max'] = runs[2], [runs[0], runs[-1]]
+        with nr.graph.backward_on_caller_thread():
+            runs = sorted(time_step(autograd_step, device, n, 5) for _ in range(5))
+        row['ms_autograd_caller_thread'] = runs[2]
+        runs = sorted(time_step(protocol_step, device, n, 5) for _ in range(5))
+        row['ms_function_protocol'] = runs[2]
+        for k in ('ms_autograd', 'ms_autograd_caller_thread', 'ms_function_protocol'):
+            row[k.replace('ms_', 'mpixel_per_s_')] = b * S * S / (row[k] * 1e-3) / 1e6
+        rows.append(row)
+        del faces, textures, grads
+    return rows
+
+
 def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views, light=False):
     """The C oracle on this host: one thread on `sample_views` views (the contract's `value`, kind "port"), all cores on
     the whole batch, and the naive NumPy per-pixel loop on BASELINE configs[0]."""
@@ -461,7 +523,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--prewarm-ms', type=float, default=250.0, help='untimed milliseconds of the same step in front of the warm-up '
                     'steps (the device reaches its steady clocks; 0 = none)')
-    ap.add_argument('--batch', type=int, default=64, help='views per GPU')
+    ap.add_argument('--batch', type=int, default=64, help='views of the whole job: split over the GPUs (strong scaling); the '
+                    '`weak_scaling` object of an N > 1 run renders this many PER GPU')
     ap.add_argument('--image-size', type=int, default=256, help='raster size S (anti-aliasing off)')
     ap.add_argument('--texture-size', type=int, default=2)
     ap.add_argument('--cpu-sample-views', type=int, default=32,
@@ -472,6 +535,7 @@ def main():
     ap.add_argument('--gather', action='store_true', help='also all_gather the rendered images each step (RCCL)')
     ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph')
     ap.add_argument('--exact', action='store_true', help='K6 with the reference\'s own arithmetic (NR_FLAG_EXACT_GRADIENT)')
+    ap.add_argument('--no-shard-rows', action='store_true', help='skip the 32 / 16 / 8-view rows of a 1-GPU run')
     ap.add_argument('--light', action='store_true', help='headline step + stage timings only (no extra rows, no Renderer '
                                                          'end-to-end, oracle check on 2 views)')
     args = ap.parse_args()
@@ -489,31 +553,41 @@ def main():
         import torch.distributed as dist
 
     import neural_renderer_amd as nr
-    B, S, ts, eps = args.batch, args.image_size, args.texture_size, 1e-3
-    faces, textures = build_scene(dev, B, rank * B, world * B, S, ts)
+    G, S, ts, eps = args.batch, args.image_size, args.texture_size, 1e-3  # G: views of the whole job
+    # strong scaling: rank r owns views [start, stop) of the G azimuths 360 i / G
+    start, stop = nrd.shard_bounds(G, rank, world)
+    B = stop - start
+    if B < 1:
+        raise SystemExit('--batch %d gives rank %d of %d no view' % (G, rank, world))
+    faces, textures = build_scene(dev, B, start, G, S, ts)
     F = faces.shape[1]
     faces.requires_grad_(True)
     textures.requires_grad_(True)
-    g_rgb, g_alpha, g_depth = upstream_gradients(faces, textures, S, eps, 1234 + rank)
+    # textures are sampled with the depths of GLOBAL view 0 -- one 177 KB broadcast before the timed region
+    # makes the shards of an N > 1 run the same computation as the unsharded batch (tests/test_sharding_gpu.py)
+    z_ref = nrd.broadcast_reference_faces(faces.detach()) if (world > 1 or nrd._force()) else None
+    g_rgb, g_alpha, g_depth = upstream_gradients(faces, textures, S, eps, 1234 + rank, z_ref=z_ref)
 
     gather = args.gather and dist is not None
     last = {}
 
-    def make_step(f, t, size, grads, with_gather=False, exact=None):
+    def make_step(f, t, size, grads, with_gather=False, exact=None, ref=None, total=G):
         def step():
             f.grad = None
             t.grad = None
             fn = nr.Rasterize(size, 0.1, 100, eps, (0, 0, 0), True, True, True)
             fn.exact_gradient = args.exact if exact is None else exact
+            fn.faces_z_ref = ref
             rgb, alpha, depth = fn(f, t)
             if with_gather:  # the downstream loss wants the whole batch: one all-gather of the rendered shards (RCCL / xGMI)
-                last['gathered'] = nrd.all_gather_images(rgb.detach(), total=world * B)
+                last['gathered'] = nrd.all_gather_images(rgb.detach(), total=total)
             torch.autograd.backward([rgb, alpha, depth], list(grads))
             last['fi'] = fn.face_index_map
         return step
 
-    step = make_step(faces, textures, S, (g_rgb, g_alpha, g_depth), with_gather=gather)
-    local_step = make_step(faces, textures, S, (g_rgb, g_alpha, g_depth))  # rank-local work only: no collective inside
+    grads = (g_rgb, g_alpha, g_depth)
+    step = make_step(faces, textures, S, grads, with_gather=gather, ref=z_ref)
+    local_step = make_step(faces, textures, S, grads, ref=z_ref)  # rank-local work only: no collective inside
 
     def barrier():
         if dist is not None:
@@ -536,41 +610,62 @@ def main():
     # behind 30: 0.367).  W warm-up steps of 0.4 ms do not get there, so the same step runs untimed for --prewarm-ms before
     # the W warm-up steps and the K timed ones (reported in `timing.prewarm`).
     # (Rank-local steps only: the loop is bounded by time, so the ranks run different numbers of them -- no collective inside.)
-    pre = local_step if gather else run
-    prewarm_steps, t_pre = 0, time.perf_counter()
-    if args.prewarm_ms > 0:  # (one-time costs of the very first calls -- allocations, kernel attributes -- are not device work)
-        pre()
+    def timed(run_fn, pre_fn):
+        """(seconds for K steps: MAX over ranks, rank-local HIP-event ms per step, pre-warm steps)."""
+        n_pre, t_pre = 0, time.perf_counter()
+        if args.prewarm_ms > 0:  # (one-time costs of the very first calls -- allocations, kernel attributes -- are not device work)
+            pre_fn()
+            torch.cuda.synchronize(dev)
+            t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for _ in range(10):
+                pre_fn()
+            torch.cuda.synchronize(dev)
+            n_pre += 10
+        for _ in range(args.warmup):
+            run_fn()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            run_fn()
+        ev1.record()
         torch.cuda.synchronize(dev)
-        t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(10):
-            pre()
-        torch.cuda.synchronize(dev)
-        prewarm_steps += 10
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        run()
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    event_ms_per_step = ev0.elapsed_time(ev1) / args.steps
-    barrier()
+        seconds = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1) / args.steps
+        barrier()
+        if dist is not None:
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        return seconds, ev_ms, n_pre
+
+    elapsed, event_ms_per_step, prewarm_steps = timed(run, local_step if gather else run)
     eager_ms = None
     if mode == 'hipgraph':  # also report the eager number
         eager_ms = time_step(local_step, dev, args.steps, 2)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    total_pixels = world * B * S * S
+    total_pixels = G * S * S  # the whole job: every rank's shard
     value = total_pixels / (ms_per_step * 1e-3) / 1e6
+
+    # The job of rounds 1-3 at N > 1: G views PER GPU (rank r: views [r G, (r + 1) G) of N G azimuths), same protocol.
+    weak = None
+    if world > 1 or nrd._force():
+        wf, wt = build_scene(dev, G, rank * G, world * G, S, ts)
+        wf.requires_grad_(True)
+        wt.requires_grad_(True)
+        wz = nrd.broadcast_reference_faces(wf.detach())
+        wg = upstream_gradients(wf, wt, S, eps, 4242 + rank, z_ref=wz)
+        w_step = make_step(wf, wt, S, wg, with_gather=gather, ref=wz, total=world * G)
+        w_local = make_step(wf, wt, S, wg, ref=wz)
+        w_elapsed, _, _ = timed(w_step, w_local)
+        w_ms = w_elapsed / args.steps * 1e3
+        weak = {'scaling': 'weak', 'views_per_gpu': G, 'views_total': world * G, 'ms_per_step': w_ms,
+                'value': world * G * S * S / (w_ms * 1e-3) / 1e6, 'unit': 'Mpixel/s',
+                'what': 'the same step on %d views per GPU (%d in all): the N > 1 points of rounds 1-3' % (G, world * G)}
+        del wf, wt, wg, w_step, w_local
 
     if rank == 0:
         local_step()  # gradients of the checked batch; rank 0 alone runs this, so it must not contain a collective
@@ -584,8 +679,8 @@ def main():
         dominant = max(stage_bytes, key=lambda k: stages[k])
         achieved = stage_bytes[dominant] / (stages[dominant] * 1e-6) / 1e9
         prof = profile_records().get('pmc', {})
-        traffic_rec = prof.get(dominant, {})
-        step_bytes = whole_step_bytes(B, F, S, ts)
+        traffic_rec = prof.get(dominant, {}) if B == 64 else {}  # (the committed counters are launches of 64 views)
+        step_bytes = whole_step_bytes(G, F, S, ts)  # the whole job's compulsory bytes against the whole job's step time
         roofline = {
             'bound': 'hbm', 'kernel': STAGE_KERNEL.get(dominant, dominant) + (' (exact mode)' if args.exact and dominant == 'backward_pixel_map' else ''),
             'stage': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -657,25 +752,42 @@ def main():
                 'rows': [measure_time_protocol(dev, 1), measure_time_protocol(dev, B),
                          measure_time_protocol(dev, 1, caller_thread=True)]}
             e2e['face_light'] = face_light_row(dev, B)
+        shards = None
+        if world == 1 and not args.no_shard_rows and not args.light:
+            shards = {'rows': shard_rows(dev, G, S, ts, eps, args.steps),
+                      'what': 'rank 0\'s shard of the %d-view job at 2 / 4 / 8 GPUs, timed on this one GPU (ms per step)' % G}
+            # no collective in forward + backward: the R-GPU step is the slowest rank's shard step
+            shards['predicted_strong_scaling'] = [
+                {'n_gpus': r['gpus_this_shard_belongs_to'], 'views_per_gpu': r['views'],
+                 'value_autograd': G * S * S / (r['ms_autograd'] * 1e-3) / 1e6,
+                 'value_autograd_caller_thread': G * S * S / (r['ms_autograd_caller_thread'] * 1e-3) / 1e6,
+                 'value_function_protocol': G * S * S / (r['ms_function_protocol'] * 1e-3) / 1e6, 'unit': 'Mpixel/s',
+                 'efficiency_vs_this_run_autograd': (ms_per_step / r['ms_autograd']) / r['gpus_this_shard_belongs_to']}
+                for r in shards['rows']]
         cpu = None
-        if args.cpu_sample_views > 0 and world == 1:
+        if args.cpu_sample_views > 0:
+            # (N > 1: rank 0's shard, one thread and all cores; the naive-NumPy row only in the 1-GPU run)
             cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
-                               min(args.cpu_sample_views, B), light=args.light)
+                               min(args.cpu_sample_views, B), light=args.light or world > 1)
         line = {
             'metric': 'rasterize fwd+bwd Mpixels/sec @256x256 batch=64', 'value': value, 'unit': 'Mpixel/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'data_note': 'synthetic cameras, textures and upstream gradients; the mesh is the reference\'s teapot.obj (embedded in '
                          'tests/golden/reference_fixtures.npz), as BASELINE.json names it',
             'config': {
-                'workload': 'teapot.obj (2464 faces, fill_back -> %d), %d azimuth views per GPU, raster %dx%d '
-                            '(anti_aliasing off), texture_size %d, rgb+alpha+depth forward + backward through the '
-                            'Rasterize autograd operator' % (F, B, S, S, ts),
-                'views_per_gpu': B, 'image_size': S, 'num_faces': F, 'texture_size': ts, 'eps': eps,
-                'k6_numerics': 'exact (reference arithmetic per term)' if args.exact else 'default (float terms via fused multiply-adds and v_rcp_f32: measured <= 4.7e-5 of the exactly summed reference terms, bound 1e-4; see grad_check)',
-                'parallelism': 'batch-of-views sharded over %d GPU(s), no collective%s'
-                               % (world, ' + all_gather(rgb)' if gather else ''),
+                'workload': 'teapot.obj (2464 faces, fill_back -> %d), %d azimuth views split over %d GPU(s) (%d per GPU), raster '
+                            '%dx%d (anti_aliasing off), texture_size %d, rgb+alpha+depth forward + backward through the '
+                            'Rasterize autograd operator' % (F, G, world, B, S, S, ts),
+                'views_total': G, 'views_per_gpu': B, 'image_size': S, 'num_faces': F, 'texture_size': ts, 'eps': eps,
+                'k6_numerics': 'exact (reference arithmetic per term, sums in double)' if args.exact else
+                               'default (float terms via fused multiply-adds and v_rcp_f32, ~1 ulp per term; tests bound the '
+                               'deviation from the exactly summed reference terms by 1e-4; measured levels: grad_check and '
+                               'profiles/*_parity_errors.jsonl)',
+                'parallelism': 'the batch of views split over %d GPU(s): rank r renders views [r*%d/%d, (r+1)*%d/%d), no collective%s'
+                               % (world, G, world, G, world, ' + all_gather(rgb)' if gather else ''),
             },
+            'weak_scaling': weak, 'shard_rows': shards,
             'roofline': roofline, 'cpu_baseline': cpu, 'stages_us': stages, 'grad_check': check,
             'extra_rows': extra_rows, 'launch_mode': mode, 'eager_ms_per_step': eager_ms, 'renderer_end_to_end': e2e,
             'timing': {'protocol': 'barrier + synchronize | K steps timed per rank up to its own synchronize (wall clock) | barrier; '
@@ -683,6 +795,7 @@ def main():
                        'rank0_hip_event_ms_per_step': event_ms_per_step,
                        'prewarm': {'ms': args.prewarm_ms, 'steps': prewarm_steps,
                                    'why': 'steady clocks before the W warm-up and K timed steps (untimed)'},
+                       'effective_warmup_steps': prewarm_steps + args.warmup,
                        'backend': (dist.get_backend() if dist is not None else None)},
         }
         print(json.dumps(line))

@@ -52,20 +52,21 @@ def run():
     parser.add_argument('--steps', type=int, default=300)
     args = parser.parse_args()
     device = torch.device('cuda', args.gpu)
-    # a one-image optimisation step is bound by the host: autograd's hand-over of the backward to its device thread is the
-    # largest single item of it (0.55 -> 0.35 ms per step of example 2 on an MI355X box), so the backward stays on this thread
-    torch.autograd.set_multithreading_enabled(False)
 
     model = Model(args.filename_obj, args.filename_ref).to(device)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.1, betas=(0.5, 0.999))  # Adam(alpha=0.1, beta1=0.5)
-    loop = tqdm.tqdm(range(args.steps))
-    for _ in loop:
-        loop.set_description('Optimizing')
-        optimizer.zero_grad()
-        loss = model()
-        loss.backward()
-        optimizer.step()
-    print('final loss %.3f' % float(loss))
+    # a one-image optimisation step is bound by the host: autograd's hand-over of the backward to its device thread is the
+    # largest single item of it (0.55 -> 0.35 ms per step of example 2 on an MI355X box), so the backward stays on this thread
+    # (a setting of this thread's autograd state: a context manager, so that nothing leaks into a caller of run())
+    with neural_renderer.graph.backward_on_caller_thread():
+        loop = tqdm.tqdm(range(args.steps))
+        for _ in loop:
+            loop.set_description('Optimizing')
+            optimizer.zero_grad()
+            loss = model()
+            loss.backward()
+            optimizer.step()
+        print('final loss %.3f' % float(loss))
 
     # draw object
     frames = []

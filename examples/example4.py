@@ -66,9 +66,6 @@ def run():
     parser.add_argument('--steps', type=int, default=1000)
     args = parser.parse_args()
     device = torch.device('cuda', args.gpu)
-    # a one-image optimisation step is bound by the host: autograd's hand-over of the backward to its device thread is the
-    # largest single item of it (0.55 -> 0.35 ms per step of example 2 on an MI355X box), so the backward stays on this thread
-    torch.autograd.set_multithreading_enabled(False)
 
     if args.make_reference_image:
         make_reference_image(args.filename_ref, args.filename_obj, device)
@@ -76,20 +73,24 @@ def run():
     model = Model(args.filename_obj, args.filename_ref).to(device)
     optimizer = torch.optim.Adam(model.parameters(), lr=0.1)  # chainer Adam(alpha=0.1)
     frames = []
-    loop = tqdm.tqdm(range(args.steps))
-    for i in loop:
-        optimizer.zero_grad()
-        loss = model()
-        loss.backward()
-        optimizer.step()
-        with torch.no_grad():
-            images = model.renderer.render(model.vertices, model.faces, model.textures)
-        frames.append(images.cpu().numpy()[0].transpose((1, 2, 0)))
-        loop.set_description('Optimizing (loss %.4f)' % float(loss))
-        if float(loss) < 70:
-            break
-    print('stopped after %d steps, loss %.3f, camera %s' % (i + 1, float(loss), model.camera_position.tolist()))
-    make_gif(frames, args.filename_output)
+    # a one-image optimisation step is bound by the host: autograd's hand-over of the backward to its device thread is the
+    # largest single item of it (0.55 -> 0.35 ms per step of example 2 on an MI355X box), so the backward stays on this thread
+    # (a setting of this thread's autograd state: a context manager, so that nothing leaks into a caller of run())
+    with neural_renderer.graph.backward_on_caller_thread():
+        loop = tqdm.tqdm(range(args.steps))
+        for i in loop:
+            optimizer.zero_grad()
+            loss = model()
+            loss.backward()
+            optimizer.step()
+            with torch.no_grad():
+                images = model.renderer.render(model.vertices, model.faces, model.textures)
+            frames.append(images.cpu().numpy()[0].transpose((1, 2, 0)))
+            loop.set_description('Optimizing (loss %.4f)' % float(loss))
+            if float(loss) < 70:
+                break
+        print('stopped after %d steps, loss %.3f, camera %s' % (i + 1, float(loss), model.camera_position.tolist()))
+        make_gif(frames, args.filename_output)
 
 
 if __name__ == '__main__':

@@ -56,7 +56,8 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 300 /* 0.3.0: any `near` (NR_E_NEAR removed); 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
+#define NR_VERSION 400 /* 0.4.0: NR_FLAG_EXACT_GRADIENT and NR_FLAG_K6_SCAN combine (one band kernel, two arithmetic modes);
+                          * 0.3.0: any `near` (NR_E_NEAR removed); 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
 
 /* argument errors */
 #define NR_E_NULL (-1)      /* a required pointer is NULL */

@@ -3,7 +3,7 @@
 The public names are the reference's (neural_renderer/__init__.py:1-16); `import neural_renderer` is an alias package."""
 # the operator and its wrappers (HIP kernels behind include/nr_hip.h)
 from .rasterize import (Rasterize, rasterize, rasterize_depth, rasterize_rgbad, rasterize_silhouettes,
-                        use_unsafe_rasterizer, use_graph_replay)
+                        use_unsafe_rasterizer, use_graph_replay, clear_workspace_cache)
 from .renderer import Renderer
 # geometry / lighting glue in front of the rasterizer
 from .cross import cross
@@ -21,7 +21,9 @@ from .save_obj import save_obj
 # not in the reference: multi-GPU helpers and the captured-graph helper for fixed-shape loops
 from . import distributed, graph
 
-__version__ = '0.2.0'
+# the C ABI's version (include/nr_hip.h NR_VERSION = major * 100 + minor), checked against the loaded library by _lib.load()
+__version__ = '0.4.0'
 __all__ = ['Rasterize', 'rasterize', 'rasterize_depth', 'rasterize_rgbad', 'rasterize_silhouettes', 'use_unsafe_rasterizer', 'use_graph_replay',
+           'clear_workspace_cache',
            'Renderer', 'cross', 'get_points_from_angles', 'lighting', 'look', 'look_at', 'perspective', 'vertices_to_faces',
            'load_obj', 'Mesh', 'Adam', 'save_obj']

@@ -58,6 +58,7 @@ SIGNATURES = {
     'nr_frontend_backward_light': (_c.c_int, [_vp] * 7 + [_i32] * 6 + [_cam_p, _light_p, _vp, _sz, _vp]),
 }
 
+NR_VERSION = 400  # include/nr_hip.h; load() refuses a library of another version (a stale build)
 NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
 NR_FLAG_EXACT_GRADIENT = 2
 NR_FLAG_K6_GLOBAL = 4
@@ -88,6 +89,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.nr_version() != NR_VERSION and not os.environ.get('NR_HIP_LIB'):  # (a development variant: the caller's business)
+        raise NRError('%s is version %d, this package binds version %d: rebuild it (python -m neural_renderer_amd._build)'
+                      % (path, lib.nr_version(), NR_VERSION))
     _lib = lib
     return lib
 

@@ -258,7 +258,6 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 //          one by one, IEEE division, the double `dist +- eps`), all sums in double: the correctly rounded sum of the
 //          reference's terms up to double round-off (<= 2e-6 against the exactly summed oracle).  _POW2: S is a power of two
 //          (x * 2. / S is then one exact float multiply; the generic form carries a double-precision division).
-constexpr int BAND_THREADS = 512;
 constexpr int BAND_WIN = 256;    // line records per window, at most
 constexpr int FSEG = 15;         // pixels per piece (odd: consecutive pieces of a sweep start on different LDS banks;
                                  // re-swept in round 3: 9 / 12 / 15 / 18 pixels -> stage 242 / 237 / 230 / 233 us)
@@ -493,7 +492,8 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
     }
 }
 
-// exclusive scan of one int per thread over the workgroup; returns the exclusive prefix, *total = sum
+// exclusive scan of one int per thread over the workgroup of NT threads; returns the exclusive prefix, *total = sum
+template <int NT>
 __device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int *total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -506,7 +506,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int *total)
     if (lane == 63) s_tmp[wave] = inc;
     __syncthreads();
     int woff = 0, tot = 0;
-    for (int w = 0; w < BAND_THREADS / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         const int c = s_tmp[w];
         if (w < wave) woff += c;
         tot += c;
@@ -853,7 +853,7 @@ struct FastPx {  // LDS pixel data of a band, [line][d1]
     int *span;      // [line][2]: first and last covered pixel of the line (first > last: none)
 };
 
-template <bool RGB, bool ALPHA>
+template <bool RGB, bool ALPHA, int NT>
 __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__restrict__ fi_map,
                                            const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
                                            const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, size_t img,
@@ -907,12 +907,12 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
     };
     if (axis && (S & 3) == 0) {  // a band line is an image row: thread -> (line, quad of 4 consecutive pixels)
         const int quads = S >> 2;
-        for (int i = tid; i < nld * quads; i += BAND_THREADS) {
+        for (int i = tid; i < nld * quads; i += NT) {
             const int ld = i / quads, x = (i - ld * quads) << 2;
             put_quad(img + (size_t)(band_lo + ld) * S + x, ld, x, 0, 1);
         }
     } else if (axis) {  // thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
-        for (int i = tid; i < nld * S; i += BAND_THREADS) {
+        for (int i = tid; i < nld * S; i += NT) {
             const int ld = i / S, x = i - ld * S;
             const size_t g = img + (size_t)(band_lo + ld) * S + x;
             float al = 0, ga = 0, r = 0, gn = 0, bl = 0, gr = 0, gg = 0, gb = 0;
@@ -924,9 +924,9 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
             put(ld, x, fi_map[g], al, ga, r, gn, bl, gr, gg, gb);
         }
     } else if (nld == 4 && (S & 3) == 0) {  // 4 adjacent columns: one thread per row
-        for (int y = tid; y < S; y += BAND_THREADS) put_quad(img + (size_t)y * S + band_lo, 0, y, 1, 0);
+        for (int y = tid; y < S; y += NT) put_quad(img + (size_t)y * S + band_lo, 0, y, 1, 0);
     } else {  // generic columns: thread -> (row d1, line ld) with ld fastest
-        for (int i = tid; i < nld * S; i += BAND_THREADS) {
+        for (int i = tid; i < nld * S; i += NT) {
             const int d1 = i / nld, ld = i - d1 * nld;
             const size_t g = img + (size_t)d1 * S + band_lo + ld;
             float al = 0, ga = 0, r = 0, gn = 0, bl = 0, gr = 0, gg = 0, gb = 0;
@@ -1029,6 +1029,7 @@ __device__ __forceinline__ int wave_incl_sum_dpp(int v)
 // exclusive scan of one 64-bit word of four 16-bit counters per thread over the workgroup (no field overflows: every total
 // is below 2^16); returns the exclusive prefix, *total = sum.  The two halves are scanned as ints with DPP moves: the LDS is
 // the busiest unit of this kernel and a shuffle-based scan would go through its crossbar twelve times.
+template <int NT>
 __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long *s_tmp,
                                                                 unsigned long long *total)
 {
@@ -1039,7 +1040,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
     if (lane == 63) s_tmp[wave] = inc;
     __syncthreads();
     unsigned long long woff = 0, tot = 0;
-    for (int w = 0; w < BAND_THREADS / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         const unsigned long long c = s_tmp[w];
         if (w < wave) woff += c;
         tot += c;
@@ -1049,7 +1050,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
     return woff + inc - v;
 }
 
-template <bool RGB, bool ALPHA, int MODE>
+template <bool RGB, bool ALPHA, int MODE, int NT>
 __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_line, int n_win, int SP, double eps, int S,
                                             double *acc, void *s_queue, int qcap, bool wide, unsigned long long *s_tmp)
 {
@@ -1114,7 +1115,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
     const int nU = nF - nM, nL = nG - nS;
     // one scan for the four numberings (16 bits each: a window holds < 2^16 pieces of every kind by the choice of win_lines)
     unsigned long long totals = 0;
-    const unsigned long long offs = block_excl_scan64((unsigned long long)nU | ((unsigned long long)nM << 16) |
+    const unsigned long long offs = block_excl_scan64<NT>((unsigned long long)nU | ((unsigned long long)nM << 16) |
                                                           ((unsigned long long)nS << 32) | ((unsigned long long)nL << 48),
                                                       s_tmp, &totals);
     const int TU = (int)(totals & 0xffff), TM = (int)((totals >> 16) & 0xffff), TS = (int)((totals >> 32) & 0xffff),
@@ -1137,7 +1138,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
         dist = (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
         return diff / dist;
     };
-    // rounds of qcap ids (qcap: a multiple of BAND_THREADS; most windows fit in one round)
+    // rounds of qcap ids (qcap: a multiple of NT; most windows fit in one round)
     for (int lo = 0; lo < total_ids; lo += qcap) {
         const int hi = min(lo + qcap, total_ids);
         if (lo > 0) __syncthreads();  // the previous round's readers are done
@@ -1155,7 +1156,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             }
         }
         __syncthreads();
-        for (int id = lo + tid; rfl(id) < hi; id += BAND_THREADS) {  // (wave-uniform trip count: all 64 lanes stay together)
+        for (int id = lo + tid; rfl(id) < hi; id += NT) {  // (wave-uniform trip count: all 64 lanes stay together)
             const int wid = rfl(id);     // ids of a wave are 64 consecutive numbers from a multiple of 64: one class per wave
             const int cls = wid < MA ? 0 : (wid < SA ? 1 : 2);
             const int cls_end = min(hi, cls == 0 ? TU : (cls == 1 ? MA + TM : (wid < LA ? SA + TS : total_ids)));
@@ -1384,9 +1385,11 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
     }
 }
 
-// The band kernel.  (launch bounds: three workgroups per CU; the generic exact form carries a double division: two)
-template <bool RGB, bool ALPHA, int MODE>
-__global__ __launch_bounds__(BAND_THREADS, MODE == K6_EXACT ? 4 : 6) void k_bpm_fast(
+// The band kernel, NT threads per workgroup (band_shape below).  (launch bounds: what the LDS of a shape admits -- six waves
+// per SIMD for three 512-thread workgroups per CU, four for four 256-thread ones; the generic exact form carries a double
+// division: four)
+template <bool RGB, bool ALPHA, int MODE, int NT>
+__global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVES_256 : 6)) void k_bpm_fast(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const unsigned *__restrict__ rng,
@@ -1409,7 +1412,7 @@ __global__ __launch_bounds__(BAND_THREADS, MODE == K6_EXACT ? 4 : 6) void k_bpm_
         // cubes) rides along: every workgroup clears one slice before it looks at its band -- half of them have nothing
         // else to do -- instead of a launch of its own between this kernel and the gather.
         const size_t per = (n_zero16 + total_wg - 1) / total_wg, z_lo = (size_t)logical * per, z_hi = min(n_zero16, z_lo + per);
-        for (size_t k = z_lo + tid; k < z_hi; k += BAND_THREADS) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t k = z_lo + tid; k < z_hi; k += NT) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
     }
     const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
@@ -1441,9 +1444,9 @@ __global__ __launch_bounds__(BAND_THREADS, MODE == K6_EXACT ? 4 : 6) void k_bpm_
 
     // ---- 1. stage the band
     const size_t img = (size_t)b * S * S;
-    for (int i = tid; i < W * px.CW; i += BAND_THREADS) px.cov[i] = 0u;
+    for (int i = tid; i < W * px.CW; i += NT) px.cov[i] = 0u;
     __syncthreads();
-    fast_stage<RGB, ALPHA>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, img, axis, band_lo, nld, S, SP);
+    fast_stage<RGB, ALPHA, NT>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, img, axis, band_lo, nld, S, SP);
     __syncthreads();
     if (tid < nld) {  // covered span of each band line (the sweeps' classification looks no further)
         int first = 0x7fffffff, last = -1;
@@ -1465,13 +1468,18 @@ __global__ __launch_bounds__(BAND_THREADS, MODE == K6_EXACT ? 4 : 6) void k_bpm_
     const int n_vis = use_rec ? 0 : vis_count[b];
     const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
     int chunk = 0, win = 0;  // (scan path) first list position of the chunk; (both) first line of the next window
+    // the 2 * n_win line sums, one or two per thread (a window has at most NT lines)
+    auto each_sum = [&](int n2, auto fn) {
+        if (tid < n2) fn(tid);
+        if (NT < 2 * BAND_WIN && tid + NT < n2) fn(tid + NT);
+    };
     for (;;) {
         int n_win;
         if (use_rec) {
             if (win >= n_band_lines) break;
             n_win = min(n_band_lines - win, win_lines);
-            if (tid < n_win) s_line[tid] = recs[win + tid];
-            if (tid < 2 * n_win) s_lacc[tid] = 0.0;
+            if (tid < n_win) s_line[tid] = recs[win + tid];  // (win_lines <= NT)
+            each_sum(2 * n_win, [&](int i) { s_lacc[i] = 0.0; });
             win += win_lines;
         } else {
             if (chunk >= n_vis) break;
@@ -1488,9 +1496,9 @@ __global__ __launch_bounds__(BAND_THREADS, MODE == K6_EXACT ? 4 : 6) void k_bpm_
                 }
             }
             int total_lines = 0;
-            const int line_off = block_excl_scan(nl, s_tmp, &total_lines);
+            const int line_off = block_excl_scan<NT>(nl, s_tmp, &total_lines);
             if (win >= total_lines) {  // (uniform) this chunk is done
-                chunk += BAND_THREADS;
+                chunk += NT;
                 win = 0;
                 continue;
             }
@@ -1515,21 +1523,21 @@ __global__ __launch_bounds__(BAND_THREADS, MODE == K6_EXACT ? 4 : 6) void k_bpm_
                                              pos | (e << 28) | (((e + 1) % 3) << 30),
                                              [&](int d1) { return px.fi[ld * SP + d1]; }, k2s);
             }
-            if (tid < 2 * n_win) s_lacc[tid] = 0.0;
+            each_sum(2 * n_win, [&](int i) { s_lacc[i] = 0.0; });
             win += win_lines;
         }
         __syncthreads();
-        fast_sweeps<RGB, ALPHA, MODE>(px, s_line, n_win, SP, eps, S, s_lacc, s_queue, qcap, wide,
+        fast_sweeps<RGB, ALPHA, MODE, NT>(px, s_line, n_win, SP, eps, S, s_lacc, s_queue, qcap, wide,
                                       reinterpret_cast<unsigned long long *>(s_tmp));
         __syncthreads();
-        if (tid < 2 * n_win) {  // line sums -> global double scratch [list position][vertex][x|y]
-            const double a = s_lacc[tid];
+        each_sum(2 * n_win, [&](int i) {  // line sums -> global double scratch [list position][vertex][x|y]
+            const double a = s_lacc[i];
             if (a != 0.0) {
-                const int tgt = s_line[tid >> 1].tgt;
-                const int pos = tgt & 0x0fffffff, v = (tid & 1) ? (tgt >> 30) & 3 : (tgt >> 28) & 3;
+                const int tgt = s_line[i >> 1].tgt;
+                const int pos = tgt & 0x0fffffff, v = (i & 1) ? (tgt >> 30) & 3 : (tgt >> 28) & 3;
                 atomicAdd(scratch + ((size_t)b * F + pos) * 6 + 2 * v + (1 - axis), a);
             }
-        }
+        });
         __syncthreads();
     }
 }
@@ -1605,30 +1613,51 @@ ListsLayout lists_layout(int B, int F)
     return L;
 }
 
+// Shape of a band workgroup, chosen per launch by the raster size (round 4, scripts/k6_variants.py -> profiles/r04_k6_shapes.jsonl;
+// K6 stage in us, variants timed in one process behind a throw-away pass: 512 threads / 4-line bands / 53 KB  ->  256
+// threads / 2-line bands / 40 KB):
+//   teapot 64 x 256^2  209 -> 204    16 x 256^2  99 -> 87    8 x 256^2  69 -> 65    64 x 384^2  499 -> 400   256 x 128^2  330 -> 273
+//   config 4 (64 spiky meshes x 10 240 faces, 256^2)  433 -> 367
+//   teapot 64 x 448^2  524 -> 579    64 x 512^2  682 -> 701    4 x 1024^2  338 -> 349
+// i.e. while a two-line band leaves room for a window of >= 128 lines (raster <= 400 with colours) it wins, walked by four
+// waves: the same ~110 lines and ~1 200 pieces per window as four lines give eight waves, in workgroups half the size --
+// four per CU, a finer grain for the tail and for the mix of busy and empty bands.  Beyond that the wide shape stays.
+struct BandShape {
+    int threads;     // 256 | 512
+    int w_max;       // widest band (lines)
+    size_t budget;   // LDS per workgroup
+};
+BandShape band_shape(int S)
+{
+    if (S <= k6::SMALL_RASTER_MAX) return {256, 2, (size_t)40 * 1024};  // four workgroups per 160 KB CU
+    return {512, k6::WMAX, k6::LDS_BUDGET};
+}
+
 // LDS of k_bpm_fast: pixel arrays [W][SP] (face index 4 B, gradients and colours 16 B each -- 4 B each for alpha alone),
-// coverage bits, and what is left is split between the line window (32 B record + two double sums per line) and the piece
-// queue (2 or 4 B per descriptor).  Returns W (0: the raster does not fit, global fallback).
-int fast_band_config(int S, bool rgb, int w_max, size_t *lds_bytes, int *win, int *qcap)
+// coverage bits, and what is left is split between the line window (32 B record + two double sums per line; at most one line
+// per thread) and the piece queue (2 or 4 B per descriptor).  Returns W (0: the raster does not fit, global fallback).
+int fast_band_config(int S, bool rgb, const BandShape &shape, int w_max, size_t *lds_bytes, int *win, int *qcap)
 {
     const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 255 * FSEG ? 4 : 2;
     // pieces per line the split is made for: measured, stage times in us, raster 256: S/22 (192 lines, 3072 descriptors)
     // 240, S/32 (224, 2560) 230, S/48 (256, 2048: two rounds per window) 267; raster 512: S/22 (160, 4096) 906, S/32 (192,
     // 3584) 891, S/48 (224, 2560) 766 -- a band of a 512 x 512 teapot view has ~185 lines: one window instead of two
     const size_t segs_per_line = (size_t)S / (S <= 320 ? 32 : 48) + 3;
-    const size_t LDS_BUDGET = k6::LDS_BUDGET;
+    const size_t NT = (size_t)shape.threads, LDS_BUDGET = shape.budget;
+    const int win_max = BAND_WIN < shape.threads ? BAND_WIN : shape.threads;
     auto lines_bytes = [&](int ww) { return (sizeof(BandLine) + 16) * (size_t)ww; };
     for (int W = w_max; W >= 1; W >>= 1) {
         const size_t px = (size_t)W * SP * per_px + (size_t)W * (((SP + 31) / 32 + 3) / 4 * 4) * 4 + 16 /* bg */ + 32 /* spans */ + 64 /* scan */ +
                           8 * 16 /* alignment slack */;
-        // the three-workgroups-per-CU budget; a one-line band may take the whole LDS
-        const size_t lim = (W == 1 && px + lines_bytes(32) + BAND_THREADS * dsz > LDS_BUDGET) ? 160 * 1024 : LDS_BUDGET;
-        if (px + lines_bytes(32) + BAND_THREADS * dsz > lim) continue;
+        // the budget of the shape; a one-line band may take the whole LDS
+        const size_t lim = (W == 1 && px + lines_bytes(32) + NT * dsz > LDS_BUDGET) ? 160 * 1024 : LDS_BUDGET;
+        if (px + lines_bytes(32) + NT * dsz > lim) continue;
         const size_t rest = lim - px;
         int w = (int)(rest / (48 + segs_per_line * dsz));
-        w = max(32, min(BAND_WIN, w / 32 * 32));
-        while (w > 32 && lines_bytes(w) + BAND_THREADS * dsz > rest) w -= 32;
+        w = max(32, min(win_max, w / 32 * 32));
+        while (w > 32 && lines_bytes(w) + NT * dsz > rest) w -= 32;
         if (W > 1 && w < 96) continue;  // a band this wide leaves no room for a useful line window: narrower bands
-        size_t q = (rest - lines_bytes(w)) / dsz / BAND_THREADS * BAND_THREADS;
+        size_t q = (rest - lines_bytes(w)) / dsz / NT * NT;
         q = q > 16384 ? 16384 : q;
         *win = w;
         *qcap = (int)q;
@@ -1664,7 +1693,7 @@ struct LdsLimit {
     }
 };
 
-template <bool RGB, bool ALPHA, int MODE>
+template <bool RGB, bool ALPHA, int MODE, int NT>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
                 const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
@@ -1672,11 +1701,11 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
                 void *zero_ptr, size_t zero_bytes)
 {
     static LdsLimit limit;  // one per instantiation
-    auto kern = k_bpm_fast<RGB, ALPHA, MODE>;
+    auto kern = k_bpm_fast<RGB, ALPHA, MODE, NT>;
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     // 1-D grid: the kernel maps ids to (image, axis, band) per XCD
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(BAND_THREADS), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(NT), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
                        eps, k2s, B, win_lines, qcap, (uint4 *)zero_ptr, zero_bytes / 16);
     return 0;
@@ -1719,9 +1748,10 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     int win = BAND_WIN, qcap = 0;
     // Narrower bands when the launch would have few band workgroups (small batches): the chip holds 768 of them at a time and
     // half of a teapot view's bands are empty; 16 views: stage 113 -> 104 us with W = 2, 4 views 70 -> 50, 1 view 66 -> 40 (W = 1).
-    int w_max = k6::WMAX;
+    const BandShape shape = band_shape(S);
+    int w_max = shape.w_max;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
-    const int W = fast_band_config(S, rgb, w_max, &lds, &win, &qcap);
+    const int W = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
     if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
         const dim3 grid((unsigned)n), block(WAVE);
         if (rgb && alpha)
@@ -1806,21 +1836,26 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         // workgroup's own work -- k6::FOLD_KB per band workgroup: 4 KB at the headline size, 61 KB on config 4; config 5's
         // 4 GB would be 2 MB for each of 2048 workgroups and go at 7 TB/s through a fill launch instead)
         const size_t band_wgs = (size_t)((S + W - 1) / W) * 2 * (size_t)B;
+        // (per workgroup: a 256-thread workgroup takes half of what a 512-thread one does)
         const bool zero_ok = zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
-                             zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10);
+                             zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10) * (size_t)shape.threads / 512;
         const int mode = !exact ? K6_FAST : ((S & (S - 1)) == 0 ? K6_EXACT_POW2 : K6_EXACT);
-        auto launch = [&](auto r, auto a, auto m) {
-            return launch_fast<decltype(r)::value, decltype(a)::value, decltype(m)::value>(
+        auto launch = [&](auto r, auto a, auto m, auto nt) {
+            return launch_fast<decltype(r)::value, decltype(a)::value, decltype(m)::value, decltype(nt)::value>(
                 faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
                 band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, k2s, win_lines, qcap, st,
                 zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
         };
         using T = std::true_type;
         using N = std::false_type;
+        auto by_threads = [&](auto r, auto a, auto m) {
+            if (shape.threads == 256) return launch(r, a, m, std::integral_constant<int, 256>());
+            return launch(r, a, m, std::integral_constant<int, 512>());
+        };
         auto by_mode = [&](auto r, auto a) {
-            if (mode == K6_FAST) return launch(r, a, std::integral_constant<int, K6_FAST>());
-            if (mode == K6_EXACT_POW2) return launch(r, a, std::integral_constant<int, K6_EXACT_POW2>());
-            return launch(r, a, std::integral_constant<int, K6_EXACT>());
+            if (mode == K6_FAST) return by_threads(r, a, std::integral_constant<int, K6_FAST>());
+            if (mode == K6_EXACT_POW2) return by_threads(r, a, std::integral_constant<int, K6_EXACT_POW2>());
+            return by_threads(r, a, std::integral_constant<int, K6_EXACT>());
         };
         rc = (rgb && alpha) ? by_mode(T(), T()) : (rgb ? by_mode(T(), N()) : by_mode(N(), T()));
         if (rc == 0 && zero_ok && zeroed) *zeroed = 1;

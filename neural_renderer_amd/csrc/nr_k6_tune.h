@@ -23,13 +23,19 @@
 #ifndef NR_K6_FB           // pixels of an unrolled piece whose LDS reads are requested together (FSEG is a multiple;
 #define NR_K6_FB 3         // 1 / 3 / 5 -> stage 229 / 230 / 252 us, 3 needs the fewest registers)
 #endif
-#ifndef NR_K6_WMAX         // widest band (lines per workgroup)
+#ifndef NR_K6_SMALL_RASTER_MAX  // up to this raster size: 256-thread workgroups on two-line bands (band_shape; 0: never)
+#define NR_K6_SMALL_RASTER_MAX 400
+#endif
+#ifndef NR_K6_MINWAVES_256  // launch bound (waves per SIMD) of the 256-thread shape
+#define NR_K6_MINWAVES_256 4
+#endif
+#ifndef NR_K6_WMAX         // widest band (lines per workgroup) of the 512-thread shape
 #define NR_K6_WMAX 4
 #endif
 #ifndef NR_K6_FOLD_KB      // largest slice of the fused backward's grad_textures fill that a band workgroup takes along
 #define NR_K6_FOLD_KB 128
 #endif
-#ifndef NR_K6_LDS_BUDGET   // three workgroups per 160 KB CU, allocation granules of 512 bytes included (3 x 53.5 KB would not fit)
+#ifndef NR_K6_LDS_BUDGET   // (512-thread shape) three workgroups per 160 KB CU, allocation granules of 512 bytes included (3 x 53.5 KB would not fit)
 #define NR_K6_LDS_BUDGET (53 * 1024)
 #endif
 
@@ -41,6 +47,8 @@ constexpr bool FUSED_DIST = NR_K6_FUSED_DIST != 0;
 constexpr bool BATCH_DOUBLE = NR_K6_BATCH_DOUBLE != 0;
 constexpr bool RUNSUM_DOUBLE = NR_K6_RUNSUM_DOUBLE != 0;
 constexpr int FB = NR_K6_FB;
+constexpr int SMALL_RASTER_MAX = NR_K6_SMALL_RASTER_MAX;
+constexpr int MINWAVES_256 = NR_K6_MINWAVES_256;
 constexpr int WMAX = NR_K6_WMAX;
 constexpr int FOLD_KB = NR_K6_FOLD_KB;
 constexpr unsigned long LDS_BUDGET = NR_K6_LDS_BUDGET;

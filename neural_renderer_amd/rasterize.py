@@ -10,7 +10,9 @@ Mirrors (reference file:line):
 
 There is no CPU path (the reference has none either: rasterize.py:893-897) and no eager fallback.
 """
+import collections
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -40,8 +42,31 @@ FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream_ptr(device):
+    """hipStream_t of torch's current stream on `device` (the raw query: no Stream object per call)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(device.index)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on_device(device):
+    """Context that makes `device` the current HIP device for the launches -- nothing at all when it already is (one process
+    per GPU: always), torch.cuda.device otherwise."""
+    return _NO_GUARD if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
 _BG_CACHE = {}
@@ -49,13 +74,23 @@ _BG_CACHE = {}
 
 def _background_tensor(bg, device):
     """Device copy of a host background colour, cached (a pageable H2D copy per call would serialise the stream)."""
+    if type(bg) is tuple:
+        key = (device.index, bg)
+        t = _BG_CACHE.get(key)
+        if t is not None:
+            return t
     arr = np.asarray(bg, dtype=np.float32)
-    key = (str(device), arr.shape, arr.tobytes())
-    t = _BG_CACHE.get(key)
+    key2 = (device.index, arr.shape, arr.tobytes())
+    t = _BG_CACHE.get(key2)
     if t is None:
         if len(_BG_CACHE) > 64:
             _BG_CACHE.clear()
-        t = _BG_CACHE[key] = torch.as_tensor(arr, device=device)
+        t = _BG_CACHE[key2] = torch.as_tensor(arr, device=device)
+    if type(bg) is tuple:
+        try:
+            _BG_CACHE[(device.index, bg)] = t
+        except TypeError:  # (an unhashable element)
+            pass
     return t
 
 
@@ -68,7 +103,9 @@ def _background_tensor(bg, device):
 # flight before the first one's backward (the residual maps live in the fixed buffers) -- that raises.  Measured (config 2):
 # 0.25 ms eager -> 0.21 ms with replay; a step captured as a whole by the caller (neural_renderer_amd.graph.capture: no
 # copies, loss and optimizer inside) 0.17 ms -- prefer that where the whole step is fixed.  Known limitation (ROCm 7.2 /
-# torch 2.10): a whole-step capture started AFTER this mode has run in the same process crashes; use one or the other.
+# torch 2.10): a whole-step capture started AFTER this mode has run in the same process crashes the process inside torch's
+# capture; neural_renderer_amd.graph.capture therefore refuses (RuntimeError) once this mode holds captured graphs -- use one
+# or the other, or call `clear_graph_replay_cache()` first.
 GRAPH_REPLAY = bool(int(os.environ.get('NR_GRAPH_REPLAY', '0')))
 
 
@@ -77,199 +114,258 @@ def use_graph_replay(flag):
     GRAPH_REPLAY = bool(flag)
 
 
-_ZBUF_CACHE = {}
+# The forward's scratch (z-buffer + queues), kept per (device, stream, sizes) and reused with a falling epoch number
+# (include/nr_hip.h: NR_FLAG_ZBUF_EPOCH) so that the library neither fills the z-buffer before a call nor cleans it afterwards.
+# Least-recently-used entries go first; the cache holds at most _ZBUF_CACHE_BYTES (a workspace larger than half of that is
+# not kept at all: such a call takes the per-call fill); `clear_workspace_cache()` releases everything.
+_ZBUF_CACHE = collections.OrderedDict()
+_ZBUF_CACHE_BYTES = int(os.environ.get('NR_WORKSPACE_CACHE_MB', '1024')) << 20
+_ZBUF_LOCK = threading.Lock()
+
+
+def clear_workspace_cache():
+    """Release the kept forward workspaces (8 bytes per raster pixel each; see _forward_workspace)."""
+    with _ZBUF_LOCK:
+        _ZBUF_CACHE.clear()
 
 
 def _forward_workspace(lib, dev, stream, B, F, S):
-    """The forward's scratch (z-buffer + queues) and the flags that go with it.  Kept per (device, stream, sizes) and reused
-    with a falling epoch number (include/nr_hip.h: NR_FLAG_ZBUF_EPOCH), so that the library neither fills the z-buffer
-    before a call nor cleans it afterwards; refilled with 0xff every 255 calls.  While a HIP graph is being captured the
-    epoch would be frozen into the graph, so capture takes a throw-away workspace and the filling path."""
+    """(workspace tensor, bytes, flags) for one forward call.  A kept workspace is refilled with 0xff every 255 calls.  While
+    a HIP graph is being captured the epoch would be frozen into the graph, so capture takes a throw-away workspace and the
+    filling path."""
     ws_bytes = lib.nr_forward_workspace_bytes(B, F, S)
     if ws_bytes == 0:
         raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
-    if F >= (1 << 24) or torch.cuda.is_current_stream_capturing():
+    if F >= (1 << 24) or 2 * ws_bytes > _ZBUF_CACHE_BYTES or torch.cuda.is_current_stream_capturing():
         return torch.empty((ws_bytes,), dtype=torch.uint8, device=dev), ws_bytes, 0
     key = (dev.index, int(stream), B, F, S)
-    ent = _ZBUF_CACHE.get(key)
-    if ent is None:
-        if len(_ZBUF_CACHE) >= 8:  # a handful of shapes at a time: drop the oldest
-            _ZBUF_CACHE.pop(next(iter(_ZBUF_CACHE)))
-        ent = _ZBUF_CACHE[key] = [torch.empty((ws_bytes,), dtype=torch.uint8, device=dev), -1]
-    if ent[1] < 0:
-        ent[0].fill_(255)
-        ent[1] = 254
-    epoch = ent[1]
-    ent[1] -= 1
+    with _ZBUF_LOCK:
+        ent = _ZBUF_CACHE.get(key)
+        if ent is None:
+            total = sum(e[0].numel() for e in _ZBUF_CACHE.values()) + ws_bytes
+            while _ZBUF_CACHE and (total > _ZBUF_CACHE_BYTES or len(_ZBUF_CACHE) >= 16):
+                total -= _ZBUF_CACHE.popitem(last=False)[1][0].numel()
+            ent = _ZBUF_CACHE[key] = [torch.empty((ws_bytes,), dtype=torch.uint8, device=dev), -1]
+        else:
+            _ZBUF_CACHE.move_to_end(key)
+        if ent[1] < 0:
+            ent[0].fill_(255)
+            ent[1] = 254
+        epoch = ent[1]
+        ent[1] -= 1
     return ent[0], ws_bytes, _lib.NR_FLAG_ZBUF_EPOCH | (epoch << 8)
+
+
+class _Config(object):
+    """What a Rasterize instance is configured with, frozen for one call (the autograd node keeps it)."""
+    __slots__ = ('image_size', 'near', 'far', 'eps', 'background_color', 'return_rgb', 'return_alpha', 'return_depth',
+                 'fix_batch_z', 'exact_gradient', 'faces_z_ref', 'owner')
+
+    def __init__(self, fn):
+        self.image_size = int(fn.image_size)
+        self.near, self.far, self.eps = float(fn.near), float(fn.far), float(fn.eps)
+        self.background_color = fn.background_color if fn.background_color is not None else DEFAULT_BACKGROUND_COLOR
+        self.return_rgb, self.return_alpha, self.return_depth = bool(fn.return_rgb), bool(fn.return_alpha), bool(fn.return_depth)
+        self.fix_batch_z, self.exact_gradient = bool(fn.fix_batch_z), bool(fn.exact_gradient)
+        self.faces_z_ref = fn.faces_z_ref
+        self.owner = weakref.ref(fn)
+
+
+class _Residuals(object):
+    """Everything one forward leaves behind for its backward (the reference keeps the same on `self`, rasterize.py:39-58)."""
+    __slots__ = ('B', 'F', 'S', 'ts', 'Nf', 'flags', 'faces', 'textures', 'light', 'z_ref', 'face_index_map', 'weight_map',
+                 'depth_map', 'rgb_map', 'alpha_map', 'visible')
+
+
+def _check_inputs(cfg, faces, textures, light):
+    """Type / shape checks of rasterize.py:66-90 (+ the face_light extension).  Returns (B, F, Nf, ts)."""
+    if not faces.is_cuda:
+        raise NotImplementedError('neural_renderer_amd has no CPU rasterizer (neither has the reference: '
+                                  'rasterize.py:893-897)')
+    if faces.dtype != torch.float32 or faces.dim() != 4 or tuple(faces.shape[2:]) != (3, 3):
+        raise ValueError('faces must be float32 [batch size, num of faces, 3, 3], got %s %s'
+                         % (faces.dtype, tuple(faces.shape)))
+    B, F = int(faces.shape[0]), int(faces.shape[1])
+    Nf, ts = F, 0
+    if cfg.return_rgb:
+        if textures is None:
+            raise ValueError('textures are required when return_rgb is set')
+        if light is not None:
+            if light.dtype != torch.float32 or tuple(light.shape) != (B, F, 3):
+                raise ValueError('face_light must be float32 [batch size, num of faces, 3], got %s %s'
+                                 % (light.dtype, tuple(light.shape)))
+            if textures.dim() == 6 and textures.shape[1] * 2 == F:
+                Nf = F // 2  # fill_back: face Nf + f is the reversed copy of face f
+        sh = textures.shape
+        if (textures.dtype != torch.float32 or textures.dim() != 6 or sh[0] != B or sh[1] != Nf or sh[2] < 2 or
+                sh[2] != sh[3] or sh[3] != sh[4] or sh[5] != 3):
+            raise ValueError('textures must be float32 [batch size, num of faces, ts, ts, ts, 3] with ts >= 2, '
+                             'got %s %s' % (textures.dtype, tuple(sh)))  # rasterize.py:78-90
+        ts = int(sh[2])
+    return B, F, Nf, ts
+
+
+def _forward_impl(cfg, faces, textures, light):
+    """forward_gpu (rasterize.py:467-513): visibility + shading behind one C-ABI call.  Returns the residuals."""
+    lib = _lib.load()
+    B, F, Nf, ts = _check_inputs(cfg, faces, textures, light)
+    return_rgb, return_alpha, return_depth = cfg.return_rgb, cfg.return_alpha, cfg.return_depth
+    dev = faces.device
+    S = cfg.image_size
+    r = _Residuals()
+    r.B, r.F, r.S, r.ts, r.Nf = B, F, S, ts, Nf
+    r.faces = faces.detach().contiguous()  # rasterize.py:470
+    r.textures = textures.detach().contiguous() if return_rgb else None  # :473
+    r.light = light.detach().contiguous() if (return_rgb and light is not None) else None
+    with _on_device(dev):
+        stream = _stream_ptr(dev)
+        need_wd = return_rgb or return_depth
+        i32, f32 = torch.int32, torch.float32
+        r.face_index_map = torch.empty((B, S, S), dtype=i32, device=dev)
+        r.weight_map = torch.empty((B, S, S, 3), dtype=f32, device=dev) if need_wd else None
+        r.depth_map = torch.empty((B, S, S), dtype=f32, device=dev) if need_wd else None
+        workspace, ws_bytes, ws_flags = _forward_workspace(lib, dev, stream, B, F, S)
+        r.rgb_map = r.alpha_map = background = None
+        bg_per_batch = 0
+        if return_rgb:
+            r.rgb_map = torch.empty((B, S, S, 3), dtype=f32, device=dev)
+            bg = cfg.background_color
+            if torch.is_tensor(bg):
+                background = bg.detach().to(device=dev, dtype=f32).contiguous()
+            else:
+                background = _background_tensor(bg, dev)
+            if tuple(background.shape) == (B, 3):
+                bg_per_batch = 1  # rasterize.py:464-465
+            elif tuple(background.shape) != (3,):
+                raise ValueError('background_color must have shape (3,) or (batch size, 3)')
+        if return_alpha:
+            r.alpha_map = torch.empty((B, S, S), dtype=f32, device=dev)
+        flags = _lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg.fix_batch_z else 0
+        if cfg.exact_gradient:
+            flags |= _lib.NR_FLAG_EXACT_GRADIENT
+        r.flags = flags
+        # batch element 0 of the GLOBAL batch when this call holds a shard of it (SURVEY Q1, include/nr_hip.h)
+        z_ref = cfg.faces_z_ref
+        if z_ref is not None:
+            z_ref = z_ref.detach().to(device=dev, dtype=f32).contiguous()
+            if tuple(z_ref.shape) != (F, 3, 3):
+                raise ValueError('faces_z_ref must have shape (num of faces, 3, 3), got %s' % (tuple(z_ref.shape),))
+        r.z_ref = z_ref
+        # per-face "owns a pixel" flags: a residual the backward starts from (K6's lists; the depth-only gather skips the
+        # faces without a pixel)
+        r.visible = torch.empty((B, F), dtype=torch.uint8, device=dev)
+        ptr = _lib.ptr
+        lit = _lib.FaceLight(r.light.data_ptr(), Nf, None, None) if r.light is not None else None
+        # visibility + shading behind one call (rasterize.py:499-502)
+        _lib.check(lib.nr_forward_rasterize_lit(
+            lit, r.faces.data_ptr(), ptr(z_ref), ptr(r.textures), r.face_index_map.data_ptr(), ptr(r.weight_map),
+            ptr(r.depth_map), ptr(r.rgb_map), ptr(r.alpha_map), r.visible.data_ptr(), ptr(background), bg_per_batch,
+            B, F, S, ts, cfg.near, cfg.far, cfg.eps, flags | ws_flags, workspace.data_ptr(), ws_bytes, stream),
+            'nr_forward_rasterize')
+    return r
+
+
+_BWD_WS_BYTES = {}
+
+
+def _backward_impl(cfg, r, g_rgb, g_alpha, g_depth, want_textures, want_light):
+    """backward_gpu (rasterize.py:849-889): K6 -> K7 -> K8 behind one C-ABI call.  `None` gradients are zeros (:858-878); a
+    zero gradient adds exactly 0 to every `diff_grad`, so the corresponding term is skipped instead of being multiplied out.
+    Returns (grad_faces, grad_textures | None, grad_light | None)."""
+    lib = _lib.load()
+    B, F, S, ts = r.B, r.F, r.S, r.ts
+    use_rgb = cfg.return_rgb and g_rgb is not None
+    use_alpha = cfg.return_alpha and g_alpha is not None
+    use_depth = cfg.return_depth and g_depth is not None
+    if not (use_rgb or use_alpha or use_depth):
+        return None, None, None
+    dev = r.faces.device
+    grad_textures = grad_light = None
+    with _on_device(dev):
+        stream = _stream_ptr(dev)
+        g_rgb = g_rgb.contiguous() if use_rgb else None
+        g_alpha = g_alpha.contiguous() if use_alpha else None
+        g_depth = g_depth.contiguous() if use_depth else None
+        grad_faces = torch.empty_like(r.faces)  # stored by the library (zeros when neither rgb nor alpha)
+        lit = None
+        f32 = torch.float32
+        if use_rgb and r.light is not None:
+            if want_textures or want_light:
+                # one gather produces both (the colours' gradient is a by-product of the texel sums)
+                grad_textures = torch.empty((B, r.Nf, ts, ts, ts, 3), dtype=f32, device=dev)
+                if want_light:
+                    grad_light = torch.empty((B, F, 3), dtype=f32, device=dev)
+            lit = _lib.FaceLight(r.light.data_ptr(), r.Nf, r.textures.data_ptr(), _lib.ptr(grad_light))
+        elif use_rgb and want_textures:
+            grad_textures = torch.empty((B, F, ts, ts, ts, 3), dtype=f32, device=dev)
+        key = (B, F, S, use_rgb, use_alpha)
+        ws_bytes = _BWD_WS_BYTES.get(key)
+        if ws_bytes is None:
+            if len(_BWD_WS_BYTES) > 256:
+                _BWD_WS_BYTES.clear()
+            ws_bytes = _BWD_WS_BYTES[key] = lib.nr_backward_workspace_bytes(B, F, S, int(use_rgb), int(use_alpha))
+        workspace = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+        ptr = _lib.ptr
+        # K6 -> K7 -> K8 (rasterize.py:881-883) behind one call
+        _lib.check(lib.nr_backward_rasterize_lit(
+            lit, r.faces.data_ptr(), ptr(r.z_ref), r.face_index_map.data_ptr(), ptr(r.weight_map), ptr(r.depth_map),
+            ptr(r.rgb_map) if use_rgb else None, ptr(r.alpha_map) if use_alpha else None, ptr(g_rgb), ptr(g_alpha),
+            ptr(g_depth), grad_faces.data_ptr(), ptr(grad_textures), B, F, S, ts, cfg.eps, r.flags, ptr(r.visible),
+            workspace.data_ptr(), ws_bytes, stream), 'nr_backward_rasterize')
+    owner = cfg.owner()
+    if owner is not None:  # rasterize.py:41-51: the gradient buffers stay readable on the instance
+        owner.grad_rgb_map, owner.grad_alpha_map, owner.grad_depth_map = g_rgb, g_alpha, g_depth
+        # (aliases, not the returned tensors themselves: a second reference to a returned gradient makes autograd's
+        # AccumulateGrad clone it instead of adopting it -- two device copies, 41 MB per step at the headline size)
+        owner.grad_faces = grad_faces.detach()
+        owner.grad_textures = grad_textures.detach() if grad_textures is not None else None
+    return grad_faces, grad_textures, grad_light
 
 
 class _RasterizeFunction(torch.autograd.Function):
     """forward(ctx, faces, textures, cfg, light) -> (rgb_map [B,S,S,3] | None, alpha_map [B,S,S] | None,
-    depth_map [B,S,S] | None); backward(ctx, g_rgb, g_alpha, g_depth) -> (grad_faces, grad_textures, None, grad_light).
-    `light` [B,F,3] (or None): per-face light colours, textures are then the original cubes [B,Nf,...] with F = Nf or 2 Nf
-    (include/nr_hip.h: nr_face_light)."""
+    depth_map [B,S,S] | None, face_index_map); backward(ctx, g_rgb, g_alpha, g_depth, _) -> (grad_faces, grad_textures, None,
+    grad_light).  `light` [B,F,3] (or None): per-face light colours, textures are then the original cubes [B,Nf,...] with
+    F = Nf or 2 Nf (include/nr_hip.h: nr_face_light)."""
 
     @staticmethod
     def forward(ctx, faces, textures, cfg, light=None):
-        lib = _lib.load()
-        if not faces.is_cuda:
-            raise NotImplementedError('neural_renderer_amd has no CPU rasterizer (neither has the reference: '
-                                      'rasterize.py:893-897)')
-        if faces.dtype != torch.float32 or faces.dim() != 4 or tuple(faces.shape[2:]) != (3, 3):
-            raise ValueError('faces must be float32 [batch size, num of faces, 3, 3], got %s %s'
-                             % (faces.dtype, tuple(faces.shape)))
-        return_rgb, return_alpha, return_depth = cfg['return_rgb'], cfg['return_alpha'], cfg['return_depth']
-        dev = faces.device
-        faces_c = faces.detach().contiguous()  # rasterize.py:470
-        B, F = faces_c.shape[:2]
-        S = int(cfg['image_size'])
-        ts = 0
-        textures_c = light_c = None
-        Nf = F
-        if not return_rgb:
-            light = None
-        if return_rgb:
-            if textures is None:
-                raise ValueError('textures are required when return_rgb is set')
-            if light is not None:
-                if light.dtype != torch.float32 or tuple(light.shape) != (B, F, 3):
-                    raise ValueError('face_light must be float32 [batch size, num of faces, 3], got %s %s'
-                                     % (light.dtype, tuple(light.shape)))
-                if textures.dim() == 6 and textures.shape[1] * 2 == F:
-                    Nf = F // 2  # fill_back: face Nf + f is the reversed copy of face f
-                light_c = light.detach().contiguous()
-            if (textures.dtype != torch.float32 or textures.dim() != 6 or textures.shape[0] != B or
-                    textures.shape[1] != Nf or textures.shape[2] < 2 or textures.shape[2] != textures.shape[3] or
-                    textures.shape[3] != textures.shape[4] or textures.shape[5] != 3):
-                raise ValueError('textures must be float32 [batch size, num of faces, ts, ts, ts, 3] with ts >= 2, '
-                                 'got %s %s' % (textures.dtype, tuple(textures.shape)))  # rasterize.py:78-90
-            textures_c = textures.detach().contiguous()  # :473
-            ts = int(textures_c.shape[2])
-
-        with torch.cuda.device(dev):
-            stream = _stream_ptr(dev)
-            need_wd = return_rgb or return_depth
-            face_index_map = torch.empty((B, S, S), dtype=torch.int32, device=dev)
-            weight_map = torch.empty((B, S, S, 3), dtype=torch.float32, device=dev) if need_wd else None
-            depth_map = torch.empty((B, S, S), dtype=torch.float32, device=dev) if need_wd else None
-            workspace, ws_bytes, ws_flags = _forward_workspace(lib, dev, stream, B, F, S)
-            rgb_map = alpha_map = background = None
-            bg_per_batch = 0
-            if return_rgb:
-                rgb_map = torch.empty((B, S, S, 3), dtype=torch.float32, device=dev)
-                bg = cfg['background_color']
-                if torch.is_tensor(bg):
-                    background = bg.detach().to(device=dev, dtype=torch.float32).contiguous()
-                else:
-                    background = _background_tensor(bg, dev)
-                if tuple(background.shape) == (B, 3):
-                    bg_per_batch = 1  # rasterize.py:464-465
-                elif tuple(background.shape) != (3,):
-                    raise ValueError('background_color must have shape (3,) or (batch size, 3)')
-            if return_alpha:
-                alpha_map = torch.empty((B, S, S), dtype=torch.float32, device=dev)
-            flags = _lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg['fix_batch_z'] else 0
-            if cfg['exact_gradient']:
-                flags |= _lib.NR_FLAG_EXACT_GRADIENT
-            # batch element 0 of the GLOBAL batch when this call holds a shard of it (SURVEY Q1, include/nr_hip.h)
-            z_ref = cfg.get('faces_z_ref')
-            if z_ref is not None:
-                z_ref = z_ref.detach().to(device=dev, dtype=torch.float32).contiguous()
-                if tuple(z_ref.shape) != (F, 3, 3):
-                    raise ValueError('faces_z_ref must have shape (num of faces, 3, 3), got %s' % (tuple(z_ref.shape),))
-            # per-face "owns a pixel" flags: a residual the backward starts from (K6's lists; the depth-only gather skips the
-            # faces without a pixel)
-            visible = torch.empty((B, F), dtype=torch.uint8, device=dev)
-            # visibility + shading behind one call (rasterize.py:499-502)
-            lit = None
-            if light_c is not None:
-                lit = _lib.FaceLight(light_c.data_ptr(), Nf, None, None)
-            _lib.check(lib.nr_forward_rasterize_lit(
-                lit, faces_c.data_ptr(), _lib.ptr(z_ref), _lib.ptr(textures_c), face_index_map.data_ptr(),
-                _lib.ptr(weight_map), _lib.ptr(depth_map), _lib.ptr(rgb_map), _lib.ptr(alpha_map), _lib.ptr(visible),
-                _lib.ptr(background), bg_per_batch, B, F, S, ts, float(cfg['near']), float(cfg['far']),
-                float(cfg['eps']), flags | ws_flags, workspace.data_ptr(), ws_bytes, stream), 'nr_forward_rasterize')
-
-        ctx.cfg = dict(cfg, keep=None, B=B, F=F, S=S, ts=ts, flags=flags, Nf=Nf)
-        ctx.lit = (light_c, textures_c) if light_c is not None else None
-        keep = cfg.get('keep')
-        if keep is not None:  # the maps the reference leaves on the Function instance (rasterize.py:39-58); no copies
-            keep.update(faces=faces_c, textures=textures_c, face_index_map=face_index_map, weight_map=weight_map,
-                        depth_map=depth_map, rgb_map=rgb_map, alpha_map=alpha_map, batch_size=B, num_faces=F,
-                        texture_size=ts if return_rgb else None)
-        ctx.z_ref = z_ref
-        ctx.visible = visible
+        if not cfg.return_rgb:
+            textures = light = None
+        r = _forward_impl(cfg, faces, textures, light)
+        owner = cfg.owner()
+        if owner is not None:
+            owner._keep(r)
+        ctx.cfg = cfg
+        # (the node must not hold its own OUTPUTS except through save_for_backward: output -> grad_fn -> node -> output is a
+        # cycle through C++ that nothing collects -- every step's maps would stay allocated)
+        ctx.meta = (r.B, r.F, r.S, r.ts, r.Nf, r.flags)
+        ctx.z_ref, ctx.visible = r.z_ref, r.visible
         ctx.set_materialize_grads(False)  # an unused output arrives as `None` in backward and its terms are skipped
-        # residuals (the reference keeps them on `self`, rasterize.py:39-58); outputs among them go through
+        # residuals (the reference keeps them on `self`, rasterize.py:39-58); outputs and inputs among them go through
         # save_for_backward so that in-place edits by the caller are detected (cf. SURVEY quirk Q6)
-        ctx.save_for_backward(faces_c, face_index_map, weight_map, depth_map, rgb_map, alpha_map)
-        ctx.mark_non_differentiable(face_index_map)
-        outs = (rgb_map if return_rgb else None, alpha_map if return_alpha else None,
-                depth_map if return_depth else None, face_index_map)
-        return outs
+        ctx.save_for_backward(r.faces, r.face_index_map, r.weight_map, r.depth_map, r.rgb_map, r.alpha_map, r.textures if
+                              r.light is not None else None, r.light)
+        ctx.mark_non_differentiable(r.face_index_map)
+        return (r.rgb_map if cfg.return_rgb else None, r.alpha_map if cfg.return_alpha else None,
+                r.depth_map if cfg.return_depth else None, r.face_index_map)
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_depth, _g_fi):
-        lib = _lib.load()
-        cfg = ctx.cfg
-        B, F, S, ts = cfg['B'], cfg['F'], cfg['S'], cfg['ts']
-        faces_c, face_index_map, weight_map, depth_map, rgb_map, alpha_map = ctx.saved_tensors
-        dev = faces_c.device
-        # None gradients are zeros (rasterize.py:858-878); a zero gradient adds exactly 0 to every
-        # `diff_grad`, so the corresponding term is skipped instead of being multiplied out.
-        use_rgb = cfg['return_rgb'] and g_rgb is not None
-        use_alpha = cfg['return_alpha'] and g_alpha is not None
-        use_depth = cfg['return_depth'] and g_depth is not None
-        if not (use_rgb or use_alpha or use_depth):
-            return None, None, None, None
-        grad_light = None
-        with torch.cuda.device(dev):
-            stream = _stream_ptr(dev)
-            if use_rgb:
-                g_rgb = g_rgb.contiguous()
-            if use_alpha:
-                g_alpha = g_alpha.contiguous()
-            if use_depth:
-                g_depth = g_depth.contiguous()
-            grad_faces = torch.empty_like(faces_c)  # stored by the library (zeros when neither rgb nor alpha)
-            grad_textures = None
-            lit = None
-            if use_rgb and ctx.lit is not None:
-                if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
-                    # one gather produces both (the colours' gradient is a by-product of the texel sums)
-                    grad_textures = torch.empty((B, cfg['Nf'], ts, ts, ts, 3), dtype=torch.float32, device=dev)
-                    if ctx.needs_input_grad[3]:
-                        grad_light = torch.empty((B, F, 3), dtype=torch.float32, device=dev)
-                lit = _lib.FaceLight(ctx.lit[0].data_ptr(), cfg['Nf'], ctx.lit[1].data_ptr(), _lib.ptr(grad_light))
-            elif use_rgb and ctx.needs_input_grad[1]:
-                grad_textures = torch.empty((B, F, ts, ts, ts, 3), dtype=torch.float32, device=dev)
-            ws_bytes = lib.nr_backward_workspace_bytes(B, F, S, int(use_rgb), int(use_alpha))
-            workspace = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
-            # K6 -> K7 -> K8 (rasterize.py:881-883) behind one call
-            _lib.check(lib.nr_backward_rasterize_lit(
-                lit, faces_c.data_ptr(), _lib.ptr(ctx.z_ref), face_index_map.data_ptr(), _lib.ptr(weight_map),
-                _lib.ptr(depth_map), _lib.ptr(rgb_map) if use_rgb else None, _lib.ptr(alpha_map) if use_alpha else None,
-                _lib.ptr(g_rgb) if use_rgb else None, _lib.ptr(g_alpha) if use_alpha else None,
-                _lib.ptr(g_depth) if use_depth else None, grad_faces.data_ptr(), _lib.ptr(grad_textures),
-                B, F, S, ts, float(cfg['eps']), cfg['flags'], _lib.ptr(ctx.visible), workspace.data_ptr(), ws_bytes,
-                stream), 'nr_backward_rasterize')
-        owner = cfg['owner']() if cfg.get('owner') is not None else None
-        if owner is not None:  # rasterize.py:41-51: the gradient buffers stay readable on the instance
-            owner.grad_rgb_map, owner.grad_alpha_map, owner.grad_depth_map = g_rgb, g_alpha, g_depth
-            # (aliases, not the returned tensors themselves: a second reference to a returned gradient makes autograd's
-            # AccumulateGrad clone it instead of adopting it -- two device copies, 41 MB per step at the headline size)
-            owner.grad_faces = grad_faces.detach()
-            owner.grad_textures = grad_textures.detach() if grad_textures is not None else None
-        if not ctx.needs_input_grad[1]:
-            grad_textures = None
-        return grad_faces, grad_textures, None, grad_light
+        r = _Residuals()
+        r.B, r.F, r.S, r.ts, r.Nf, r.flags = ctx.meta
+        r.z_ref, r.visible = ctx.z_ref, ctx.visible
+        # (unpacking checks the version counters of the saved tensors: an in-place edit since the forward raises)
+        r.faces, r.face_index_map, r.weight_map, r.depth_map, r.rgb_map, r.alpha_map, r.textures, r.light = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gf, gt, gl = _backward_impl(ctx.cfg, r, g_rgb, g_alpha, g_depth, need[1], need[3])
+        return gf, (gt if need[1] else None), None, gl
 
 
 def _capture(fn, dev):
     """Warm `fn` up on a side stream, then capture it (see neural_renderer_amd.graph.capture)."""
     from .graph import capture
-    return capture(fn, dev, warmup=2)
+    return capture(fn, dev, warmup=2, _operator_replay=True)
 
 
 class _GraphEntry(object):
@@ -279,7 +375,7 @@ class _GraphEntry(object):
         self.lib, self.dev, self.cfg = lib, dev, cfg
         self.dims = (B, F, S, ts)
         f32 = dict(dtype=torch.float32, device=dev)
-        rgb, alpha, depth = cfg['return_rgb'], cfg['return_alpha'], cfg['return_depth']
+        rgb, alpha, depth = cfg.return_rgb, cfg.return_alpha, cfg.return_depth
         need_wd = rgb or depth
         self.faces = torch.zeros((B, F, 3, 3), **f32)
         self.textures = torch.zeros((B, F, ts, ts, ts, 3), **f32) if rgb else None
@@ -296,8 +392,8 @@ class _GraphEntry(object):
         if ws_bytes == 0:
             raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
         self.fwd_ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        self.flags = (_lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg['fix_batch_z'] else 0) | \
-                     (_lib.NR_FLAG_EXACT_GRADIENT if cfg['exact_gradient'] else 0)
+        self.flags = (_lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg.fix_batch_z else 0) | \
+                     (_lib.NR_FLAG_EXACT_GRADIENT if cfg.exact_gradient else 0)
         self.generation = 0
         self.pending = None  # generation of the forward whose residuals the buffers hold and whose backward may still come
         self.bwd = {}        # (use_rgb, use_alpha, use_depth, want grad_textures) -> (graph, buffers)
@@ -311,8 +407,8 @@ class _GraphEntry(object):
         _lib.check(self.lib.nr_forward_rasterize(
             self.faces.data_ptr(), _lib.ptr(self.z_ref), _lib.ptr(self.textures), self.face_index_map.data_ptr(),
             _lib.ptr(self.weight_map), _lib.ptr(self.depth_map), _lib.ptr(self.rgb_map), _lib.ptr(self.alpha_map),
-            self.visible.data_ptr(), _lib.ptr(self.background), self.bg_per_batch, B, F, S, ts, float(cfg['near']),
-            float(cfg['far']), float(cfg['eps']), self.flags, self.fwd_ws.data_ptr(), self.fwd_ws.numel(),
+            self.visible.data_ptr(), _lib.ptr(self.background), self.bg_per_batch, B, F, S, ts, cfg.near,
+            cfg.far, cfg.eps, self.flags, self.fwd_ws.data_ptr(), self.fwd_ws.numel(),
             _stream_ptr(self.dev)), 'nr_forward_rasterize')
 
     def _backward_buffers(self, use_rgb, use_alpha, use_depth, want_gt):
@@ -332,7 +428,7 @@ class _GraphEntry(object):
                 _lib.ptr(self.depth_map), _lib.ptr(self.rgb_map) if use_rgb else None,
                 _lib.ptr(self.alpha_map) if use_alpha else None, _lib.ptr(buf['g_rgb']), _lib.ptr(buf['g_alpha']),
                 _lib.ptr(buf['g_depth']), buf['grad_faces'].data_ptr(), _lib.ptr(buf['grad_textures']), B, F, S, ts,
-                float(self.cfg['eps']), self.flags, self.visible.data_ptr(), buf['ws'].data_ptr(), ws_bytes,
+                self.cfg.eps, self.flags, self.visible.data_ptr(), buf['ws'].data_ptr(), ws_bytes,
                 _stream_ptr(self.dev)), 'nr_backward_rasterize')
         return run, buf
 
@@ -358,6 +454,11 @@ class _GraphEntry(object):
 _GRAPH_CACHE = {}
 
 
+def clear_graph_replay_cache():
+    """Drop the operator's captured graphs and their fixed buffers (a later call in replay mode captures again)."""
+    _GRAPH_CACHE.clear()
+
+
 class _GraphedRasterizeFunction(torch.autograd.Function):
     """The operator replayed from captured graphs (see GRAPH_REPLAY): same results as _RasterizeFunction."""
 
@@ -374,8 +475,8 @@ class _GraphedRasterizeFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         fi = entry.face_index_map.clone()
         ctx.mark_non_differentiable(fi)
-        return (entry.rgb_map.clone() if cfg['return_rgb'] else None, entry.alpha_map.clone() if cfg['return_alpha'] else None,
-                entry.depth_map.clone() if cfg['return_depth'] else None, fi)
+        return (entry.rgb_map.clone() if cfg.return_rgb else None, entry.alpha_map.clone() if cfg.return_alpha else None,
+                entry.depth_map.clone() if cfg.return_depth else None, fi)
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha, g_depth, _g_fi):
@@ -383,9 +484,9 @@ class _GraphedRasterizeFunction(torch.autograd.Function):
         if entry.generation != ctx.generation:
             raise RuntimeError('graph replay: a later forward of the same shapes has replaced the residual maps of this call; '
                                'run backward before the next forward of these shapes, or switch graph replay off')
-        use_rgb = cfg['return_rgb'] and g_rgb is not None
-        use_alpha = cfg['return_alpha'] and g_alpha is not None
-        use_depth = cfg['return_depth'] and g_depth is not None
+        use_rgb = cfg.return_rgb and g_rgb is not None
+        use_alpha = cfg.return_alpha and g_alpha is not None
+        use_depth = cfg.return_depth and g_depth is not None
         if not (use_rgb or use_alpha or use_depth):
             return None, None, None
         want_gt = bool(use_rgb and ctx.needs_input_grad[1])
@@ -405,14 +506,14 @@ def _graph_entry(faces, textures, cfg):
         return None
     dev = faces.device
     B, F = int(faces.shape[0]), int(faces.shape[1])
-    S = int(cfg['image_size'])
+    S = cfg.image_size
     ts = 0
     bg, bg_per_batch, bg_key = None, 0, None
-    if cfg['return_rgb']:
+    if cfg.return_rgb:
         if textures is None or textures.dim() != 6 or textures.dtype != torch.float32 or tuple(textures.shape[:2]) != (B, F):
             return None
         ts = int(textures.shape[2])
-        b = cfg['background_color']
+        b = cfg.background_color
         if torch.is_tensor(b):
             return None  # a device-side background may change between calls: eager path
         arr = np.asarray(b, dtype=np.float32)
@@ -421,15 +522,15 @@ def _graph_entry(faces, textures, cfg):
         elif arr.shape != (3,):
             return None
         bg, bg_key = _background_tensor(b, dev), arr.tobytes()
-    if cfg.get('faces_z_ref') is not None:
+    if cfg.faces_z_ref is not None:
         return None  # sharded batches hand a reference view over per call: eager path
-    key = (dev.index, B, F, S, ts, cfg['return_rgb'], cfg['return_alpha'], cfg['return_depth'], float(cfg['near']),
-           float(cfg['far']), float(cfg['eps']), bg_key, bg_per_batch, cfg['fix_batch_z'], cfg['exact_gradient'])
+    key = (dev.index, B, F, S, ts, cfg.return_rgb, cfg.return_alpha, cfg.return_depth, cfg.near, cfg.far, cfg.eps, bg_key,
+           bg_per_batch, cfg.fix_batch_z, cfg.exact_gradient)
     entry = _GRAPH_CACHE.get(key)
     if entry is None:
         if len(_GRAPH_CACHE) >= 8:
             _GRAPH_CACHE.pop(next(iter(_GRAPH_CACHE)))
-        entry = _GRAPH_CACHE[key] = _GraphEntry(_lib.load(), dev, dict(cfg), B, F, S, ts, bg, bg_per_batch, False)
+        entry = _GRAPH_CACHE[key] = _GraphEntry(_lib.load(), dev, cfg, B, F, S, ts, bg, bg_per_batch, False)
     return entry
 
 
@@ -482,7 +583,15 @@ class Rasterize(object):
     """Same constructor and call convention as the reference's `Rasterize` chainer.Function
     (rasterize.py:19-64): `Rasterize(...)(faces[, textures]) -> (rgb, alpha, depth)` in the internal
     layout (rgb [B,S,S,3], alpha/depth [B,S,S], row 0 = bottom), `None` for outputs not requested.
-    The intermediate maps of the last call stay on the instance like in the reference (:54-58)."""
+    The intermediate maps of the last call stay on the instance like in the reference (:54-58).
+
+    Two ways in, as on a chainer.Function:
+      fn(faces, textures)                          the differentiable call (torch.autograd.Function underneath)
+      fn.forward_gpu((faces, textures)), fn.backward_gpu(inputs, grad_outputs)
+                                                   the Function protocol itself (rasterize.py:467, :849), no autograd graph:
+                                                   what Chainer calls on the reference.  Same kernels, same results; at small
+                                                   batches the direct calls save torch's autograd hand-over to its device
+                                                   thread, which costs more host time than the launches."""
 
     def __init__(self, image_size, near, far, eps, background_color, return_rgb=False, return_alpha=False,
                  return_depth=False):
@@ -504,44 +613,127 @@ class Rasterize(object):
         # the reference samples textures with batch element 0's depths); None = element 0 of this call
         self.faces_z_ref = None
         # buffers of the last call, as on the reference's Function (rasterize.py:39-64).  The reference also keeps
-        # face_inv_map and the two sampling maps; here they are recomputed inside the backward kernels instead of being
-        # stored, so those three attributes stay None.
+        # face_inv_map and the two sampling maps; the kernels here recompute them instead of storing them, so
+        # those three are properties that run the per-stage entry point with the optional pointers when somebody reads them.
         self.faces = self.textures = None
         self.grad_rgb_map = self.grad_alpha_map = self.grad_depth_map = None
         self.rgb_map = self.alpha_map = self.depth_map = None
         self.grad_faces = self.grad_textures = None
         self.face_index_map = self.weight_map = None
-        self.face_inv_map = self.sampling_index_map = self.sampling_weight_map = None
         self.batch_size = self.num_faces = self.texture_size = None
+        self._res = None    # residuals of the last forward (forward_gpu / backward_gpu protocol, lazy maps)
+        self._lazy = {}
+
+    # ---- the buffers of the last call (rasterize.py:39-58)
+    def _keep(self, r):
+        self._res = r
+        self._lazy = {}
+        self.faces, self.textures = r.faces, r.textures
+        self.face_index_map, self.weight_map, self.depth_map = r.face_index_map, r.weight_map, r.depth_map
+        self.rgb_map, self.alpha_map = r.rgb_map, r.alpha_map
+        self.batch_size, self.num_faces = r.B, r.F
+        self.texture_size = r.ts if self.return_rgb else None
+
+    def _lazy_maps(self, which):
+        """face_inv_map [B,S,S,3,3] (rasterize.py:57) or the sampling maps [B,S,S,8] (:47-48) of the last call: not kept by
+        the kernels (they recompute them), so reading one runs the per-stage entry point with the optional output pointers."""
+        if which in self._lazy:
+            return self._lazy[which]
+        r = self._res
+        if r is None:
+            return None
+        lib = _lib.load()
+        dev = r.faces.device
+        B, F, S, ts = r.B, r.F, r.S, r.ts
+        f32 = torch.float32
+        with _on_device(dev):
+            stream = _stream_ptr(dev)
+            if which == 'face_inv_map':
+                out = torch.empty((B, S, S, 3, 3), dtype=f32, device=dev)
+                ws_bytes = lib.nr_forward_workspace_bytes(B, F, S)
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+                fi = torch.empty_like(r.face_index_map)
+                wm = torch.empty((B, S, S, 3), dtype=f32, device=dev)
+                dm = torch.empty((B, S, S), dtype=f32, device=dev)
+                _lib.check(lib.nr_forward_face_index_map(r.faces.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(),
+                                                         out.data_ptr(), None, B, F, S, float(self.near), float(self.far),
+                                                         ws.data_ptr(), ws_bytes, stream), 'nr_forward_face_index_map')
+                self._lazy['face_inv_map'] = out
+            else:
+                if r.textures is None or r.light is not None:
+                    return None  # no texture sampling in this call (or per-face light colours: no reference counterpart)
+                si = torch.empty((B, S, S, 8), dtype=torch.int32, device=dev)
+                sw = torch.empty((B, S, S, 8), dtype=f32, device=dev)
+                rgb = torch.empty((B, S, S, 3), dtype=f32, device=dev)
+                bg = self.background_color if self.background_color is not None else DEFAULT_BACKGROUND_COLOR
+                bg = bg.detach().to(device=dev, dtype=f32).contiguous() if torch.is_tensor(bg) else _background_tensor(bg, dev)
+                _lib.check(lib.nr_forward_texture_sampling(
+                    r.faces.data_ptr(), _lib.ptr(r.z_ref), r.textures.data_ptr(), r.face_index_map.data_ptr(),
+                    r.weight_map.data_ptr(), r.depth_map.data_ptr(), rgb.data_ptr(), si.data_ptr(), sw.data_ptr(), bg.data_ptr(),
+                    int(tuple(bg.shape) == (B, 3)), None, B, F, S, ts, float(self.eps), r.flags, stream),
+                    'nr_forward_texture_sampling')
+                self._lazy['sampling_index_map'], self._lazy['sampling_weight_map'] = si, sw
+        return self._lazy[which]
+
+    face_inv_map = property(lambda self: self._lazy_maps('face_inv_map'))
+    sampling_index_map = property(lambda self: self._lazy_maps('sampling_index_map'))
+    sampling_weight_map = property(lambda self: self._lazy_maps('sampling_weight_map'))
+
+    # ---- the chainer.Function protocol of the reference (rasterize.py:467-513, :849-889)
+    def forward_gpu(self, inputs, face_light=None):
+        """inputs = (faces,) or (faces, textures) -> (rgb_map, alpha_map, depth_map), `None` for outputs not requested.  Keeps
+        the maps on the instance for backward_gpu.  No autograd graph is recorded."""
+        faces = inputs[0]
+        textures = inputs[1] if len(inputs) > 1 and self.return_rgb else None
+        r = _forward_impl(_Config(self), faces, textures, face_light if self.return_rgb else None)
+        self._keep(r)
+        return (r.rgb_map if self.return_rgb else None, r.alpha_map if self.return_alpha else None,
+                r.depth_map if self.return_depth else None)
+
+    forward = forward_gpu
+
+    def backward_gpu(self, inputs, grad_outputs):
+        """grad_outputs = (grad_rgb_map, grad_alpha_map, grad_depth_map), `None` = zeros (rasterize.py:858-878) ->
+        (grad_faces,) or (grad_faces, grad_textures) like :886-889; with face_light also grad_light (third).  `inputs` is
+        accepted for the protocol's sake: the residuals of the last forward_gpu are what is used."""
+        r = self._res
+        if r is None:
+            raise RuntimeError('backward_gpu before forward_gpu')
+        g_rgb, g_alpha, g_depth = (tuple(grad_outputs) + (None, None, None))[:3]
+        gf, gt, gl = _backward_impl(_Config(self), r, g_rgb, g_alpha, g_depth, self.return_rgb, r.light is not None)
+        if gf is None:  # no gradient at all: zeros (:851-853)
+            gf = torch.zeros_like(r.faces)
+        if not self.return_rgb or len(inputs) < 2:
+            return (gf,)
+        if gt is None:
+            gt = torch.zeros_like(r.textures)
+        return (gf, gt) if r.light is None else (gf, gt, gl)
+
+    backward = backward_gpu
 
     def __call__(self, faces, textures=None, face_light=None):
         """`face_light` (not in the reference; include/nr_hip.h nr_face_light): [B,F,3] colours that multiply the sampled
         colour of each face; `textures` are then the cubes of the original faces ([B,F,...], or [B,F/2,...] when the second
         half of `faces` are fill_back's reversed copies)."""
-        keep = {}
-        cfg = dict(keep=keep, owner=weakref.ref(self), image_size=self.image_size, near=self.near, far=self.far, eps=self.eps,
-                   background_color=self.background_color if self.background_color is not None
-                   else DEFAULT_BACKGROUND_COLOR,
-                   return_rgb=bool(self.return_rgb), return_alpha=bool(self.return_alpha),
-                   return_depth=bool(self.return_depth), fix_batch_z=bool(self.fix_batch_z),
-                   exact_gradient=bool(self.exact_gradient), faces_z_ref=self.faces_z_ref)
+        cfg = _Config(self)
         if not self.return_rgb:
             textures = face_light = None
-        entry = _graph_entry(faces, textures, cfg) if self.graph_replay and face_light is None else None
-        if entry is not None and torch.is_grad_enabled() and (faces.requires_grad or (textures is not None and textures.requires_grad)):
-            # the usual case: every requested output receives a gradient
-            entry.prepare_backward((bool(self.return_rgb), bool(self.return_alpha), bool(self.return_depth),
-                                    bool(self.return_rgb and textures is not None and textures.requires_grad)))
-        if entry is not None:
-            rgb, alpha, depth, fi = _GraphedRasterizeFunction.apply(faces, textures, entry)
-            keep.update(faces=entry.faces, textures=entry.textures, weight_map=entry.weight_map, depth_map=depth if depth is not None else entry.depth_map,
-                        rgb_map=rgb, alpha_map=alpha, batch_size=entry.dims[0], num_faces=entry.dims[1],
-                        texture_size=entry.dims[3] if self.return_rgb else None)
-        else:
-            rgb, alpha, depth, fi = _RasterizeFunction.apply(faces, textures, cfg, face_light)
-        for k, v in keep.items():
-            setattr(self, k, v)
-        self.face_index_map = fi
+        if self.graph_replay and face_light is None:
+            entry = _graph_entry(faces, textures, cfg)
+            if entry is not None:
+                if torch.is_grad_enabled() and (faces.requires_grad or (textures is not None and textures.requires_grad)):
+                    # the usual case: every requested output receives a gradient
+                    entry.prepare_backward((bool(self.return_rgb), bool(self.return_alpha), bool(self.return_depth),
+                                            bool(self.return_rgb and textures is not None and textures.requires_grad)))
+                rgb, alpha, depth, fi = _GraphedRasterizeFunction.apply(faces, textures, entry)
+                self._res, self._lazy = None, {}
+                self.faces, self.textures, self.weight_map = entry.faces, entry.textures, entry.weight_map
+                self.depth_map = depth if depth is not None else entry.depth_map
+                self.rgb_map, self.alpha_map, self.face_index_map = rgb, alpha, fi
+                self.batch_size, self.num_faces = entry.dims[0], entry.dims[1]
+                self.texture_size = entry.dims[3] if self.return_rgb else None
+                return rgb, alpha, depth
+        rgb, alpha, depth, _ = _RasterizeFunction.apply(faces, textures, cfg, face_light)
         return rgb, alpha, depth
 
 

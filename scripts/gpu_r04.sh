@@ -30,8 +30,14 @@ done
 unset NR_HIP_LIB
 [ -f $OUT/variants.log ] && cat $OUT/variants.log
 for b in ${SHARDS}; do
-  B=$b TAG=B$b ITERS=30 timeout 200 python scripts/stage_times.py 2>&1 | tail -1 >> $OUT/shards.log
-  B=$b timeout 200 python scripts/thread_gap_probe.py 2>/dev/null | tail -6 | sed "s/^/B$b /" >> $OUT/shards.log
+  for v in "" ${SHARD_VARIANTS}; do
+    if [ -z "$v" ]; then unset NR_HIP_LIB; else export NR_HIP_LIB=$PWD/neural_renderer_amd/libnr_hip_$v.so; fi
+    for fl in 0 ${SHARD_FLAGS}; do
+      B=$b NR_STAGE_FLAGS=$fl TAG=B${b}_lib${v:-new}_flags$fl ITERS=30 timeout 200 python scripts/stage_times.py 2>&1 | tail -1 >> $OUT/shards.log
+    done
+  done
+  unset NR_HIP_LIB
+  [ -n "$SHARD_PROBE" ] && B=$b timeout 200 python scripts/thread_gap_probe.py 2>/dev/null | tail -6 | sed "s/^/B$b /" >> $OUT/shards.log
 done
 [ -f $OUT/shards.log ] && cat $OUT/shards.log
 if [ -n "$HOSTPROF" ]; then

@@ -101,7 +101,8 @@ def main():
     for name in os.environ.get('SCENES', 'H C4').split():
         faces, tex, S, (rgb, alpha), bg, seed = scene(name)
         t0 = time.time()
-        fn = O.Rasterize(S, 0.1, 100, 1e-3, bg, rgb, alpha, False)
+        eps = float(os.environ.get('EPS', 1e-3))
+        fn = O.Rasterize(S, 0.1, 100, eps, bg, rgb, alpha, False)
         fn.blocked = True
         fn(faces, tex) if rgb else fn(faces)
         rng = np.random.default_rng(seed)
@@ -112,7 +113,7 @@ def main():
         noise = H.rel_err(fn.backward(g_rgb, g_alpha, None, skip_textures=True)[0], ref)
         t_oracle = time.time() - t0
         use_library('')
-        fw = abi.forward_fused(faces, tex, S, 0.1, 100.0, 1e-3, bg, 0, rgb, alpha, False)
+        fw = abi.forward_fused(faces, tex, S, 0.1, 100.0, eps, bg, 0, rgb, alpha, False)
         assert int((abi.host(fw['face_index_map']) != fn.face_index_map).sum()) == 0
         gr = abi.dev(g_rgb, torch.float32) if rgb else None
         ga = abi.dev(g_alpha, torch.float32) if alpha else None
@@ -126,7 +127,7 @@ def main():
                 err = np.abs(gf.astype(np.float64) - ref)
                 print(json.dumps({
                     'scene': name, 'B': int(faces.shape[0]), 'F': int(faces.shape[1]), 'S': S, 'variant': tag or 'product',
-                    'mode': 'exact' if flags else 'default', 'stage_us': us,
+                    'mode': 'exact' if flags else 'default', 'eps': eps, 'stage_us': us,
                     'err_floor_metric': H.rel_err(gf, ref), 'max_abs_err': float(err.max()), 'max_abs': float(np.abs(ref).max()),
                     'frac_within_1e-4_elementwise': float(np.mean(err[ok] <= 1e-4 * np.abs(ref[ok]))),
                     'frac_within_1e-5_elementwise': float(np.mean(err[ok] <= 1e-5 * np.abs(ref[ok]))),

@@ -1,0 +1,57 @@
+"""Development: time the K6 stage call (nr_backward_pixel_map) and the fused backward for several libraries (variant builds,
+NR_K6_* knobs of csrc/nr_k6_tune.h) on teapot batches of several sizes, one process.
+    VARIANTS="t256b40 t128b20" SHAPES="8x256 16x256 64x256 64x512" python scripts/k6_variants.py"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench
+import neural_renderer_amd as nr
+from neural_renderer_amd import _lib
+from k6_numerics import use_library
+
+dev = torch.device('cuda', 0)
+iters = int(os.environ.get('ITERS', 30))
+variants = [''] + os.environ.get('VARIANTS', '').split()
+for shape in os.environ.get('SHAPES', '8x256 16x256 32x256 64x256').split():
+    B, S = (int(x) for x in shape.split('x'))
+    use_library('')
+    faces, textures = bench.build_scene(dev, B, 0, 64 if B <= 64 else B, S, 2)
+    F, ts = faces.shape[1], 2
+    g_rgb, g_alpha, g_depth = bench.upstream_gradients(faces, textures, S, 1e-3, 1234)
+    fn = nr.Rasterize(S, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
+    fn.forward_gpu((faces, textures))
+    r = fn._res
+    row = {'B': B, 'S': S}
+    for tag in [variants[0]] + variants:  # (the first pass is thrown away: whatever runs first is ~3 % slow)
+        lib = use_library(tag)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        gf = torch.empty_like(faces)
+        gt = torch.empty_like(textures)
+        wsb = lib.nr_backward_workspace_bytes(B, F, S, 1, 1)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        calls = {
+            'k6': lambda: lib.nr_backward_pixel_map(faces.data_ptr(), r.face_index_map.data_ptr(), r.rgb_map.data_ptr(),
+                                                    r.alpha_map.data_ptr(), g_rgb.data_ptr(), g_alpha.data_ptr(), gf.data_ptr(), B, F,
+                                                    S, 1e-3, 1, 1, 0, r.visible.data_ptr(), ws.data_ptr(), wsb, st),
+            'bwd': lambda: lib.nr_backward_rasterize(faces.data_ptr(), None, r.face_index_map.data_ptr(), r.weight_map.data_ptr(),
+                                                     r.depth_map.data_ptr(), r.rgb_map.data_ptr(), r.alpha_map.data_ptr(),
+                                                     g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(),
+                                                     gt.data_ptr(), B, F, S, ts, 1e-3, 0, r.visible.data_ptr(), ws.data_ptr(), wsb, st)}
+        for name, call in calls.items():
+            for _ in range(3):
+                _lib.check(call(), name)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            row['%s_%s' % (tag or 'product', name)] = round(e0.elapsed_time(e1) * 1e3 / iters, 1)
+    print(json.dumps(row), flush=True)
+use_library('')

@@ -71,7 +71,10 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_host_only_entry_points(lib_path):
     lib = _lib.load()
-    assert lib.nr_version() == 300
+    assert lib.nr_version() == 400 == _lib.NR_VERSION
+    import neural_renderer_amd
+    v = _lib.NR_VERSION
+    assert neural_renderer_amd.__version__ == '%d.%d.%d' % (v // 1000, v // 100 % 10, v % 100)
     assert lib.nr_error_string(0) == b'success'
     assert b'workspace' in lib.nr_error_string(-3)
     assert lib.nr_forward_workspace_bytes(64, 4928, 256) >= 64 * 256 * 256 * 8 + 64 * 4928 * 4

@@ -914,3 +914,161 @@ def test_graph_replay_equals_the_eager_operator():
         imgs.append((img.detach().cpu().numpy(), vt.grad.cpu().numpy()))
     np.testing.assert_array_equal(imgs[0][0], imgs[1][0])
     assert H.rel_err(imgs[1][1], imgs[0][1]) <= 1e-5
+
+
+def test_function_protocol_equals_the_autograd_operator():
+    """`fn.forward_gpu(inputs)` / `fn.backward_gpu(inputs, grad_outputs)` -- the chainer.Function protocol of the reference
+    (rasterize.py:467, :849), no autograd graph -- return what the differentiable call returns: maps bit for bit, gradients
+    up to K6's summation order; `None` gradients are zeros; the buffers stay on the instance (:39-58)."""
+    import neural_renderer_amd as nr
+    rng = np.random.default_rng(77)
+    S, B = 96, 3
+    faces_np, _ = H.teapot_views(B, S)
+    tex_np = rng.uniform(0, 1, (B, faces_np.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    g = [torch.tensor(rng.normal(size=(B, S, S, 3)).astype(np.float32), device='cuda'),
+         torch.tensor(rng.normal(size=(B, S, S)).astype(np.float32), device='cuda'),
+         torch.tensor(rng.normal(size=(B, S, S)).astype(np.float32), device='cuda')]
+    for modes in ((True, True, True), (False, True, False), (False, False, True), (True, False, False)):
+        ft = torch.tensor(faces_np, device='cuda', requires_grad=True)
+        tt = torch.tensor(tex_np, device='cuda', requires_grad=True)
+        op = nr.Rasterize(S, 0.1, 100, 1e-3, (0.1, 0.2, 0.3), *modes)
+        outs = op(ft, tt)
+        sel = [(o, gg) for o, gg in zip(outs, g) if o is not None]
+        torch.autograd.backward([o for o, _ in sel], [gg for _, gg in sel])
+        fn = nr.Rasterize(S, 0.1, 100, 1e-3, (0.1, 0.2, 0.3), *modes)
+        inputs = (ft.detach(), tt.detach()) if modes[0] else (ft.detach(),)
+        outs2 = fn.forward_gpu(inputs)
+        for a, b2 in zip(outs, outs2):
+            assert (a is None) == (b2 is None)
+            if a is not None:
+                np.testing.assert_array_equal(a.detach().cpu().numpy(), b2.cpu().numpy())
+                assert not b2.requires_grad
+        np.testing.assert_array_equal(fn.face_index_map.cpu().numpy(), op.face_index_map.cpu().numpy())
+        grads = fn.backward_gpu(inputs, tuple(gg if o is not None else None for o, gg in zip(outs2, g)))
+        assert len(grads) == (2 if modes[0] else 1)
+        tol = SAME_TERMS if (modes[0] or modes[1]) else 0.0
+        assert H.rel_err(grads[0].cpu().numpy(), ft.grad.cpu().numpy()) <= tol
+        assert fn.grad_faces is not None and fn.faces is not None and fn.batch_size == B and fn.num_faces == faces_np.shape[1]
+        if modes[0]:
+            np.testing.assert_array_equal(grads[1].cpu().numpy(), tt.grad.cpu().numpy())
+        # no gradient at all: zeros, like rasterize.py:851-853
+        zero = fn.backward_gpu(inputs, (None, None, None))
+        assert all(float(z.abs().max()) == 0.0 for z in zero)
+    with pytest.raises(RuntimeError):
+        nr.Rasterize(S, 0.1, 100, 1e-3, (0, 0, 0), False, True, False).backward_gpu((ft.detach(),), (None, g[1], None))
+
+
+def test_lazy_residual_maps_on_the_instance():
+    """The reference keeps face_inv_map and the two sampling maps on the Function (rasterize.py:47-48, :57); here the kernels
+    recompute them, and reading the attribute runs the per-stage entry point with the optional pointers: same values as the
+    oracle's maps."""
+    import neural_renderer_amd as nr
+    rng = np.random.default_rng(78)
+    S, B = 64, 2
+    faces_np, _ = H.teapot_views(B, S)
+    tex_np = rng.uniform(0, 1, (B, faces_np.shape[1], 3, 3, 3, 3)).astype(np.float32)
+    ref = oracle_forward(faces_np, tex_np, S, 0.1, 100, 1e-3, (0.2, 0.4, 0.6), True, True, True)
+    fn = nr.Rasterize(S, 0.1, 100, 1e-3, (0.2, 0.4, 0.6), True, True, True)
+    assert fn.face_inv_map is None and fn.sampling_index_map is None  # nothing rendered yet
+    fn(torch.tensor(faces_np, device='cuda'), torch.tensor(tex_np, device='cuda'))
+    # (the stage kernels write every element, init values included: whole maps compare)
+    np.testing.assert_array_equal(fn.face_inv_map.cpu().numpy(), ref.face_inv_map)
+    np.testing.assert_array_equal(fn.sampling_weight_map.cpu().numpy(), ref.sampling_weight_map)
+    np.testing.assert_array_equal(fn.sampling_index_map.cpu().numpy(), ref.sampling_index_map)
+    assert fn.sampling_weight_map is fn.sampling_weight_map  # computed once per call
+    fn2 = nr.Rasterize(S, 0.1, 100, 1e-4, None, False, True, False)
+    fn2(torch.tensor(faces_np, device='cuda'))
+    assert fn2.sampling_index_map is None and fn2.face_inv_map is not None
+
+
+def test_workspace_cache_is_bounded_and_can_be_cleared():
+    """The kept forward workspaces (8 B per raster pixel): least recently used first out, a byte cap, clear_workspace_cache()."""
+    import neural_renderer_amd as nr
+    import sys
+    R = sys.modules['neural_renderer_amd.rasterize']  # (the package attribute `rasterize` is the function)
+    nr.clear_workspace_cache()
+    faces = torch.tensor(H.random_scene(np.random.default_rng(5), 1, 8), device='cuda')
+    for S in range(8, 8 + 20):
+        nr.Rasterize(S, 0.1, 100, 1e-3, None, False, True, False)(faces)
+    assert 0 < len(R._ZBUF_CACHE) <= 16
+    first = next(iter(R._ZBUF_CACHE))
+    nr.Rasterize(first[4], 0.1, 100, 1e-3, None, False, True, False)(faces)  # a hit moves the entry to the young end
+    assert next(reversed(R._ZBUF_CACHE)) == first
+    cap = R._ZBUF_CACHE_BYTES
+    try:
+        R._ZBUF_CACHE_BYTES = 1024  # nothing fits: every call takes the per-call fill, results unchanged
+        nr.clear_workspace_cache()
+        a = nr.Rasterize(64, 0.1, 100, 1e-3, None, False, True, False)(faces)[1]
+        assert len(R._ZBUF_CACHE) == 0
+    finally:
+        R._ZBUF_CACHE_BYTES = cap
+    b = nr.Rasterize(64, 0.1, 100, 1e-3, None, False, True, False)(faces)[1]
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    nr.clear_workspace_cache()
+    assert len(R._ZBUF_CACHE) == 0
+
+
+_CAPTURE_AFTER_REPLAY = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import numpy as np
+import neural_renderer_amd as nr
+R = sys.modules['neural_renderer_amd.rasterize']
+faces = torch.rand((2, 50, 3, 3), device='cuda') - 0.5
+faces[..., 2] += 2.0
+f = faces.clone().requires_grad_(True)
+fn = nr.Rasterize(32, 0.1, 100, 1e-3, None, False, True, False)
+fn.graph_replay = True
+fn(f)[1].sum().backward()          # the operator's replay mode has captured graphs now
+torch.cuda.synchronize()
+assert len(R._GRAPH_CACHE) == 1
+g = faces.clone().requires_grad_(True)
+def step():
+    g.grad = None
+    nr.Rasterize(32, 0.1, 100, 1e-3, None, False, True, False)(g)[1].sum().backward()
+try:
+    nr.graph.capture(step)
+    print('CAPTURED')
+except RuntimeError as e:
+    print('REFUSED', str(e)[:60])
+R.clear_graph_replay_cache()
+print('CLEARED', len(R._GRAPH_CACHE))
+'''
+
+
+def test_whole_step_capture_after_operator_replay_is_refused():
+    """ROCm 7.2 / torch 2.10: capturing a whole step after the operator's graph-replay mode has captured graphs in the same
+    process crashes inside torch's capture (a host segfault; LAB-NOTEBOOK round 3).  `graph.capture` refuses with a clear
+    RuntimeError instead.  In a subprocess, so that a crash would fail this test and not the session."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, '-c', _CAPTURE_AFTER_REPLAY % root], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stdout[-500:], res.stderr[-1500:])
+    assert 'REFUSED' in res.stdout and 'CAPTURED' not in res.stdout and 'CLEARED 0' in res.stdout
+
+
+def test_operator_does_not_leak_device_memory():
+    """The autograd node must not hold its own outputs outside save_for_backward (output -> grad_fn -> node -> output is a cycle
+    through C++ that nothing collects): after warm-up, steps of the differentiable call leave the allocated bytes unchanged."""
+    import gc
+    import neural_renderer_amd as nr
+    faces = torch.tensor(H.teapot_views(2, 64)[0], device='cuda', requires_grad=True)
+    tex = torch.ones((2, faces.shape[1], 2, 2, 2, 3), device='cuda', requires_grad=True)
+
+    def step():
+        faces.grad = tex.grad = None
+        fn = nr.Rasterize(64, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
+        rgb, alpha, depth = fn(faces, tex)
+        (rgb.sum() + alpha.sum() + depth.sum()).backward()
+
+    for _ in range(5):
+        step()
+    gc.collect()
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    for _ in range(20):
+        step()
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() <= before + (1 << 16), (before, torch.cuda.memory_allocated())

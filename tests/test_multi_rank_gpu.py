@@ -48,5 +48,11 @@ def test_bench_two_ranks_on_one_gpu(gather):
     lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['value'] > 0 and d['steps'] == 2 and d['scaling'] == 'weak'
+    # the 64-view batch is SPLIT (BASELINE.md "Multi-GPU rows": B / R views per rank); 64 per GPU is the weak_scaling object
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['steps'] == 2 and d['scaling'] == 'strong'
+    assert d['config']['views_total'] == 64 and d['config']['views_per_gpu'] == 64 // 2
+    assert abs(d['value'] - 64 * 256 * 256 / (d['ms_per_step'] * 1e-3) / 1e6) <= 1e-6 * d['value']
+    w = d['weak_scaling']
+    assert w['scaling'] == 'weak' and w['views_per_gpu'] == 64 and w['views_total'] == 128 and w['value'] > 0
     assert ('all_gather' in d['config']['parallelism']) == gather
+    assert d['cpu_baseline'] is None  # (--cpu-sample-views 0 in this test; an N > 1 run otherwise carries rank 0's CPU rows)
