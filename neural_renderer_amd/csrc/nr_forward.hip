@@ -37,6 +37,9 @@ namespace {
 // negative ones), so any `near` -- the reference accepts any, :331 -- orders correctly, faces behind the camera
 // (negative zp with near < 0) included.  The result does not depend on the order of the atomics:
 // face_index_map is bit-reproducible.
+#ifndef NR_FWD_SMALL_WAVES  // launches of fewer than this many x 32 faces take 16 faces per wave (0: never)
+#define NR_FWD_SMALL_WAVES 16384
+#endif
 constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized by k_face_raster (measured with the round-2 form of
                                   // the kernel: 128 / 64 make config 4 15 % / 28 % slower, the headline +0 / +11 %)
 constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (wave_raster); beyond, and strips: one workgroup (k_large_raster)
@@ -151,9 +154,10 @@ __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S
 #define FR_PIX 256  // pixel items per window (7.4 KB of LDS per wave: five workgroups per CU)
 #endif
 // FACES: faces per wave (its first FACES lanes take one each) and GROUP: consecutive faces per run of the face -> lane mapping
-// are template parameters: 64 / 16 in general, 32 / 8 for launches of fewer than 2048 such waves (less than two per SIMD: the
-// kernel is then one round of waves and as long as a wave lives -- 16 teapot views: 25 -> 17 us; at 64 views and on config 4
-// the halves cost 0-12 %).
+// are template parameters: 64 / 16 for large launches, 16 / 4 below 16 384 x 32 faces (round 4: the kernel is latency-bound,
+// a wave lives as long as its rows and pixels take, and smaller waves' worth of faces means more, shorter waves -- fused
+// forward in us, teapot views at 256^2: 8 views 43 -> 32, 16 views 42 -> 34, 32 views 62 -> 47, 48 views 67 -> 58, 64 views
+// 70 -> 70; 64 views at 512^2 306 -> 290; rounds 2-3 had 32 / 8 below 2048 x 64 faces).
 // Measured and dropped: two pixels per lane and evaluation step (neutral, more code); the row interval estimated from the edge
 // equations and pinned down with ~4 exact tests by a one-test-per-step state machine (89 vs 81 us fused forward).
 static_assert(SMALL_AREA <= 256, "rows and columns of a kept box are packed into 8 bits each");
@@ -684,11 +688,11 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     }
     int *wave_list = large_list + n;
     {
-        const bool pow2 = (S & (S - 1)) == 0, few = n < 2048 * 64;
+        const bool pow2 = (S & (S - 1)) == 0, small = n < (size_t)NR_FWD_SMALL_WAVES * 32;
 #define NR_FACE_RASTER(P, FC, G)                                                                                           \
     hipLaunchKernelGGL((k_face_raster<P, FC, G>), dim3((unsigned)((n + 4 * FC - 1) / (4 * FC))), dim3(256), 0, st, faces, zbuf, \
                        large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far, epoch)
-        if (few) { if (pow2) NR_FACE_RASTER(true, 32, 8); else NR_FACE_RASTER(false, 32, 8); }
+        if (small) { if (pow2) NR_FACE_RASTER(true, 16, 4); else NR_FACE_RASTER(false, 16, 4); }
         else { if (pow2) NR_FACE_RASTER(true, 64, 16); else NR_FACE_RASTER(false, 64, 16); }
 #undef NR_FACE_RASTER
     }
