@@ -17,23 +17,16 @@ to a kernel -- is settled by the warm-up calls, which run outside the capture.""
 import torch
 
 
-def capture(fn, device=None, warmup=3, _operator_replay=False):
+def capture(fn, device=None, warmup=3):
     """Run `fn` `warmup` times on a side stream (allocator and kernel attributes settle), capture one more call into a
     graph and return a zero-argument callable that replays it.  Tensors created inside `fn` live in the graph's private
     pool: read results from the tensors `fn` assigns to (e.g. `.grad` fields or pre-allocated outputs).
 
-    Raises RuntimeError when the operator's own graph-replay mode (`use_graph_replay` / NR_GRAPH_REPLAY / `graph_replay`
-    attributes) has captured graphs in this process: on ROCm 7.2 / torch 2.10 a capture of a step that contains the
-    operator, started after that, takes the process down inside torch's capture (tests/test_hip_parity.py::
-    test_whole_step_capture_after_operator_replay_is_refused).  Use one mode or the other, or
-    `neural_renderer_amd.rasterize.clear_graph_replay_cache()` first (then the capture goes ahead at the caller's risk)."""
-    if not _operator_replay:
-        import sys
-        _r = sys.modules[__package__ + '.rasterize']  # (the package attribute of that name is the function)
-        if _r._GRAPH_CACHE:
-            raise RuntimeError('neural_renderer_amd.graph.capture: the operator-level graph replay has captured graphs in this '
-                               'process; a whole-step capture after it crashes on this ROCm / torch stack.  Capture the whole '
-                               'step first, keep graph_replay off, or call rasterize.clear_graph_replay_cache().')
+    (Round 3 had a crash here -- a whole-step capture after the operator's own graph-replay mode had run in the same process
+    took the process down inside torch's capture.  It came from that round's host code, not from the kernels (round 3's
+    Python with this round's library still crashes, this round's Python with round 3's library does not:
+    scripts/graph_crash_probe.py), and is gone with the rewritten operator; tests/test_hip_parity.py::
+    test_whole_step_capture_after_operator_replay runs the sequence in a subprocess.)"""
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     side = torch.cuda.Stream(device=device)
     side.wait_stream(torch.cuda.current_stream(device))

@@ -102,10 +102,8 @@ def _background_tensor(bg, device):
 # results are returned as copies, so callers may keep them; what replay cannot offer is two forwards of the same shapes in
 # flight before the first one's backward (the residual maps live in the fixed buffers) -- that raises.  Measured (config 2):
 # 0.25 ms eager -> 0.21 ms with replay; a step captured as a whole by the caller (neural_renderer_amd.graph.capture: no
-# copies, loss and optimizer inside) 0.17 ms -- prefer that where the whole step is fixed.  Known limitation (ROCm 7.2 /
-# torch 2.10): a whole-step capture started AFTER this mode has run in the same process crashes the process inside torch's
-# capture; neural_renderer_amd.graph.capture therefore refuses (RuntimeError) once this mode holds captured graphs -- use one
-# or the other, or call `clear_graph_replay_cache()` first.
+# copies, loss and optimizer inside) 0.17 ms -- prefer that where the whole step is fixed.  (Round 3's crash of a whole-step
+# capture after this mode had run is gone: neural_renderer_amd.graph.capture.)  `clear_graph_replay_cache()` drops the graphs.
 GRAPH_REPLAY = bool(int(os.environ.get('NR_GRAPH_REPLAY', '0')))
 
 
@@ -365,7 +363,7 @@ class _RasterizeFunction(torch.autograd.Function):
 def _capture(fn, dev):
     """Warm `fn` up on a side stream, then capture it (see neural_renderer_amd.graph.capture)."""
     from .graph import capture
-    return capture(fn, dev, warmup=2, _operator_replay=True)
+    return capture(fn, dev, warmup=2)
 
 
 class _GraphEntry(object):

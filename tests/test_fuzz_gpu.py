@@ -156,3 +156,57 @@ def test_fuzz_micro_triangles_and_needles(seed):
         if _coverage_mismatches(faces, S):
             bad.append(('needle', it, S))
     assert not bad, bad
+
+
+@pytest.mark.parametrize('seed', [31, 32])
+def test_fuzz_default_k6_error_levels(seed):
+    """How far the default (tolerance-mode) K6 kernel gets from the exactly summed reference terms on scenes built to cancel:
+    many overlapping faces of similar, bright colours (small `diff`, both signs), large and small `eps` (with a large eps every
+    term of a sweep has the same size, so thousands of comparable terms cancel), alpha-only and colour-only modes, meshes seen
+    edge-on.  The default kernel is ~1 ulp per term with double sums above a piece, so its deviation in the parity metric
+    (helpers.rel_err: |a - b| / max(|b|, 1e-3 max|b|)) must stay below the north star's 1e-4 whatever the scene; the levels go
+    to gpurun_out/parity_errors.jsonl (`worst` per scene family)."""
+    from test_hip_parity import icosphere, project_mesh, report
+    rng = np.random.default_rng(seed)
+    worst = {}
+    failures = []
+    for it in range(14):
+        family = ['soup', 'bright_soup', 'sphere', 'teapot', 'big_faces'][it % 5]
+        S = int(rng.choice([96, 128, 200, 256]))
+        eps = float(rng.choice([1e-4, 1e-3, 1e-2, 0.1]))
+        B = 2
+        if family in ('soup', 'bright_soup'):
+            faces = H.random_scene(rng, B, int(rng.choice([800, 2500])), spread=0.7, size=float(rng.choice([0.08, 0.25])))
+        elif family == 'big_faces':
+            faces = H.random_scene(rng, B, 60, spread=0.5, size=1.2)
+        elif family == 'sphere':
+            v0, f0 = icosphere(3)
+            faces = np.stack([project_mesh((v0 * (0.5 + 0.2 * rng.normal(size=(v0.shape[0], 1)))).astype(np.float32), f0,
+                                           [float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), -2.6])
+                              for _ in range(B)])
+        else:
+            faces = H.teapot_views(64, S)[0][rng.integers(0, 64, B)]
+        F = faces.shape[1]
+        if family == 'bright_soup':  # nearly equal colours: `diff` is the small difference of large products
+            textures = (0.9 + 0.1 * rng.uniform(size=(B, F, 2, 2, 2, 3))).astype(np.float32)
+            bg = (0.95, 0.95, 0.95)
+        else:
+            textures = rng.uniform(0, 1, (B, F, 2, 2, 2, 3)).astype(np.float32)
+            bg = (0.1, 0.2, 0.3)
+        rgb, alpha = [(True, True), (True, False), (False, True)][int(rng.integers(0, 3))]
+        fn = O.Rasterize(S, 0.1, 100, eps, bg, rgb, alpha, False)
+        fn(faces, textures) if rgb else fn(faces)
+        fw = abi.forward(faces, textures if rgb else None, S, 0.1, 100.0, eps, bg, 0, rgb, alpha, False)
+        assert int((abi.host(fw['face_index_map']) != fn.face_index_map).sum()) == 0
+        scale = float(rng.choice([1.0, 100.0]))
+        g_rgb = (scale * rng.normal(size=(B, S, S, 3))).astype(np.float32) if rgb else None
+        g_alpha = (scale * rng.normal(size=(B, S, S))).astype(np.float32) if alpha else None
+        ref = fn.backward(g_rgb, g_alpha, None, accumulate_double=True)[0]
+        gf = abi.host(abi.backward_fused(fw, g_rgb, g_alpha, None)[0])
+        ge = abi.host(abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=2)[0])
+        e_def, e_exact = H.rel_err(gf, ref), H.rel_err(ge, ref)
+        worst[family] = max(worst.get(family, 0.0), e_def)
+        if not e_def <= 1e-4 or not e_exact <= 2e-6:
+            failures.append((it, family, dict(S=S, eps=eps, rgb=rgb, alpha=alpha, F=F), e_def, e_exact))
+    report('fuzz_default_k6_error_levels', seed=seed, worst=worst)
+    assert not failures, failures
