@@ -57,6 +57,7 @@ extern "C" {
 #endif
 
 #define NR_VERSION 400 /* 0.4.0: NR_FLAG_EXACT_GRADIENT and NR_FLAG_K6_SCAN combine (one band kernel, two arithmetic modes);
+                          *        NR_FLAG_SPARSE_WEIGHT_MAP;
                           * 0.3.0: any `near` (NR_E_NEAR removed); 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
 
 /* argument errors */
@@ -90,6 +91,11 @@ extern "C" {
                                          which fills).  Needs num_faces < 2^24 (ignored otherwise).  Saves the 8 B / pixel fill
                                          of every forward (7 us and 33.5 MB at the headline size). */
 #define NR_ZBUF_EPOCH_FLAGS(e) (NR_FLAG_ZBUF_EPOCH | (((e) & 0xff) << 8))
+#define NR_FLAG_SPARSE_WEIGHT_MAP 32   /* nr_forward_rasterize: weight_map is written for the pixels a face covers only; the
+                                         elements of uncovered pixels (zeros in the reference, rasterize.py:479) are left as
+                                         they are.  For callers that keep weight_map as a residual of the backward -- which
+                                         reads it at covered pixels only -- and do not hand it out: 7 of 8 pixels of a teapot
+                                         view are uncovered (44 of the map's 50 MB at the headline size). */
 
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):

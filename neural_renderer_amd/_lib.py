@@ -64,6 +64,7 @@ NR_FLAG_EXACT_GRADIENT = 2
 NR_FLAG_K6_GLOBAL = 4
 NR_FLAG_K6_SCAN = 8
 NR_FLAG_ZBUF_EPOCH = 16  # + epoch number << 8 (include/nr_hip.h)
+NR_FLAG_SPARSE_WEIGHT_MAP = 32
 NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1
 NR_CAMERA_LOOK = 2

@@ -254,12 +254,14 @@ def _forward_impl(cfg, faces, textures, light):
         r.visible = torch.empty((B, F), dtype=torch.uint8, device=dev)
         ptr = _lib.ptr
         lit = _lib.FaceLight(r.light.data_ptr(), Nf, None, None) if r.light is not None else None
-        # visibility + shading behind one call (rasterize.py:499-502)
+        # visibility + shading behind one call (rasterize.py:499-502).  weight_map is a residual only (the backward reads it at
+        # covered pixels): the zeros of uncovered pixels are not stored (NR_FLAG_SPARSE_WEIGHT_MAP; `Rasterize.weight_map`
+        # fills them in when somebody reads the attribute)
         _lib.check(lib.nr_forward_rasterize_lit(
             lit, r.faces.data_ptr(), ptr(z_ref), ptr(r.textures), r.face_index_map.data_ptr(), ptr(r.weight_map),
             ptr(r.depth_map), ptr(r.rgb_map), ptr(r.alpha_map), r.visible.data_ptr(), ptr(background), bg_per_batch,
-            B, F, S, ts, cfg.near, cfg.far, cfg.eps, flags | ws_flags, workspace.data_ptr(), ws_bytes, stream),
-            'nr_forward_rasterize')
+            B, F, S, ts, cfg.near, cfg.far, cfg.eps, flags | ws_flags | _lib.NR_FLAG_SPARSE_WEIGHT_MAP,
+            workspace.data_ptr(), ws_bytes, stream), 'nr_forward_rasterize')
     return r
 
 
@@ -617,7 +619,7 @@ class Rasterize(object):
         self.grad_rgb_map = self.grad_alpha_map = self.grad_depth_map = None
         self.rgb_map = self.alpha_map = self.depth_map = None
         self.grad_faces = self.grad_textures = None
-        self.face_index_map = self.weight_map = None
+        self.face_index_map = None
         self.batch_size = self.num_faces = self.texture_size = None
         self._res = None    # residuals of the last forward (forward_gpu / backward_gpu protocol, lazy maps)
         self._lazy = {}
@@ -627,7 +629,7 @@ class Rasterize(object):
         self._res = r
         self._lazy = {}
         self.faces, self.textures = r.faces, r.textures
-        self.face_index_map, self.weight_map, self.depth_map = r.face_index_map, r.weight_map, r.depth_map
+        self.face_index_map, self.depth_map = r.face_index_map, r.depth_map
         self.rgb_map, self.alpha_map = r.rgb_map, r.alpha_map
         self.batch_size, self.num_faces = r.B, r.F
         self.texture_size = r.ts if self.return_rgb else None
@@ -667,12 +669,27 @@ class Rasterize(object):
                 bg = bg.detach().to(device=dev, dtype=f32).contiguous() if torch.is_tensor(bg) else _background_tensor(bg, dev)
                 _lib.check(lib.nr_forward_texture_sampling(
                     r.faces.data_ptr(), _lib.ptr(r.z_ref), r.textures.data_ptr(), r.face_index_map.data_ptr(),
-                    r.weight_map.data_ptr(), r.depth_map.data_ptr(), rgb.data_ptr(), si.data_ptr(), sw.data_ptr(), bg.data_ptr(),
+                    self.weight_map.data_ptr(), r.depth_map.data_ptr(), rgb.data_ptr(), si.data_ptr(), sw.data_ptr(), bg.data_ptr(),
                     int(tuple(bg.shape) == (B, 3)), None, B, F, S, ts, float(self.eps), r.flags, stream),
                     'nr_forward_texture_sampling')
                 self._lazy['sampling_index_map'], self._lazy['sampling_weight_map'] = si, sw
         return self._lazy[which]
 
+    def _get_weight_map(self):
+        """weight_map [B,S,S,3] of the last call (rasterize.py:43): the forward stores the weights of covered pixels only; the
+        zeros of the others (:479) are filled in here, once, when the attribute is read."""
+        if 'weight_map' not in self._lazy:
+            r = self._res
+            if r is None or r.weight_map is None:
+                return None
+            self._lazy['weight_map'] = torch.where((r.face_index_map >= 0).unsqueeze(-1), r.weight_map,
+                                                   torch.zeros((), dtype=r.weight_map.dtype, device=r.weight_map.device))
+        return self._lazy['weight_map']
+
+    def _set_weight_map(self, value):
+        self._lazy['weight_map'] = value
+
+    weight_map = property(_get_weight_map, _set_weight_map)
     face_inv_map = property(lambda self: self._lazy_maps('face_inv_map'))
     sampling_index_map = property(lambda self: self._lazy_maps('sampling_index_map'))
     sampling_weight_map = property(lambda self: self._lazy_maps('sampling_weight_map'))
@@ -725,7 +742,7 @@ class Rasterize(object):
                                             bool(self.return_rgb and textures is not None and textures.requires_grad)))
                 rgb, alpha, depth, fi = _GraphedRasterizeFunction.apply(faces, textures, entry)
                 self._res, self._lazy = None, {}
-                self.faces, self.textures, self.weight_map = entry.faces, entry.textures, entry.weight_map
+                self.faces, self.textures, self.weight_map = entry.faces, entry.textures, entry.weight_map  # (dense there)
                 self.depth_map = depth if depth is not None else entry.depth_map
                 self.rgb_map, self.alpha_map, self.face_index_map = rgb, alpha, fi
                 self.batch_size, self.num_faces = entry.dims[0], entry.dims[1]

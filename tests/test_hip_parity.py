@@ -971,6 +971,18 @@ def test_lazy_residual_maps_on_the_instance():
     fn = nr.Rasterize(S, 0.1, 100, 1e-3, (0.2, 0.4, 0.6), True, True, True)
     assert fn.face_inv_map is None and fn.sampling_index_map is None  # nothing rendered yet
     fn(torch.tensor(faces_np, device='cuda'), torch.tensor(tex_np, device='cuda'))
+    # weight_map (rasterize.py:43): the operator's forward stores covered pixels only (NR_FLAG_SPARSE_WEIGHT_MAP); the attribute
+    # fills in the zeros
+    np.testing.assert_array_equal(fn.weight_map.cpu().numpy(), ref.weight_map)
+    assert fn.weight_map is fn.weight_map
+    # the flag at the C ABI: covered pixels as without it, the others untouched (the test driver pre-fills with NaN)
+    fw = abi.forward_fused(faces_np, tex_np, S, 0.1, 100.0, 1e-3, (0.2, 0.4, 0.6), 32, True, True, True)
+    w = abi.host(fw['weight_map'])
+    cov = ref.face_index_map >= 0
+    np.testing.assert_array_equal(w[cov], ref.weight_map[cov])
+    assert np.isnan(w[~cov]).all() and cov.any() and (~cov).any()
+    for k in ('depth_map', 'rgb_map', 'alpha_map'):
+        np.testing.assert_array_equal(abi.host(fw[k]), getattr(ref, k))
     # (the stage kernels write every element, init values included: whole maps compare)
     np.testing.assert_array_equal(fn.face_inv_map.cpu().numpy(), ref.face_inv_map)
     np.testing.assert_array_equal(fn.sampling_weight_map.cpu().numpy(), ref.sampling_weight_map)
