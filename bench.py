@@ -182,10 +182,21 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flag
             faces.data_ptr(), dm.data_ptr(), fi.data_ptr(), None, wm.data_ptr(), g_depth.data_ptr(), gf.data_ptr(),
             B, F, S, st),
     }
-    # the two fused entry points the autograd operator actually calls
-    calls['fused_forward_rasterize'] = lambda: lib.nr_forward_rasterize(
-        faces.data_ptr(), None, textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(),
-        am.data_ptr(), vis.data_ptr(), bg.data_ptr(), 0, B, F, S, ts, 0.1, 100.0, eps, 0, ws.data_ptr(), wsb, st)
+    # the two fused entry points the autograd operator actually calls -- the forward as the operator calls it: a kept workspace
+    # with falling epoch numbers (filled once, here) and weights stored for covered pixels only
+    ws_kept = torch.full((wsb,), 255, dtype=torch.uint8, device=dev)
+    epoch = [254]
+
+    def fused_forward():
+        e = epoch[0]
+        epoch[0] = e - 1 if e > 0 else 254
+        if e == 0:
+            ws_kept.fill_(255)
+        return lib.nr_forward_rasterize(
+            faces.data_ptr(), None, textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(),
+            am.data_ptr(), vis.data_ptr(), bg.data_ptr(), 0, B, F, S, ts, 0.1, 100.0, eps,
+            _lib.NR_FLAG_ZBUF_EPOCH | (e << 8) | _lib.NR_FLAG_SPARSE_WEIGHT_MAP, ws_kept.data_ptr(), wsb, st)
+    calls['fused_forward_rasterize'] = fused_forward
     calls['fused_backward_rasterize'] = lambda: lib.nr_backward_rasterize(
         faces.data_ptr(), None, fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(), am.data_ptr(),
         g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(), gt.data_ptr(), B, F, S, ts, eps, k6_flags,
@@ -406,6 +417,37 @@ def shard_rows(device, total_views, S, ts, eps, steps, gpus=(2, 4, 8)):
         rows.append(row)
         del faces, textures, grads
     return rows
+
+
+def host_floor(device, steps=300):
+    """What a step costs the HOST whatever the batch: one teapot view at 16x16 (a few microseconds of device work per kernel, so
+    the loop is bound by issuing it), the three ways of shard_rows, ms per step.  The difference between the first two rows is
+    torch's hand-over of the backward to its device thread and back; the third is the operator's own Python + ~8 kernel launches."""
+    import neural_renderer_amd as nr
+    faces, textures = build_scene(device, 1, 0, 64, 16, 2)
+    faces.requires_grad_(True)
+    textures.requires_grad_(True)
+    grads = upstream_gradients(faces, textures, 16, 1e-3, 5)
+    fd, td = faces.detach(), textures.detach()
+
+    def autograd_step():
+        faces.grad = None
+        textures.grad = None
+        fn = nr.Rasterize(16, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
+        torch.autograd.backward(list(fn(faces, textures)), list(grads))
+
+    def protocol_step():
+        fn = nr.Rasterize(16, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
+        fn.forward_gpu((fd, td))
+        fn.backward_gpu((fd, td), grads)
+
+    out = {'what': 'one teapot view at 16x16, rgb+alpha+depth forward + backward: host-bound, ms per step (median of 5 runs)'}
+    med = lambda fn: sorted(time_step(fn, device, steps, 10) for _ in range(5))[2]
+    out['ms_autograd'] = med(autograd_step)
+    with nr.graph.backward_on_caller_thread():
+        out['ms_autograd_caller_thread'] = med(autograd_step)
+    out['ms_function_protocol'] = med(protocol_step)
+    return out
 
 
 def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views, light=False):
@@ -757,6 +799,7 @@ def main():
             shards = {'rows': shard_rows(dev, G, S, ts, eps, args.steps),
                       'what': 'rank 0\'s shard of the %d-view job at 2 / 4 / 8 GPUs, timed on this one GPU (ms per step)' % G}
             # no collective in forward + backward: the R-GPU step is the slowest rank's shard step
+            shards['host_floor'] = host_floor(dev)
             shards['predicted_strong_scaling'] = [
                 {'n_gpus': r['gpus_this_shard_belongs_to'], 'views_per_gpu': r['views'],
                  'value_autograd': G * S * S / (r['ms_autograd'] * 1e-3) / 1e6,

@@ -21,6 +21,13 @@ from .save_obj import save_obj
 # not in the reference: multi-GPU helpers and the captured-graph helper for fixed-shape loops
 from . import distributed, graph
 
+# NR_BACKWARD_ON_CALLER_THREAD=1 (opt-in, read once here): graph.backward_on_caller_thread() for the importing thread -- torch's
+# autograd then runs CUDA nodes on the thread that calls backward() instead of handing them to its device thread, which costs a
+# host-bound loop ~80 us per step (bench.py shard_rows).  One process per GPU gains nothing from the device thread.
+import os as _os
+if _os.environ.get('NR_BACKWARD_ON_CALLER_THREAD', '0') not in ('', '0'):
+    graph.backward_on_caller_thread()
+
 # the C ABI's version (include/nr_hip.h NR_VERSION = major * 100 + minor), checked against the loaded library by _lib.load()
 __version__ = '0.4.0'
 __all__ = ['Rasterize', 'rasterize', 'rasterize_depth', 'rasterize_rgbad', 'rasterize_silhouettes', 'use_unsafe_rasterizer', 'use_graph_replay',

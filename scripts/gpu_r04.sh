@@ -64,6 +64,19 @@ if [ -n "$KSTATS" ]; then
   python scripts/rocpd_stats.py $OUT/stats_results.db $OUT/kernel_stats.csv > /dev/null 2>&1
   head -16 $OUT/kernel_stats.csv | cut -c1-70,100-170
 fi
+for c in ${KSTATS_CONFIGS}; do
+  ONLY=$c timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o stats_$c -- python scripts/bench_configs.py > $OUT/stats_$c.log 2>&1
+  python scripts/rocpd_stats.py $OUT/stats_${c}_results.db $OUT/kernel_stats_$c.csv > /dev/null 2>&1
+  head -8 $OUT/kernel_stats_$c.csv | cut -c1-70,100-170
+done
+if [ -n "$NUMERICS" ]; then
+  VARIANTS="" SCENES="${NUMERICS}" ITERS=20 timeout 600 python scripts/k6_numerics.py > $OUT/k6_numerics.jsonl 2> $OUT/k6_numerics.err
+  cut -c1-330 $OUT/k6_numerics.jsonl
+fi
+if [ -n "$SHAPES" ]; then
+  (cd scripts; ITERS=40 VARIANTS="${SHAPE_VARIANTS}" SHAPES="$SHAPES" timeout 600 python k6_variants.py 2>&1 | grep -v amdgpu.ids) > $OUT/k6_shapes.jsonl
+  cat $OUT/k6_shapes.jsonl
+fi
 for b in ${TRACE_SHARDS}; do
   B=$b PROBE=A timeout 300 rocprofv3 --kernel-trace -d $OUT -o seqB$b -- python scripts/thread_gap_probe.py > $OUT/seqB$b.log 2>&1
   { echo "== B=$b raw nr_forward_rasterize + nr_backward_rasterize calls, one thread"; python scripts/step_gaps.py $OUT/seqB${b}_results.db k_face_raster; } >> $OUT/step_sequence_shards.txt 2>&1

@@ -30,7 +30,9 @@ KERNEL_STAGES = [
     ('k_face_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
     ('k_large_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
     ('k_resolve', ['forward_face_index_map', 'fused_forward_rasterize']),
-    ('k_fill_bytes', ['forward_face_index_map', 'fused_forward_rasterize']),  # (the fused backward's fill rides in k_bpm_fast)
+    # (round 4: the fused forward of bench.time_stages keeps its workspace with epochs like the operator: no fill there; the
+    # fused backward's fill rides in k_bpm_fast)
+    ('k_fill_bytes', ['forward_face_index_map']),
     ('k_shade', ['forward_texture_sampling']),
 ] + [(k, ['backward_pixel_map', 'fused_backward_rasterize']) for k in K6] + [
     # (template argument lists are matched as prefixes: the gathers carry a third argument, the per-face light mode)

@@ -41,10 +41,19 @@ wsb_b = lib.nr_backward_workspace_bytes(B, F, S, 1, 1)
 wsb = torch.empty(wsb_b, dtype=torch.uint8, device=dev)
 
 
-def fwd():
+wsf.fill_(255)
+_epoch = [254]
+
+
+def fwd():  # as the operator calls it: kept workspace with falling epochs, weights of covered pixels only
+    e = _epoch[0]
+    _epoch[0] = e - 1 if e > 0 else 254
+    if e == 0:
+        wsf.fill_(255)
     _lib.check(lib.nr_forward_rasterize(faces.data_ptr(), None, textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(),
                                         rgb.data_ptr(), am.data_ptr(), vis.data_ptr(), bg.data_ptr(), 0, B, F, S, ts, 0.1, 100.0,
-                                        1e-3, 0, wsf.data_ptr(), wsf_b, stream), 'f')
+                                        1e-3, _lib.NR_FLAG_ZBUF_EPOCH | (e << 8) | _lib.NR_FLAG_SPARSE_WEIGHT_MAP, wsf.data_ptr(),
+                                        wsf_b, stream), 'f')
 
 
 def bwd():

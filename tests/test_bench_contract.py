@@ -27,7 +27,7 @@ def test_bench_json_line():
     sh = d['shard_rows']  # rank 0's shard of the job at 2 / 4 GPUs, on this GPU (8 GPUs would leave no view: no row)
     assert [r['views'] for r in sh['rows']] == [2, 1] and [p['n_gpus'] for p in sh['predicted_strong_scaling']] == [2, 4]
     assert all(r[k] > 0 for r in sh['rows'] for k in ('ms_autograd', 'ms_autograd_caller_thread', 'ms_function_protocol'))
-    assert d['timing']['effective_warmup_steps'] >= d['warmup']
+    assert d['timing']['effective_warmup_steps'] >= d['warmup'] and sh['host_floor']['ms_function_protocol'] > 0
     assert 'workload' in d['config'] and d['value'] > 0 and d['ms_per_step'] > 0
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
