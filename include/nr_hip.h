@@ -71,11 +71,12 @@ extern "C" {
 /* flags */
 #define NR_FLAG_FIX_TEXTURE_BATCH_Z 1 /* texture sampling (K4 / K7): read the face's z from the pixel's own batch element
                                          instead of batch 0 (the reference reads batch 0: rasterize.py:389) */
-#define NR_FLAG_EXACT_GRADIENT 2      /* K6: every per-pixel term with the reference's arithmetic (IEEE division, the double
-                                         `dist +- eps`), <= 2e-6 against the exactly summed reference terms, ~1.5x the K6 time.
-                                         Default (flag clear): float terms through fused multiply-adds and v_rcp_f32; measured
-                                         <= 4.7e-5 against the same sums over the whole test suite (full-size configs included),
-                                         bound 1e-4. */
+#define NR_FLAG_EXACT_GRADIENT 2      /* K6: every per-pixel term with the reference's arithmetic (its operations one by one, IEEE
+                                         division, the double `dist +- eps`), all sums in double: bit-identical terms, bound 2e-6
+                                         against the exactly summed reference terms.  Default (flag clear): float terms through
+                                         fused multiply-adds and v_rcp_f32, ~1 ulp per term, bound 1e-4 (the north star's
+                                         tolerance).  Same sweep structure either way; what the modes cost and measure:
+                                         profiles/<round>_parity_summary.md, DESIGN.md 3. */
 #define NR_FLAG_K6_GLOBAL 4           /* K6: force the global-memory kernel that otherwise only serves rasters whose band
                                          does not fit in LDS (a testing aid) */
 #define NR_FLAG_K6_SCAN 8             /* K6: let every band workgroup derive its lines from the image's visible-face list

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                                                      int *__restrict__ large_list, int *__restrict__ wave_list,
                                                      int *__restrict__ n_large,
                                                      unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
-                                                     int S, double near_d, double far_d, int epoch)
+                                                     int S, double near_d, double far_d, int epoch,
+                                                     unsigned char *__restrict__ touched)
 {
     __shared__ FaceWaveLds<FACES> lds[4];
     FaceWaveLds<FACES> &L = lds[threadIdx.x >> 6];
@@ -366,7 +367,10 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                 const int pix_here = min(FR_PIX, n_pix - pbase);
                 for (int pp = lane; pp < pix_here; pp += 64) {
                     unsigned long long key, *at;
-                    if (slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key, at, epoch)) atomicMin(at, key);
+                    if (slot_pixel(L, L.pix[pp], S, near_d, far_d, zbuf, key, at, epoch)) {
+                        atomicMin(at, key);
+                        if (touched) touched[(size_t)(at - zbuf) >> 6] = (unsigned char)epoch;  // (see k_resolve)
+                    }
                 }
                 FWD_PH(5);
             }
@@ -383,7 +387,8 @@ constexpr int CQ = 128;  // queue words per wave: < 64 waiting + <= 64 new
 template <class PixelOf>
 __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu, int n_cand, int first, int step,
                                                   PixelOf pixel_of, int *__restrict__ queue, int S, double near_d,
-                                                  double far_d, unsigned long long *__restrict__ zimg, int epoch)
+                                                  double far_d, unsigned long long *__restrict__ zimg, int epoch,
+                                                  unsigned char *__restrict__ touched, size_t img_off)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -393,8 +398,10 @@ __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu
     auto evaluate = [&](int e) {
         const int x = e & 0xffff, y = e >> 16;
         float zp, w0, w1, w2;
-        if (eval_inside(g, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2))
+        if (eval_inside(g, (float)x, (float)y, near_d, far_d, zp, w0, w1, w2)) {
             atomicMin(zimg + (size_t)y * S + x, zword(zp, fnu, epoch));
+            if (touched) touched[(img_off + (size_t)y * S + x) >> 6] = (unsigned char)epoch;
+        }
     };
     for (int base = first; base < n_cand; base += step) {  // (wave-uniform trip count)
         const int k = base + lane;
@@ -423,7 +430,8 @@ __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu
 // queues 1/5 of its faces): one wave per face, lanes stride over the box.
 __device__ __forceinline__ void wave_raster(const float *__restrict__ faces, unsigned long long *__restrict__ zbuf,
                                             const int *__restrict__ wave_list, const int *__restrict__ n_wave, int F, int S,
-                                            double near_d, double far_d, int *__restrict__ queue, int epoch)
+                                            double near_d, double far_d, int *__restrict__ queue, int epoch,
+                                            unsigned char *__restrict__ touched)
 {
     const int n = *n_wave + 1;  // the counter starts at -1
     const int waves = gridDim.x * (blockDim.x >> 6);
@@ -443,7 +451,7 @@ __device__ __forceinline__ void wave_raster(const float *__restrict__ faces, uns
                 y = cd.y_lo + yy;
                 return true;
             },
-            queue, S, near_d, far_d, zbuf + (size_t)b * S * S, epoch);
+            queue, S, near_d, far_d, zbuf + (size_t)b * S * S, epoch, touched, (size_t)b * S * S);
     }
 }
 
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
                                                       unsigned long long *__restrict__ zbuf,
                                                       const int *__restrict__ large_list, const int *__restrict__ wave_list,
                                                       const int *__restrict__ n_large, int F, int S, double near_d,
-                                                      double far_d, int epoch)
+                                                      double far_d, int epoch, unsigned char *__restrict__ touched)
 {
     __shared__ int s_queue[4][CQ];
     int *queue = s_queue[threadIdx.x >> 6];
@@ -469,9 +477,9 @@ __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ 
         raster_candidates(
             g, (unsigned)(i - b * F), cd.n, (int)(threadIdx.x >> 6) * 64, 256,
             [&](int k, int &x, int &y) { return cand_pixel(cd, k, S, x, y); }, queue, S, near_d, far_d,
-            zbuf + (size_t)b * S * S, epoch);
+            zbuf + (size_t)b * S * S, epoch, touched, (size_t)b * S * S);
     }
-    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d, queue, epoch);
+    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d, queue, epoch, touched);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -576,20 +584,26 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
                                                  float *__restrict__ rgb_map, const float *__restrict__ background,
                                                  int bg_per_batch, float *__restrict__ alpha_map, int ts, double eps,
                                                  int fix_batch_z, int epoch, int *__restrict__ queue_counters,
-                                                 FaceLight lit, int sparse_weights)
+                                                 FaceLight lit, int sparse_weights,
+                                                 const unsigned char *__restrict__ touched)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // epoch mode: nobody fills the workspace for the next call, so the two queue counters go back to -1 here (the raster
     // kernels that read them are done: this launch is behind them on the stream)
     if (i == 0 && epoch >= 0) { queue_counters[0] = -1; queue_counters[1] = -1; }
     if (i >= n_pixels) return;
-    const unsigned long long pk = zbuf[i];
+    // Epoch mode keeps a byte per 64 consecutive pixels (= the pixels of one wave here) that every z-buffer update of this call
+    // sets to the call's epoch number: where it holds anything else nobody drew -- 7 of 8 segments of a teapot view -- and the
+    // 512 bytes of z-buffer behind it are not read (round 4: 33.5 -> ~6 MB of z-buffer reads at the headline size).  Stale
+    // bytes of earlier calls carry larger epoch numbers, the initial fill 0xff: no clearing.
+    const bool drawn = !touched || touched[i >> 6] == (unsigned char)epoch;
+    const unsigned long long pk = drawn ? zbuf[i] : ZEMPTY;
     int fn = -1;
     float zp = (float)far_d, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;  // rasterize.py:296, :478-480
     float inv[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     int b = 0;
     if (rgb_map || alpha_map) b = (int)(i / ((size_t)S * S));
-    const bool hit = epoch < 0 ? pk != ZEMPTY : (int)(pk >> 56) == epoch;
+    const bool hit = drawn && (epoch < 0 ? pk != ZEMPTY : (int)(pk >> 56) == epoch);
     if (hit) {
         fn = epoch < 0 ? (int)(unsigned)(pk & 0xffffffffu) : (int)(unsigned)(pk & 0xffffffu);
         const size_t SS = (size_t)S * S;
@@ -641,7 +655,7 @@ NR_API const char *nr_error_string(int code)
 
 namespace {
 struct FwdLayout {
-    size_t zbuf_off, list_off, count_off, total;
+    size_t zbuf_off, list_off, count_off, touch_off, total;
 };
 FwdLayout fwd_layout(int B, int F, int S)
 {
@@ -650,7 +664,8 @@ FwdLayout fwd_layout(int B, int F, int S)
     L.zbuf_off = 0;
     L.count_off = L.zbuf_off + P * sizeof(unsigned long long);  // the counter sits right behind the z-buffer
     L.list_off = align_up(L.count_off + sizeof(long long), 256);
-    L.total = L.list_off + 2 * n * sizeof(int);  // the queue of large faces, then the queue of medium ones
+    L.touch_off = align_up(L.list_off + 2 * n * sizeof(int), 256);  // the queue of large faces, then the queue of medium ones
+    L.total = L.touch_off + (P + 63) / 64;  // epoch mode: one byte per 64 pixels, "drawn in this call" (k_resolve)
     return L;
 }
 }  // namespace
@@ -689,22 +704,26 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
         if (int he = fill_bytes(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st)) return he;  // (nr_device.h: not a memset node)
     }
     int *wave_list = large_list + n;
+    unsigned char *touched = epoch >= 0 ? ws + L.touch_off : nullptr;
     {
         const bool pow2 = (S & (S - 1)) == 0, small = n < (size_t)NR_FWD_SMALL_WAVES * 32;
 #define NR_FACE_RASTER(P, FC, G)                                                                                           \
     hipLaunchKernelGGL((k_face_raster<P, FC, G>), dim3((unsigned)((n + 4 * FC - 1) / (4 * FC))), dim3(256), 0, st, faces, zbuf, \
-                       large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far, epoch)
+                       large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far, epoch, touched)
         if (small) { if (pow2) NR_FACE_RASTER(true, 16, 4); else NR_FACE_RASTER(false, 16, 4); }
         else { if (pow2) NR_FACE_RASTER(true, 64, 16); else NR_FACE_RASTER(false, 64, 16); }
 #undef NR_FACE_RASTER
     }
-    // a resident grid loops over the two queues; with empty queues (a fine mesh) its workgroups read two counters and leave
-    hipLaunchKernelGGL(k_large_raster, dim3(2048), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
-                       far, epoch);
+    // a resident grid loops over the two queues; with empty queues (a fine mesh) its workgroups read two counters and leave --
+    // which costs what dispatching them costs (2048 workgroups: 4.7 us), so small launches get a smaller grid (a face per 256
+    // of the call's, 256 .. 2048 workgroups: the queues hold a fraction of the faces, and each large face is a workgroup's work)
+    const unsigned queue_wgs = (unsigned)(n / 256 < 256 ? 256 : (n / 256 > 2048 ? 2048 : n / 256));
+    hipLaunchKernelGGL(k_large_raster, dim3(queue_wgs), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
+                       far, epoch, touched);
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, zbuf, face_index_map,
                        weight_map, depth_map, face_inv_map, visible_faces, F, S, near, far, P,
                        faces_z_ref ? faces_z_ref : faces, textures, rgb_map, background, bg_per_batch, alpha_map, ts, eps,
-                       fix_batch_z, epoch, n_large, lit, (flags & NR_FLAG_SPARSE_WEIGHT_MAP) ? 1 : 0);
+                       fix_batch_z, epoch, n_large, lit, (flags & NR_FLAG_SPARSE_WEIGHT_MAP) ? 1 : 0, touched);
     return launch_status();
 }
 }  // namespace

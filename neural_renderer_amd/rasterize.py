@@ -36,9 +36,10 @@ if 'NEURAL_RENDERER_UNSAFE' in os.environ and int(os.environ['NEURAL_RENDERER_UN
 # attribute of a Rasterize instance) uses the pixel's own batch element.
 FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 
-# K6 (backward_pixel_map) numerics.  Default: float terms through fused multiply-adds and the hardware reciprocal, measured <= 4.7e-5 from the
-# reference's terms summed exactly (tests bound it by the north star's 1e-4).  NR_EXACT_GRADIENT=1 (read once, here) or the
-# `exact_gradient` attribute of a Rasterize instance: every term with the reference's own arithmetic, <= 2e-6, ~1.5x the K6 time.
+# K6 (backward_pixel_map) numerics.  Default: float terms through fused multiply-adds and the hardware reciprocal, ~1 ulp per
+# term; the tests bound the deviation from the reference's terms summed exactly by the north star's 1e-4.  NR_EXACT_GRADIENT=1
+# (read once, here) or the `exact_gradient` attribute of a Rasterize instance: every term with the reference's own arithmetic,
+# sums in double (bound 2e-6).  Measured levels and costs of both: profiles/*_parity_summary.md.
 EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
 
 
