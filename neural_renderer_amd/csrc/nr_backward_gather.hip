@@ -756,13 +756,15 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
 }
 
 // k_backward_big's grid: one workgroup per range of 256 faces (or list slots), times as many workgroups per range (z) as it
-// takes to put ~4096 workgroups on the chip -- they share out the range's big faces
+// takes to put ~4096 workgroups on the chip -- they share out the range's big faces.  (Small launches: a workgroup per 64
+// faces of the call, at least 1024 -- with nothing to do, as on a fine mesh, the kernel costs what dispatching it costs.)
 inline dim3 big_grid(bool listed, int B, int F)
 {
     const size_t n = (size_t)B * F;
     const dim3 g = listed ? dim3((unsigned)((F + 255) / 256), (unsigned)B) : dim3((unsigned)((n + 255) / 256));
     const size_t ranges = (size_t)g.x * g.y;
-    const size_t z = 4096 / ranges;
+    const size_t target = n / 64 < 1024 ? 1024 : (n / 64 > 4096 ? 4096 : n / 64);
+    const size_t z = target / ranges;
     return dim3(g.x, g.y, (unsigned)(z < 1 ? 1 : (z > 64 ? 64 : z)));
 }
 
