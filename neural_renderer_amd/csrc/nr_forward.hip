@@ -37,9 +37,7 @@ namespace {
 // negative ones), so any `near` -- the reference accepts any, :331 -- orders correctly, faces behind the camera
 // (negative zp with near < 0) included.  The result does not depend on the order of the atomics:
 // face_index_map is bit-reproducible.
-#ifndef NR_FWD_SMALL_WAVES  // launches of fewer than this many x 32 faces take 16 faces per wave (0: never)
-#define NR_FWD_SMALL_WAVES 16384
-#endif
+constexpr size_t SMALL_LAUNCH_FACES = (size_t)16384 * 32;  // launches of fewer faces take 16 faces per raster wave (k_face_raster)
 constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized by k_face_raster (measured with the round-2 form of
                                   // the kernel: 128 / 64 make config 4 15 % / 28 % slower, the headline +0 / +11 %)
 constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (wave_raster); beyond, and strips: one workgroup (k_large_raster)
@@ -147,12 +145,8 @@ __device__ __forceinline__ void load_face_geo(const float *__restrict__ f, int S
 //   3. lane = inside pixel: weights, depth, depth test, 64-bit atomicMin.
 // Rows and pixels are handed over through small LDS lists, written by their producers at wave-prefix positions, a window of
 // the list at a time (any box shape fits).  The waves of a workgroup are independent: no barrier, only wave-scope fences.
-#ifndef FR_ROWS
-#define FR_ROWS 128  // row items per window
-#endif
-#ifndef FR_PIX
-#define FR_PIX 256  // pixel items per window (7.4 KB of LDS per wave: five workgroups per CU)
-#endif
+constexpr int FR_ROWS = 128;  // row items per window
+constexpr int FR_PIX = 256;   // pixel items per window (7.4 KB of LDS per wave: five workgroups per CU)
 // FACES: faces per wave (its first FACES lanes take one each) and GROUP: consecutive faces per run of the face -> lane mapping
 // are template parameters: 64 / 16 for large launches, 16 / 4 below 16 384 x 32 faces (round 4: the kernel is latency-bound,
 // a wave lives as long as its rows and pixels take, and smaller waves' worth of faces means more, shorter waves -- fused
@@ -211,23 +205,6 @@ __device__ __forceinline__ bool slot_pixel(const FaceWaveLds<FACES> &L, int e, i
     return ok;
 }
 
-#ifdef NR_FWD_PHASES  // development build: cycles per phase of k_face_raster summed over waves (scripts/fwd_phases.py)
-__device__ unsigned long long g_fwd_phase[8];
-#define FWD_PH_BEGIN() unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_t = clock64(), ph_w = wall_clock64()
-#define FWD_PH(k) do { const unsigned long long ph_n = clock64(); ph_acc[k] += ph_n - ph_t; ph_t = ph_n; } while (0)
-#define FWD_PH_END()                                                                                  \
-    do {                                                                                              \
-        if (lane == 0) {                                                                              \
-            for (int k = 0; k < 6; k++) atomicAdd(&g_fwd_phase[k], ph_acc[k]);                        \
-            atomicAdd(&g_fwd_phase[6], wall_clock64() - ph_w);                                        \
-            atomicAdd(&g_fwd_phase[7], 1ull);                                                         \
-        }                                                                                             \
-    } while (0)
-#else
-#define FWD_PH_BEGIN()
-#define FWD_PH(k)
-#define FWD_PH_END()
-#endif
 
 template <bool POW2, int FACES, int GROUP>
 __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces,
@@ -241,7 +218,6 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     __shared__ FaceWaveLds<FACES> lds[4];
     FaceWaveLds<FACES> &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    FWD_PH_BEGIN();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_faces_total && visible_faces) visible_faces[t] = 0;  // k_resolve raises the flags of the faces that win a pixel
     // A wave takes 64 / GROUP groups of GROUP consecutive faces, the groups W apart (W = number of waves): faces that are
@@ -296,9 +272,7 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     // 1. kept faces -> slots (lane order), their constants -> LDS
     const bool keep = cd.n > 0 && !queued;  // not: back faces, off-screen faces, coincident vertices; queued faces
     const unsigned long long mk = __ballot(keep);
-    FWD_PH(0);
     if (mk == 0) {
-        FWD_PH_END();
         return;
     }
     const int slot = __popcll(mk & ((1ull << lane) - 1ull));
@@ -318,14 +292,12 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     const int n_rows = __builtin_amdgcn_readlane(row_end, 63);
     constexpr bool pow2 = POW2;  // (S & (S - 1)) == 0: pixel centres with one multiply, no division in the search loop
     const float inv_s = 1.0f / (float)S;
-    FWD_PH(1);
     for (int rbase = 0; rbase < n_rows; rbase += FR_ROWS) {
         wave_lds_sync();  // (the previous window's readers are done)
         for (int r = max(rbase - row0, 0), r_hi = min(rbase + FR_ROWS - row0, bh); r < r_hi; ++r)
             L.rows[row0 + r - rbase] = (slot << 8) | r;
         wave_lds_sync();
         const int rows_here = min(FR_ROWS, n_rows - rbase);
-        FWD_PH(2);
         for (int rp = 0; rp < rows_here; rp += 64) {
             // 2. the inside interval [xa, xa + cnt) of this lane's row
             int item = 0, xa = 0, cnt = 0;
@@ -354,7 +326,6 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                 }
                 xa -= x_lo;
             }
-            FWD_PH(3);
             const int pix_end = wave_inclusive_sum(cnt), pix0 = pix_end - cnt;
             const int n_pix = __builtin_amdgcn_readlane(pix_end, 63);
             for (int pbase = 0; pbase < n_pix; pbase += FR_PIX) {
@@ -362,7 +333,6 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                 for (int k = max(pbase - pix0, 0), k_hi = min(pbase + FR_PIX - pix0, cnt); k < k_hi; ++k)
                     L.pix[pix0 + k - pbase] = (item << 8) | (xa + k);  // slot, row, column
                 wave_lds_sync();
-                FWD_PH(4);
                 // 3. one inside pixel per lane
                 const int pix_here = min(FR_PIX, n_pix - pbase);
                 for (int pp = lane; pp < pix_here; pp += 64) {
@@ -372,11 +342,9 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
                         if (touched) touched[(size_t)(at - zbuf) >> 6] = (unsigned char)epoch;  // (see k_resolve)
                     }
                 }
-                FWD_PH(5);
             }
         }
     }
-    FWD_PH_END();
 }
 
 // Candidate pixels first + step * j (j = 0, 1, ...) of one face for the calling wave, lane by lane: the half-plane tests run on
@@ -706,7 +674,7 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     int *wave_list = large_list + n;
     unsigned char *touched = epoch >= 0 ? ws + L.touch_off : nullptr;
     {
-        const bool pow2 = (S & (S - 1)) == 0, small = n < (size_t)NR_FWD_SMALL_WAVES * 32;
+        const bool pow2 = (S & (S - 1)) == 0, small = n < SMALL_LAUNCH_FACES;
 #define NR_FACE_RASTER(P, FC, G)                                                                                           \
     hipLaunchKernelGGL((k_face_raster<P, FC, G>), dim3((unsigned)((n + 4 * FC - 1) / (4 * FC))), dim3(256), 0, st, faces, zbuf, \
                        large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far, epoch, touched)
@@ -806,16 +774,3 @@ NR_API int nr_forward_texture_sampling(const float *faces, const float *faces_z_
                        (flags & NR_FLAG_FIX_TEXTURE_BATCH_Z) ? 1 : 0, n, FaceLight());
     return launch_status();
 }
-
-#ifdef NR_FWD_PHASES
-// development build only (not declared in include/nr_hip.h)
-NR_API int nr_debug_fwd_phases(unsigned long long *out8, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fwd_phase), 8 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase), z, sizeof(z));
-    }
-    return e == hipSuccess ? 0 : -1;
-}
-#endif

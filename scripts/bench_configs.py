@@ -94,6 +94,16 @@ def main():
             for name, modes, eps in (('H silhouette', (False, True, False), 1e-4), ('H rgb', (True, False, False), 1e-3),
                                      ('H depth', (False, False, True), 1e-4), ('H rgb+alpha+depth', (True, True, True), 1e-3)):
                 run('%s S%d' % (name, S), faces, textures, S, modes, eps)
+    if not only or 'SH' in only:
+        # the per-GPU shards of the 64-view headline job at 2 / 4 / 8 GPUs (views [0, 64/R) of the 64 azimuths, global view 0 as
+        # the texture-depth reference), on this one GPU: bench.py's shard_rows, one row each
+        for r in bench.shard_rows(dev, 64, 256, 2, 1e-3, 100):
+            print(json.dumps({'config': 'SH shard of H for %d GPUs: %d views' % (r['gpus_this_shard_belongs_to'], r['views']), 'B': r['views'],
+                              'S': 256, 'modes': 'rad', 'ms_fwd_bwd': round(r['ms_autograd'], 4),
+                              'ms_fwd_bwd_min_max_of_5': [round(x, 4) for x in r['ms_autograd_min_max']],
+                              'ms_fwd_bwd_single_threaded_autograd': round(r['ms_autograd_caller_thread'], 4),
+                              'ms_fwd_bwd_function_protocol': round(r['ms_function_protocol'], 4),
+                              'mpixel_s_function_protocol': round(r['mpixel_per_s_function_protocol'], 1)}), flush=True)
     if not only or 'C2' in only:
         # config 2: 16 azimuth views, RGB + depth + silhouette
         faces, textures = bench.build_scene(dev, 16, 0, 16, 256, 2)
