@@ -780,6 +780,18 @@ def main():
                 ms5 = time_step(make_step(faces, textures, S, (g_rgb, g_alpha, g_depth), exact=True), dev, args.steps, 2)
                 extra_rows.append({'row': 'headline step with NR_FLAG_EXACT_GRADIENT (K6 with the reference\'s own arithmetic per term)',
                                    'ms_per_step': ms5, 'mpixel_per_s_raster': B * S * S / (ms5 * 1e-3) / 1e6})
+            # the same step through the operator's chainer.Function protocol (forward_gpu / backward_gpu: no autograd graph, no
+            # hand-over of the backward to torch's device thread): the device-bound figure whatever the host's thread wake-ups cost
+            fd, td = faces.detach(), textures.detach()
+
+            def protocol_step():
+                fn = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+                fn.faces_z_ref = z_ref
+                fn.forward_gpu((fd, td))
+                fn.backward_gpu((fd, td), grads)
+            ms6 = time_step(protocol_step, dev, args.steps, 5)
+            extra_rows.append({'row': 'headline step through Rasterize.forward_gpu / backward_gpu (the Function protocol, no autograd graph)',
+                               'ms_per_step': ms6, 'mpixel_per_s_raster': B * S * S / (ms6 * 1e-3) / 1e6})
             try:  # the same step replayed from a captured HIP graph: what the ~15 launches and allocations cost the host
                 from neural_renderer_amd.graph import capture
                 ms4 = time_step(capture(local_step, dev), dev, args.steps, 2)

@@ -151,7 +151,8 @@ constexpr int FR_PIX = 256;   // pixel items per window (7.4 KB of LDS per wave:
 // are template parameters: 64 / 16 for large launches, 16 / 4 below 16 384 x 32 faces (round 4: the kernel is latency-bound,
 // a wave lives as long as its rows and pixels take, and smaller waves' worth of faces means more, shorter waves -- fused
 // forward in us, teapot views at 256^2: 8 views 43 -> 32, 16 views 42 -> 34, 32 views 62 -> 47, 48 views 67 -> 58, 64 views
-// 70 -> 70; 64 views at 512^2 306 -> 290; rounds 2-3 had 32 / 8 below 2048 x 64 faces).
+// 70 -> 70; 64 views at 512^2 306 -> 290; rounds 2-3 had 32 / 8 below 2048 x 64 faces).  Above the threshold 16 per wave loses:
+// config 4 (655 360 faces) 242 -> 323, 256 views of 128^2 101 -> 132, 1024 views of 32^2 142 -> 265.
 // Measured and dropped: two pixels per lane and evaluation step (neutral, more code); the row interval estimated from the edge
 // equations and pinned down with ~4 exact tests by a one-test-per-step state machine (89 vs 81 us fused forward).
 static_assert(SMALL_AREA <= 256, "rows and columns of a kept box are packed into 8 bits each");

@@ -18,8 +18,14 @@ variants = [''] + os.environ.get('VARIANTS', '').split()
 for shape in os.environ.get('SHAPES', '1x256 4x256 8x256 16x256').split():
     B, S = (int(x) for x in shape.split('x'))
     use_library('')
-    faces, textures = bench.build_scene(dev, B, 0, 64 if B <= 64 else B, S, 2)
-    F, ts = faces.shape[1], 2
+    if os.environ.get('SCENE') == 'C4':  # config 4: B distinct random meshes x 10 240 faces, texture_size 4
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from test_full_size_gpu import config4_meshes
+        faces = torch.from_numpy(config4_meshes(B)).to(dev)
+        textures = torch.rand((B, faces.shape[1], 4, 4, 4, 3), device=dev)
+    else:
+        faces, textures = bench.build_scene(dev, B, 0, 64 if B <= 64 else B, S, 2)
+    F, ts = faces.shape[1], int(textures.shape[2])
     fi = torch.empty((B, S, S), dtype=torch.int32, device=dev)
     wm = torch.empty((B, S, S, 3), device=dev); dm = torch.empty((B, S, S), device=dev)
     rgb = torch.empty((B, S, S, 3), device=dev); am = torch.empty((B, S, S), device=dev)

@@ -43,7 +43,8 @@ def test_bench_json_line():
     w = r['whole_step']
     assert w['algorithmic_bytes'] == 92 * 4 * 256 * 256 + (108 + 24 * 8) * 4 * d['config']['num_faces']
     assert r['traffic'] is None and 'traffic_from_profiles' in r
-    assert len(d['extra_rows']) == 4 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
+    assert len(d['extra_rows']) == 5 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
+    assert any('forward_gpu' in x['row'] for x in d['extra_rows'])
     assert any('NR_FLAG_EXACT_GRADIENT' in x['row'] for x in d['extra_rows'])
     assert d['renderer_end_to_end']['frontend'] == 'fused'
     rows = d['renderer_end_to_end']['reference_protocol']['rows']  # misc/measure_time.py protocol, Renderer defaults (AA on)
