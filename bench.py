@@ -577,6 +577,7 @@ def main():
     ap.add_argument('--gather', action='store_true', help='also all_gather the rendered images each step (RCCL)')
     ap.add_argument('--graph', action='store_true', help='replay the step from a captured HIP graph')
     ap.add_argument('--exact', action='store_true', help='K6 with the reference\'s own arithmetic (NR_FLAG_EXACT_GRADIENT)')
+    ap.add_argument('--no-pin', action='store_true', help='do not pin the process to one L3 group of cores')
     ap.add_argument('--no-shard-rows', action='store_true', help='skip the 32 / 16 / 8-view rows of a 1-GPU run')
     ap.add_argument('--light', action='store_true', help='headline step + stage timings only (no extra rows, no Renderer '
                                                          'end-to-end, oracle check on 2 views)')
@@ -590,6 +591,22 @@ def main():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
     from neural_renderer_amd import distributed as nrd
     _, _, dev = nrd.init_from_env()  # one process per GPU; backend "nccl" = RCCL
+    # one process per GPU, pinned to the cores of one L3 group near that GPU (rank r: the r-th group): where torch's autograd
+    # device thread wakes up decides what its hand-over costs a host-bound step (distributed.pin_to_l3_group; --no-pin: leave it)
+    all_cpus = os.sched_getaffinity(0)
+    pinned = None if args.no_pin else nrd.pin_to_l3_group(int(os.environ.get('LOCAL_RANK', '0')), dev.index)
+
+    class on_all_cores(object):
+        """The CPU oracle (checker / CPU baseline) runs on every core the process was given: its OpenMP threads are created
+        inside and inherit the calling thread's affinity of that moment."""
+
+        def __enter__(self):
+            self.prev = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, all_cpus)
+
+        def __exit__(self, *exc):
+            os.sched_setaffinity(0, self.prev)
+            return False
     dist = None
     if world > 1 or nrd._force():  # NR_DIST_FORCE=1: one rank, but through RCCL all the same (tests/test_rccl_gpu.py)
         import torch.distributed as dist
@@ -712,8 +729,9 @@ def main():
     if rank == 0:
         local_step()  # gradients of the checked batch; rank 0 alone runs this, so it must not contain a collective
         torch.cuda.synchronize(dev)
-        check = grad_check(last['fi'], faces, textures, S, eps, g_rgb, g_alpha, g_depth,
-                           min(B, 2 if args.light else args.check_views))
+        with on_all_cores():
+            check = grad_check(last['fi'], faces, textures, S, eps, g_rgb, g_alpha, g_depth,
+                               min(B, 2 if args.light else args.check_views))
 
         k6_flags = 2 if args.exact else 0
         stages = time_stages(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth, args.stage_iters, k6_flags)
@@ -822,8 +840,9 @@ def main():
         cpu = None
         if args.cpu_sample_views > 0:
             # (N > 1: rank 0's shard, one thread and all cores; the naive-NumPy row only in the 1-GPU run)
-            cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
-                               min(args.cpu_sample_views, B), light=args.light or world > 1)
+            with on_all_cores():
+                cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
+                                   min(args.cpu_sample_views, B), light=args.light or world > 1)
         line = {
             'metric': 'rasterize fwd+bwd Mpixels/sec @256x256 batch=64', 'value': value, 'unit': 'Mpixel/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -851,6 +870,7 @@ def main():
                        'prewarm': {'ms': args.prewarm_ms, 'steps': prewarm_steps,
                                    'why': 'steady clocks before the W warm-up and K timed steps (untimed)'},
                        'effective_warmup_steps': prewarm_steps + args.warmup,
+                       'cpu_affinity': ('pinned to one L3 group: %d logical CPUs from %d' % (len(pinned), min(pinned))) if pinned else 'not pinned',
                        'backend': (dist.get_backend() if dist is not None else None)},
         }
         print(json.dumps(line))

@@ -88,3 +88,24 @@ def test_two_process_gloo(total):
         assert p.exitcode == 0
     for rank, g1, g2, gr in results:
         assert g1 and g2 and gr, (rank, g1, g2, gr)
+
+
+def test_pin_to_l3_group_picks_one_cache_group_per_rank():
+    """distributed.pin_to_l3_group: one process per GPU pinned to the logical CPUs that share one L3 (rank r: the r-th group);
+    every thread of the process follows; None -- and no change -- where the topology cannot be read."""
+    import os
+    from neural_renderer_amd import distributed as nrd
+    before = os.sched_getaffinity(0)
+    try:
+        groups = nrd.l3_groups()
+        got = nrd.pin_to_l3_group(local_rank=1)
+        if not groups:
+            assert got is None and os.sched_getaffinity(0) == before
+            return
+        assert got == groups[1 % len(groups)] and got <= before
+        assert os.sched_getaffinity(0) == got
+        assert all(a.isdisjoint(b) for i, a in enumerate(groups) for b in groups[i + 1:])
+        assert set().union(*groups) == before
+    finally:
+        for tid in os.listdir('/proc/self/task'):
+            os.sched_setaffinity(int(tid), before)
