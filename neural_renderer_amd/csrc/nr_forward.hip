@@ -3,7 +3,8 @@
 //   k_face_raster   F1+F2  per face: back-face cull, inverse matrix, screen box (ref K1, :240-277) and
 //                          rasterization of the face's pixels into a packed 64-bit z-buffer (ref K2, :279-359)
 //   k_large_raster  F2'    faces with a large screen box: one wave or one workgroup per face
-//   k_resolve       F2''   per pixel: decode the winner, write face_index / weight / depth / face_inv maps
+//   k_resolve       F2''   per pixel: decode the winner, write face_index / weight / depth / face_inv maps (+ fused F3);
+//   k_resolve_quads        the same with 16-byte fills of undrawn stretches (kept workspace, even raster side)
 //   k_shade         F3  per pixel: trilinear texture sampling + background + alpha        (ref K4+K5, :361-465)
 #include "nr_device.h"
 
@@ -542,36 +543,43 @@ __global__ __launch_bounds__(256) void k_shade(const float *__restrict__ faces, 
                 background, bg_per_batch, alpha_map, F, ts, eps, fix_batch_z, lit);
 }
 
-__global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces,
-                                                 const unsigned long long *__restrict__ zbuf,
-                                                 int32_t *__restrict__ face_index_map, float *__restrict__ weight_map,
-                                                 float *__restrict__ depth_map, float *__restrict__ face_inv_map,
-                                                 unsigned char *__restrict__ visible_faces, int F, int S, double near_d,
-                                                 double far_d, size_t n_pixels,
-                                                 // fused shading (all NULL / 0 when not requested)
-                                                 const float *__restrict__ zbase, const float *__restrict__ textures,
-                                                 float *__restrict__ rgb_map, const float *__restrict__ background,
-                                                 int bg_per_batch, float *__restrict__ alpha_map, int ts, double eps,
-                                                 int fix_batch_z, int epoch, int *__restrict__ queue_counters,
-                                                 FaceLight lit, int sparse_weights,
-                                                 const unsigned char *__restrict__ touched)
+// Everything the resolve pass needs (passed by value: one kernel argument block for its two launch shapes).
+struct ResolveArgs {
+    const float *faces;
+    const unsigned long long *zbuf;
+    int32_t *face_index_map;
+    float *weight_map, *depth_map, *face_inv_map;
+    unsigned char *visible_faces;
+    int F, S;
+    double near_d, far_d;
+    size_t n_pixels;
+    // fused shading (all NULL / 0 when not requested)
+    const float *zbase, *textures;
+    float *rgb_map;
+    const float *background;
+    int bg_per_batch;
+    float *alpha_map;
+    int ts;
+    double eps;
+    int fix_batch_z, epoch;
+    int *queue_counters;
+    FaceLight lit;
+    int sparse_weights;
+    const unsigned char *touched;
+};
+
+// One pixel of the resolve pass: decode the winner of z-buffer word i (`drawn` false: nobody drew near it, the word is not
+// read), re-evaluate it exactly as the candidate tests did, write the maps and shade.
+__device__ __forceinline__ void resolve_pixel(const ResolveArgs &a, size_t i, bool drawn)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // epoch mode: nobody fills the workspace for the next call, so the two queue counters go back to -1 here (the raster
-    // kernels that read them are done: this launch is behind them on the stream)
-    if (i == 0 && epoch >= 0) { queue_counters[0] = -1; queue_counters[1] = -1; }
-    if (i >= n_pixels) return;
-    // Epoch mode keeps a byte per 64 consecutive pixels (= the pixels of one wave here) that every z-buffer update of this call
-    // sets to the call's epoch number: where it holds anything else nobody drew -- 7 of 8 segments of a teapot view -- and the
-    // 512 bytes of z-buffer behind it are not read (round 4: 33.5 -> ~6 MB of z-buffer reads at the headline size).  Stale
-    // bytes of earlier calls carry larger epoch numbers, the initial fill 0xff: no clearing.
-    const bool drawn = !touched || touched[i >> 6] == (unsigned char)epoch;
-    const unsigned long long pk = drawn ? zbuf[i] : ZEMPTY;
+    const float *__restrict__ faces = a.faces;
+    const int S = a.S, F = a.F, epoch = a.epoch;
+    const unsigned long long pk = drawn ? a.zbuf[i] : ZEMPTY;
     int fn = -1;
-    float zp = (float)far_d, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;  // rasterize.py:296, :478-480
+    float zp = (float)a.far_d, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;  // rasterize.py:296, :478-480
     float inv[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     int b = 0;
-    if (rgb_map || alpha_map) b = (int)(i / ((size_t)S * S));
+    if (a.rgb_map || a.alpha_map) b = (int)(i / ((size_t)S * S));
     const bool hit = drawn && (epoch < 0 ? pk != ZEMPTY : (int)(pk >> 56) == epoch);
     if (hit) {
         fn = epoch < 0 ? (int)(unsigned)(pk & 0xffffffffu) : (int)(unsigned)(pk & 0xffffffu);
@@ -581,27 +589,89 @@ __global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ faces
         const int py = pn / S, px = pn - py * S;
         FaceGeo g;
         load_face_geo(faces + ((size_t)b * F + fn) * 9, S, g, inv);
-        eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, near_d, far_d, zp, w0, w1, w2);
-        if (visible_faces) visible_faces[(size_t)b * F + fn] = 1;  // same value from every pixel of the face: no atomic
+        eval_pixel(g, pixel_center_f(px, S), pixel_center_f(py, S), (float)px, (float)py, a.near_d, a.far_d, zp, w0, w1, w2);
+        if (a.visible_faces) a.visible_faces[(size_t)b * F + fn] = 1;  // same value from every pixel of the face: no atomic
     }
-    face_index_map[i] = fn;
-    if (depth_map) depth_map[i] = zp;
+    a.face_index_map[i] = fn;
+    if (a.depth_map) a.depth_map[i] = zp;
     // (NR_FLAG_SPARSE_WEIGHT_MAP: the zeros of the pixels no face covers -- 7 of 8 on a teapot view, 44 of the 50 MB of this
     // map at the headline size -- are not stored; the backward reads weights of covered pixels only)
-    if (weight_map && (hit || !sparse_weights)) {
-        float *w = weight_map + 3 * i;
+    if (a.weight_map && (hit || !a.sparse_weights)) {
+        float *w = a.weight_map + 3 * i;
         w[0] = w0;
         w[1] = w1;
         w[2] = w2;
     }
-    if (face_inv_map) {
-        float *o = face_inv_map + 9 * i;
+    if (a.face_inv_map) {
+        float *o = a.face_inv_map + 9 * i;
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = inv[k];
     }
-    if (rgb_map || alpha_map)
-        shade_pixel(i, b, fn, w0, w1, w2, zp, faces, zbase, textures, rgb_map, nullptr, nullptr, background, bg_per_batch,
-                    alpha_map, F, ts, eps, fix_batch_z, lit);
+    if (a.rgb_map || a.alpha_map)
+        shade_pixel(i, b, fn, w0, w1, w2, zp, faces, a.zbase, a.textures, a.rgb_map, nullptr, nullptr, a.background,
+                    a.bg_per_batch, a.alpha_map, F, a.ts, a.eps, a.fix_batch_z, a.lit);
+}
+
+// epoch mode: nobody fills the workspace for the next call, so the two queue counters go back to -1 in the resolve pass (the
+// raster kernels that read them are done: this launch is behind them on the stream)
+__device__ __forceinline__ void reset_queue_counters(const ResolveArgs &a)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.epoch >= 0) { a.queue_counters[0] = -1; a.queue_counters[1] = -1; }
+}
+
+__global__ __launch_bounds__(256) void k_resolve(ResolveArgs a)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    reset_queue_counters(a);
+    if (i >= a.n_pixels) return;
+    // Epoch mode keeps a byte per 64 consecutive pixels (= the pixels of one wave here) that every z-buffer update of this call
+    // sets to the call's epoch number: where it holds anything else nobody drew -- 7 of 8 segments of a teapot view -- and the
+    // 512 bytes of z-buffer behind it are not read (round 4: 33.5 -> ~6 MB of z-buffer reads at the headline size).  Stale
+    // bytes of earlier calls carry larger epoch numbers, the initial fill 0xff: no clearing.
+    resolve_pixel(a, i, !a.touched || a.touched[i >> 6] == (unsigned char)a.epoch);
+}
+
+// The same pass for epoch mode on rasters with an even side.  Most of what the pass writes is the constant of undrawn pixels
+// -- 88 % of the 108 MB at the headline size -- and one pixel per lane stores those as dwords (the RGB ones 12 bytes apart).
+// Here the first wave of a workgroup fills the undrawn ones of the workgroup's four segments FOUR consecutive pixels per lane,
+// with 16-byte stores (a quad never straddles segments or images: 4 | 64, 4 | S * S); the drawn segments are resolved one
+// pixel per lane as before, and the other waves of an undrawn stretch leave at once.  (Fused forward of the headline batch
+// 72.3 -> 66.2 us; workgroups of 512 / 1024 pixels with 2 / 4 passes per lane: 72.9 / 82.6, profiles/r04_fwd_variants.jsonl.)
+__global__ __launch_bounds__(256) void k_resolve_quads(ResolveArgs a)
+{
+    reset_queue_counters(a);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, i0 = (size_t)blockIdx.x * 256 + 4 * threadIdx.x;
+    const unsigned char ep = (unsigned char)a.epoch;
+    unsigned char tq = ep, ti = (unsigned char)(ep + 1);
+    if (threadIdx.x < 64 && i0 < a.n_pixels) tq = a.touched[i0 >> 6];
+    if (i < a.n_pixels) ti = a.touched[i >> 6];
+    if (tq != ep) {
+        reinterpret_cast<int4 *>(a.face_index_map)[i0 >> 2] = make_int4(-1, -1, -1, -1);
+        const float zf = (float)a.far_d;  // rasterize.py:296
+        if (a.depth_map) reinterpret_cast<float4 *>(a.depth_map)[i0 >> 2] = make_float4(zf, zf, zf, zf);
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (a.weight_map && !a.sparse_weights) {
+            float4 *w = reinterpret_cast<float4 *>(a.weight_map + 3 * i0);
+            w[0] = zero; w[1] = zero; w[2] = zero;
+        }
+        if (a.face_inv_map) {
+            float4 *o = reinterpret_cast<float4 *>(a.face_inv_map + 9 * i0);
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k] = zero;
+        }
+        if (a.alpha_map) reinterpret_cast<float4 *>(a.alpha_map)[i0 >> 2] = zero;  // :449
+        if (a.rgb_map) {
+            const float *bg = a.background + (a.bg_per_batch ? 3 * (int)(i0 / ((size_t)a.S * a.S)) : 0);
+            float c[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) c[k] = 0.0f * 0.0f + 1.0f * bg[k];  // :463 with mask = 0 (shade_pixel)
+            float4 *o = reinterpret_cast<float4 *>(a.rgb_map + 3 * i0);
+            o[0] = make_float4(c[0], c[1], c[2], c[0]);
+            o[1] = make_float4(c[1], c[2], c[0], c[1]);
+            o[2] = make_float4(c[2], c[0], c[1], c[2]);
+        }
+    }
+    if (ti == ep) resolve_pixel(a, i, true);
 }
 
 }  // namespace
@@ -689,10 +759,19 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     const unsigned queue_wgs = (unsigned)(n / 256 < 256 ? 256 : (n / 256 > 2048 ? 2048 : n / 256));
     hipLaunchKernelGGL(k_large_raster, dim3(queue_wgs), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
                        far, epoch, touched);
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, faces, zbuf, face_index_map,
-                       weight_map, depth_map, face_inv_map, visible_faces, F, S, near, far, P,
-                       faces_z_ref ? faces_z_ref : faces, textures, rgb_map, background, bg_per_batch, alpha_map, ts, eps,
-                       fix_batch_z, epoch, n_large, lit, (flags & NR_FLAG_SPARSE_WEIGHT_MAP) ? 1 : 0, touched);
+    ResolveArgs ra;
+    ra.faces = faces; ra.zbuf = zbuf; ra.face_index_map = face_index_map; ra.weight_map = weight_map; ra.depth_map = depth_map;
+    ra.face_inv_map = face_inv_map; ra.visible_faces = visible_faces; ra.F = F; ra.S = S; ra.near_d = near; ra.far_d = far;
+    ra.n_pixels = P; ra.zbase = faces_z_ref ? faces_z_ref : faces; ra.textures = textures; ra.rgb_map = rgb_map;
+    ra.background = background; ra.bg_per_batch = bg_per_batch; ra.alpha_map = alpha_map; ra.ts = ts; ra.eps = eps;
+    ra.fix_batch_z = fix_batch_z; ra.epoch = epoch; ra.queue_counters = n_large; ra.lit = lit;
+    ra.sparse_weights = (flags & NR_FLAG_SPARSE_WEIGHT_MAP) ? 1 : 0; ra.touched = touched;
+    const uintptr_t align = (uintptr_t)face_index_map | (uintptr_t)weight_map | (uintptr_t)depth_map | (uintptr_t)face_inv_map |
+                            (uintptr_t)rgb_map | (uintptr_t)alpha_map;
+    if (touched && S % 2 == 0 && (align & 15) == 0)  // (k_resolve_quads: 16-byte stores into every map)
+        hipLaunchKernelGGL(k_resolve_quads, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, ra);
+    else
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, ra);
     return launch_status();
 }
 }  // namespace

@@ -14,6 +14,7 @@ from k6_numerics import use_library
 
 dev = torch.device('cuda', 0)
 iters = int(os.environ.get('ITERS', 50))
+fwd_flags = int(os.environ.get('FWD_FLAGS', 16 | 32))  # epochs + sparse weight map: what the operator passes
 variants = [''] + os.environ.get('VARIANTS', '').split()
 for shape in os.environ.get('SHAPES', '1x256 4x256 8x256 16x256').split():
     B, S = (int(x) for x in shape.split('x'))
@@ -43,7 +44,7 @@ for shape in os.environ.get('SHAPES', '1x256 4x256 8x256 16x256').split():
             ep[0] -= 1
             return lib.nr_forward_rasterize(faces.data_ptr(), None, textures.data_ptr(), fi.data_ptr(), wm.data_ptr(), dm.data_ptr(),
                                             rgb.data_ptr(), am.data_ptr(), vis.data_ptr(), bg.data_ptr(), 0, B, F, S, ts, 0.1, 100.0,
-                                            1e-3, 16 | (e << 8), ws.data_ptr(), wsb, st)
+                                            1e-3, fwd_flags | (e << 8), ws.data_ptr(), wsb, st)
         for _ in range(3):
             _lib.check(call(), 'fwd')
         torch.cuda.synchronize()
@@ -54,7 +55,8 @@ for shape in os.environ.get('SHAPES', '1x256 4x256 8x256 16x256').split():
         e1.record()
         torch.cuda.synchronize()
         row[tag or 'product'] = round(e0.elapsed_time(e1) * 1e3 / iters, 1)
-        ref = fi.clone() if tag == '' else ref
-        assert bool((fi == ref).all())
+        got = (fi, dm, rgb, am)
+        ref = tuple(x.clone() for x in got) if tag == '' else ref
+        assert all(torch.equal(x, y) for x, y in zip(got, ref)), 'variant %r differs from the product library' % tag
     print(json.dumps(row), flush=True)
 use_library('')
