@@ -56,7 +56,8 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 400 /* 0.4.0: NR_FLAG_EXACT_GRADIENT and NR_FLAG_K6_SCAN combine (one band kernel, two arithmetic modes);
+#define NR_VERSION 401 /* 0.4.1: NR_FLAG_SERIAL_BACKWARD (the fused backward's gather shares a launch with K6's line setup);
+                          * 0.4.0: NR_FLAG_EXACT_GRADIENT and NR_FLAG_K6_SCAN combine (one band kernel, two arithmetic modes);
                           *        NR_FLAG_SPARSE_WEIGHT_MAP;
                           * 0.3.0: any `near` (NR_E_NEAR removed); 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
 
@@ -97,6 +98,12 @@ extern "C" {
                                          they are.  For callers that keep weight_map as a residual of the backward -- which
                                          reads it at covered pixels only -- and do not hand it out: 7 of 8 pixels of a teapot
                                          view are uncovered (44 of the map's 50 MB at the headline size). */
+#define NR_FLAG_SERIAL_BACKWARD 64     /* nr_backward_rasterize[_lit]: K6's line setup, its band kernel and the K7 / K8 gather as
+                                         launches of their own, one after the other (round 3's order).  Default (flag clear,
+                                         texture_size <= 13): the gather and the zeros of grad_textures share ONE launch with the
+                                         line setup, in front of the band kernel -- both only need the visible-face lists -- and
+                                         K6's sums are added onto grad_faces last.  Same values: one float addition per element
+                                         of grad_faces either way; a testing / measuring aid. */
 
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):

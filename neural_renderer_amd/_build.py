@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(HERE, 'csrc', n) for n in ('nr_forward.hip', 'nr_backward_pixel_map.hip', 'nr_backward_gather.hip', 'nr_geometry.hip',
                                                       'nr_image.hip', 'nr_frontend.hip', 'nr_texture_io.hip', 'nr_optim.hip')]
 HEADERS = [os.path.join(os.path.dirname(HERE), 'include', 'nr_hip.h'), os.path.join(HERE, 'csrc', 'nr_device.h'),
-           os.path.join(HERE, 'csrc', 'nr_k6_tune.h')]
+           os.path.join(HERE, 'csrc', 'nr_k6_tune.h'), os.path.join(HERE, 'csrc', 'nr_band_lines.h')]
 LIB_PATH = os.path.join(HERE, 'libnr_hip.so')
 
 # -ffp-contract=off + correctly rounded division: the parity contract (DESIGN.md "Numerics").

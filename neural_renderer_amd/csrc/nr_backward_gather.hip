@@ -16,6 +16,7 @@
 // Per-pixel terms use the reference's arithmetic; the order of the additions differs (as it does between
 // any two runs of the reference, whose atomics are unordered).
 #include "nr_device.h"
+#include "nr_band_lines.h"
 #include <type_traits>
 
 using namespace nr;
@@ -87,34 +88,55 @@ __device__ __forceinline__ void walk_owned_pixels(const Cand &cd, int n_mine, in
     const int qshift = (tid & 63) & ~(QL - 1);
     const unsigned long long qmask = QL == 64 ? ~0ull : ((1ull << QL) - 1ull);
     int waiting = 0;
-    for (int i = sub;; i += L) {
-        const bool more = i < n_mine;
-        const bool any_more = __ballot(more) != 0ull;
-        int x = 0, y = 0, off = 0;
-        bool owned = false;
-        if (more && cand_pixel(cd, i, S, x, y)) {
-            off = y * S + x;
-            owned = fi_img[off] == fn;
+    // Two candidate steps per round: both ownership words are requested before either is used (a face's walk is a chain of
+    // dependent round trips -- list, vertices, ownership, pixel data -- and a workgroup's time is that chain's, not its
+    // instructions'); the steps themselves run one after the other as before, so the order in which a lane meets its pixels
+    // is the candidate order still.
+    for (int i = sub;; i += 2 * L) {
+        bool more2[2], owned2[2];
+        int off2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ii = i + h * L;
+            more2[h] = ii < n_mine;
+            int x = 0, y = 0, f = 0;
+            off2[h] = 0;
+            bool in = false;
+            if (more2[h] && cand_pixel(cd, ii, S, x, y)) {
+                off2[h] = y * S + x;
+                f = fi_img[off2[h]];
+                in = true;
+            }
+            owned2[h] = in && f == fn;
         }
-        const unsigned long long m = (__ballot(owned) >> qshift) & qmask;
-        if (owned) queue[waiting + __popcll(m & ((1ull << qsub) - 1ull))] = off;
-        waiting += __popcll(m);
-        const bool ready = waiting >= QL || (!any_more && waiting > 0);
-        if (__ballot(ready) != 0ull) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int take = ready ? (waiting < QL ? waiting : QL) : 0;
-            const int e = qsub < take ? queue[qsub] : 0;
-            const int rest = (ready && qsub + QL < waiting) ? queue[qsub + QL] : 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            waiting -= take;
-            if (ready && qsub < waiting) queue[qsub] = rest;
-            if (qsub < take) eval(e);
+        bool done = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (done) break;
+            const bool more = more2[h], owned = owned2[h];
+            const int off = off2[h];
+            const bool any_more = __ballot(more) != 0ull;
+            const unsigned long long m = (__ballot(owned) >> qshift) & qmask;
+            if (owned) queue[waiting + __popcll(m & ((1ull << qsub) - 1ull))] = off;
+            waiting += __popcll(m);
+            const bool ready = waiting >= QL || (!any_more && waiting > 0);
+            if (__ballot(ready) != 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int take = ready ? (waiting < QL ? waiting : QL) : 0;
+                const int e = qsub < take ? queue[qsub] : 0;
+                const int rest = (ready && qsub + QL < waiting) ? queue[qsub + QL] : 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                waiting -= take;
+                if (ready && qsub < waiting) queue[qsub] = rest;
+                if (qsub < take) eval(e);
+            }
+            if (!any_more) done = true;  // (the evaluation above took everything that was waiting)
         }
-        if (!any_more) break;  // (the evaluation above took everything that was waiting)
+        if (done) break;
     }
 }
 
@@ -127,16 +149,41 @@ __device__ __forceinline__ void walk_owned_pixels(const Cand &cd, int n_mine, in
 // LIT = true: per-face light colours (FaceLight in nr_device.h) -- a template parameter, so that the kernels of the plain
 // path are exactly what they were without it (as a run-time branch it cost them registers: K7 alone 72 -> 76 VGPRs, one
 // wave of occupancy, 62 -> 71 us).
+struct FaceGatherArgs {
+    const int32_t *face_index_map;
+    const float *sampling_weight_map;
+    const int32_t *sampling_index_map;
+    const float *faces, *zbase, *weight_map, *depth_map, *g_rgb;
+    float *grad_textures;
+    int n_faces_total, F, S, ts;
+    double eps;
+    int fix_batch_z, L;
+    const int *vis_list, *vis_count;
+    const float *g_depth;
+    float *grad_faces;
+    const double *k6_scratch;
+    const int *slot_of;
+    FaceLight lit;
+};
+
+// bx, by: the workgroup's place in the gather's grid (blockIdx of k_backward_textures_face)
 template <bool TS2, bool DEPTH, bool LIT>
-__global__ __launch_bounds__(256) void k_backward_textures_face(
-    const int32_t *__restrict__ face_index_map, const float *__restrict__ sampling_weight_map,
-    const int32_t *__restrict__ sampling_index_map, const float *__restrict__ faces,
-    const float *__restrict__ zbase, const float *__restrict__ weight_map, const float *__restrict__ depth_map,
-    const float *__restrict__ g_rgb, float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts,
-    double eps, int fix_batch_z, int L,
-    const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces, const double *__restrict__ k6_scratch, const int *__restrict__ slot_of, FaceLight lit)
+__device__ __forceinline__ void face_gather_body(const FaceGatherArgs &a, const int bx, const int by)
 {
+    const int32_t *__restrict__ face_index_map = a.face_index_map;
+    const float *__restrict__ sampling_weight_map = a.sampling_weight_map;
+    const int32_t *__restrict__ sampling_index_map = a.sampling_index_map;
+    const float *__restrict__ faces = a.faces, *__restrict__ zbase = a.zbase, *__restrict__ weight_map = a.weight_map,
+                *__restrict__ depth_map = a.depth_map, *__restrict__ g_rgb = a.g_rgb;
+    float *__restrict__ grad_textures = a.grad_textures;
+    const int n_faces_total = a.n_faces_total, F = a.F, S = a.S, ts = a.ts;
+    const double eps = a.eps;
+    const int fix_batch_z = a.fix_batch_z, L = a.L;
+    const int *__restrict__ vis_list = a.vis_list, *__restrict__ vis_count = a.vis_count;
+    const float *__restrict__ g_depth = a.g_depth;
+    float *__restrict__ grad_faces = a.grad_faces;
+    const double *__restrict__ k6_scratch = a.k6_scratch;
+    const FaceLight &lit = a.lit;
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [256 / L][ts^3 * 3] (general path)
     __shared__ int s_queue[512];  // owned pixels waiting for their evaluation (walk_owned_pixels)
     __shared__ int s_own;         // lit, L == 256: does the workgroup's face own a pixel?
@@ -145,10 +192,10 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     const int tid = threadIdx.x;
     const int grp = tid / L, sub = tid - grp * L;
     const int n_tex = ts * ts * ts * 3;
-    int gi = blockIdx.x * (256 / L) + grp;  // global face index b * F + fn
+    int gi = bx * (256 / L) + grp;  // global face index b * F + fn
     bool face_ok = gi < n_faces_total;
     int slot = 0;
-    if (vis_list) {  // blockIdx.y = image, slot -> face through the image's visible list
+    if (vis_list) {  // by = image, slot -> face through the image's visible list
         // The grid covers F list slots per image, the list holds the ~1/6 of them that own a pixel: the other workgroups
         // leave here (they used to run the 24-sum reduction below on zeros -- 40 % of the kernel's instructions at the
         // headline size).
@@ -158,10 +205,13 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
         // +19 us on config 4 and 2.5x this kernel's time on 1024 views of 32 x 32, where 5 M faces mean 300 k workgroups that
         // each wait for a slot_of load before they can leave.)
         slot = gi;
-        const int n_vis = vis_count[blockIdx.y];
-        if ((int)blockIdx.x * (256 / L) >= n_vis) return;
+        // (the list entry is requested beside the list's length, not behind it: one round trip less in front of the walk;
+        // entries behind the length hold anything and are not used)
+        const int listed = slot < F ? vis_list[(size_t)by * F + slot] : 0;
+        const int n_vis = vis_count[by];
+        if (bx * (256 / L) >= n_vis) return;
         face_ok = slot < n_vis;
-        gi = face_ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + slot] : 0;
+        gi = face_ok ? by * F + listed : 0;
     }
     double *acc_l = s_acc + (size_t)grp * n_tex;
 
@@ -195,7 +245,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
     bool flip = false;
     size_t cube = 0;  // b * Nf + original face
     if (LIT) {
-        const int b = vis_list ? (int)blockIdx.y : gi / F, f = gi - b * F;
+        const int b = vis_list ? by : gi / F, f = gi - b * F;
         flip = f >= lit.tex_faces;
         cube = (size_t)b * lit.tex_faces + (flip ? f - lit.tex_faces : f);
     }
@@ -383,7 +433,7 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
             if (k6_scratch) {
                 // K6's result for this face (rasterize.py:736 stores, K8 then accumulates, :881-883): the double sums of
                 // its list position rounded to float, z = 0; the K8 sums (zero without a box of this kernel's) on top
-                const double *sc = k6_scratch + ((size_t)blockIdx.y * F + slot) * 6;
+                const double *sc = k6_scratch + ((size_t)by * F + slot) * 6;
 #pragma unroll
                 for (int v = 0; v < 3; v++) {
                     gf[3 * v + 0] = (float)sc[2 * v + 0] + dacc[3 * v + 0];
@@ -396,6 +446,55 @@ __global__ __launch_bounds__(256) void k_backward_textures_face(
             }
         }
     }
+}
+
+template <bool TS2, bool DEPTH, bool LIT>
+__global__ __launch_bounds__(256) void k_backward_textures_face(FaceGatherArgs a)
+{
+    face_gather_body<TS2, DEPTH, LIT>(a, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// --------------------------------------------------------------------------------------------------
+// The fused backward's launch between K6's compaction and its band kernel: the line setup (nr_band_lines.h), the K7 / K8
+// gather and the zeros of grad_textures in ONE grid.  All three need the visible-face lists and nothing else of each other;
+// the first two are latency-bound launches that each leave most of the chip idle (at the headline size 25.8 us on ~1000
+// working workgroups and 44.6 us on ~1900), the third is what would otherwise be a fill in front of the gather.  Side by
+// side they take what the longest takes.  (On two streams with event fork / join the same overlap cost 8 + 6 us of barrier
+// packets on the critical stream and a finishing launch: 3 us gained of 250; LAB-NOTEBOOK, round 4.)
+//   grid.x = [line setup | gather | zeros], grid.y = image.  The line-setup workgroups come first: the band kernel behind
+//   this launch waits for their records, the chip's dispatcher hands out workgroups in grid order.
+//   Zeros: every unlisted face's cube (slot_of < 0: the gather stores the listed ones completely), 2048 elements of 16 or 4
+//   bytes per workgroup, so that no fill has to finish before the gather may store.
+struct ZeroArgs {
+    float *grad_textures;
+    const int *slot_of;
+    int F;
+    int epf;        // elements per face cube: ts^3 * 3 floats, or a quarter of that in 16-byte elements
+    int vec;        // 16-byte elements (the cube is a multiple of four floats and the array 16-byte aligned)
+    unsigned wgs;   // zero workgroups per image
+};
+
+__device__ __forceinline__ void zero_unlisted_body(const ZeroArgs &z, const int bx, const int by)
+{
+    const size_t per_image = (size_t)z.F * z.epf;
+    const size_t e0 = (size_t)bx * 2048, e1 = e0 + 2048 < per_image ? e0 + 2048 : per_image;
+    const int *__restrict__ slot = z.slot_of + (size_t)by * z.F;
+    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int face = (int)(e / (unsigned)z.epf);
+        if (slot[face] >= 0) continue;
+        const size_t at = (size_t)by * per_image + e;
+        if (z.vec) reinterpret_cast<float4 *>(z.grad_textures)[at] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        else z.grad_textures[at] = 0.0f;
+    }
+}
+
+template <bool TS2, bool DEPTH, bool LIT>
+__global__ __launch_bounds__(256) void k_setup_gather(LineSetupArgs ls, FaceGatherArgs g, ZeroArgs z, unsigned gather_x)
+{
+    const unsigned bx = blockIdx.x;
+    if (bx < ls.grid_x) line_setup_body(ls, (int)bx, (int)blockIdx.y);
+    else if (bx < ls.grid_x + gather_x) face_gather_body<TS2, DEPTH, LIT>(g, (int)(bx - ls.grid_x), (int)blockIdx.y);
+    else zero_unlisted_body(z, (int)(bx - ls.grid_x - gather_x), (int)blockIdx.y);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -778,7 +877,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
                               int S, int ts, double eps, int flags, const int *vis_list, const int *vis_count,
                               hipStream_t st, const float *g_depth, float *grad_faces, int *depth_done,
                               const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit,
-                              bool prefilled)
+                              bool prefilled, int phase, const LineSetupArgs *ls, const int *zero_slot_of)
 {
     if (depth_done) *depth_done = 0;
     if (k6_finalized) *k6_finalized = 0;
@@ -803,51 +902,66 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     const bool fold = vis_list && k6_scratch && slot_of && grad_faces && ts <= 13;
     if (!fold) k6_scratch = nullptr, slot_of = nullptr;
     if (fold && k6_finalized) *k6_finalized = 1;
+    // The line setup rides in the gather's launch (k_setup_gather) when there is a face-walking gather on the lists and the two
+    // fit one launch's dynamic LDS; the zeros of grad_textures ride along too (plain path; zero_slot_of: K6's face -> position
+    // table), else they are filled in front.
+    const bool face_kernel = ts <= 13 && !(sampling_weight_map && ts > 13);
+    const size_t gather_lds = (ts2_static && !sampling_weight_map) ? 0 : (size_t)(256 / (ts <= 5 ? 16 : (ts <= 8 ? 64 : 256))) * n_tex * sizeof(double);
+    const bool fuse = ls && vis_list && face_kernel && phase != 2 && ls->lds_bytes <= 32768 && gather_lds <= 49152;
+    const bool zero_in_launch = fuse && !lit.light && zero_slot_of && !prefilled && ((size_t)grad_textures & 15) == 0;
+    if (phase != 2) {
     if (lit.light) {
         // original cubes: a face and its reversed copy share one, so only the one that owns a pixel stores; the rest is zero
         int e = prefilled ? 0 : fill_bytes(grad_textures, 0, (size_t)B * lit.tex_faces * n_tex * sizeof(float), st);
         if (e == 0 && lit.grad_light) e = fill_bytes(lit.grad_light, 0, (size_t)n * 3 * sizeof(float), st);
         if (e != 0) return e;
-    } else if (vis_list && !prefilled) {
+    } else if (vis_list && !prefilled && !zero_in_launch) {
         // only visible faces are visited: everything else is zero.  (Round 4 tried to spare the listed faces' cubes, which the
         // gathers store completely -- config 5: a 4 GB fill, 565 us at 7.1 TB/s -- with a fill predicated on K6's face ->
         // position table: 622-787 us in four forms, the division / table load / predicate cost more than the ~10 % of the
-        // bytes they save; the plain fill stays.)
+        // bytes they save; as a launch of its own the plain fill stays.)
         const int e = fill_bytes(grad_textures, 0, (size_t)n * n_tex * sizeof(float), st);
         if (e != 0) return e;
     }
+    }
+    bool setup_launched = false;
     // (the kernels take the per-face light mode as a template parameter: see k_backward_textures_face)
     auto launch = [&](auto lit_mode) {
     constexpr bool LITV = decltype(lit_mode)::value;
-    if (ts2_static && !sampling_weight_map) {
-        const dim3 grid = vis_list ? dim3((unsigned)((F + 15) / 16), (unsigned)B) : dim3((unsigned)((n + 15) / 16));
-        if (g_depth)
-            hipLaunchKernelGGL((k_backward_textures_face<true, true, LITV>), grid, dim3(256), 0, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
-                               slot_of, lit);
-        else
-            hipLaunchKernelGGL((k_backward_textures_face<true, false, LITV>), grid, dim3(256), 0, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, 16, vis_list, vis_count, (const float *)nullptr,
-                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of, lit);
-    } else if (ts <= 13) {
-        const int L = ts <= 5 ? 16 : (ts <= 8 ? 64 : 256);
+    if (phase != 2 && ts <= 13) {
+        const bool st2 = ts2_static && !sampling_weight_map;
+        const int L = st2 ? 16 : (ts <= 5 ? 16 : (ts <= 8 ? 64 : 256));
         const int per = 256 / L;
-        const size_t lds = (size_t)per * n_tex * sizeof(double);
+        const size_t lds = st2 ? 0 : (size_t)per * n_tex * sizeof(double);
         const dim3 grid = vis_list ? dim3((unsigned)((F + per - 1) / per), (unsigned)B) : dim3((unsigned)((n + per - 1) / per));
-        if (g_depth && L <= 64)
-            hipLaunchKernelGGL((k_backward_textures_face<false, true, LITV>), grid, dim3(256), lds, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, g_depth, grad_faces, k6_scratch,
-                               slot_of, lit);
-        else
-            hipLaunchKernelGGL((k_backward_textures_face<false, false, LITV>), grid, dim3(256), lds, st, face_index_map,
-                               sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map, grad_rgb_map,
-                               grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count, (const float *)nullptr,
-                               fold ? grad_faces : (float *)nullptr, k6_scratch, slot_of, lit);
+        const bool depth = g_depth && L <= 64;  // K8 rides along in the one-wave-per-group gathers
+        const FaceGatherArgs ga = {face_index_map, sampling_weight_map, sampling_index_map, faces, zbase, weight_map, depth_map,
+                                   grad_rgb_map, grad_textures, n, F, S, ts, eps, fix, L, vis_list, vis_count,
+                                   depth ? g_depth : (const float *)nullptr,
+                                   depth ? grad_faces : (fold ? grad_faces : (float *)nullptr), k6_scratch, slot_of, lit};
+        auto go = [&](auto ts2, auto dep) {
+            constexpr bool T = decltype(ts2)::value, D = decltype(dep)::value;
+            if (fuse) {
+                ZeroArgs z = {grad_textures, zero_slot_of, F, (int)n_tex, 0, 0u};
+                if (zero_in_launch) {
+                    z.vec = n_tex % 4 == 0;
+                    z.epf = z.vec ? (int)(n_tex / 4) : (int)n_tex;
+                    z.wgs = (unsigned)(((size_t)F * z.epf + 2047) / 2048);
+                }
+                const size_t both = lds > ls->lds_bytes ? lds : ls->lds_bytes;
+                hipLaunchKernelGGL((k_setup_gather<T, D, LITV>), dim3(ls->grid_x + grid.x + z.wgs, (unsigned)B), dim3(256), both, st,
+                                   *ls, ga, z, grid.x);
+                setup_launched = true;
+            } else {
+                hipLaunchKernelGGL((k_backward_textures_face<T, D, LITV>), grid, dim3(256), lds, st, ga);
+            }
+        };
+        using T = std::true_type;
+        using N = std::false_type;
+        if (st2) { if (depth) go(T(), T()); else go(T(), N()); }
+        else { if (depth) go(N(), T()); else go(N(), N()); }
     }
-    if (ts <= 8) {
+    if (ts <= 8 && phase != 1) {
         // faces the gathers above left out (more than BIG_PX candidates): a workgroup each
         const dim3 grid = big_grid(vis_list != nullptr, B, F);
         const bool st2 = ts2_static && !sampling_weight_map;
@@ -863,6 +977,9 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     }
     };
     if (lit.light) launch(std::true_type()); else launch(std::false_type());
+    if (phase == 2) return launch_status();
+    if (ls && !setup_launched)  // the line setup as a launch of its own (no face-walking gather to share one with)
+        if (int rc = run_line_setup(*ls, st)) return rc;
     if (ts > 13 && lit.light) {
         // (grad_textures and grad_light were zero-filled above)
         const size_t np = (size_t)B * S * S;

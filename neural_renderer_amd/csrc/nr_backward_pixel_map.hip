@@ -1,6 +1,7 @@
 // nr_backward_pixel_map.hip -- K6, the approximate gradient of rgb / alpha w.r.t. vertex x, y
 // (reference Rasterize.backward_pixel_map_gpu, rasterize.py:517-748) + its C-ABI entry point.
 #include "nr_device.h"
+#include "nr_band_lines.h"
 #include "nr_k6_tune.h"
 
 #include <atomic>
@@ -263,15 +264,6 @@ constexpr int FSEG = 15;         // pixels per piece (odd: consecutive pieces of
                                  // re-swept in round 3: 9 / 12 / 15 / 18 pixels -> stage 242 / 237 / 230 / 233 us)
 enum { K6_FAST = 0, K6_EXACT_POW2 = 1, K6_EXACT = 2 };
 
-struct __attribute__((aligned(16))) BandLine {
-    int in_rng;   // from | to << 16 (from > to: empty)
-    int out_rng;  // from | to << 16
-    int geo;      // d1_in | ld << 16 | flags << 24   (flags: 1 has out, 2 has0, 4 has1, 8 direction > 0)
-    int tgt;      // list position | v0 << 28 | v1 << 30
-    float cross, c0, c1;
-    int fn;
-};
-
 __global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict__ fi_map,
                                                       unsigned char *__restrict__ flags, int F, int SS, size_t P)
 {
@@ -279,17 +271,6 @@ __global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict_
     if (i >= P) return;
     const int fi = fi_map[i];
     if (fi >= 0) flags[(i / SS) * F + fi] = 1;
-}
-
-// Line range of one edge along one axis (rasterize.py:567-569), packed lo | hi << 16; RNG_EMPTY (lo > hi) when the edge
-// crosses no integer line or is parallel to the sweeps (p0x == p1x: both contributions are skipped, :648, :653).
-constexpr unsigned RNG_EMPTY = 1u;
-
-__device__ __forceinline__ unsigned edge_range(float p0x, float p1x, int S)
-{
-    const int d0_from = (int)fmax((double)ceilf(fminf(p0x, p1x)), 0.0);   // :568
-    const int d0_to = (int)fmin((double)fmaxf(p0x, p1x), S - 1.0);        // :569
-    return (p0x != p1x && d0_to >= d0_from) ? (unsigned)d0_from | ((unsigned)d0_to << 16) : RNG_EMPTY;
 }
 
 // What the compaction records for the face at list position `pos` of image b: its index, the six edge line ranges
@@ -326,6 +307,7 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
 
 // grad_faces of a face that owns no pixel (K6 contributes nothing, rasterize.py:604 / :707; K8 neither): when the fused
 // backward finishes K6 inside its gather launch, the compaction -- which visits every face anyway -- stores these zeros
+// (zero_listed: those of the listed faces too -- the fused backward whose gather runs BEFORE the band kernel and adds K8's sums)
 __device__ __forceinline__ void zero_face(float *__restrict__ o)
 {
 #pragma unroll
@@ -350,7 +332,8 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *
                                                            const float *__restrict__ faces, unsigned *__restrict__ rng,
                                                            double *__restrict__ scratch, int S,
                                                            int *__restrict__ chunk_band, int n_bands, int W,
-                                                           int *__restrict__ band_cursor, float *__restrict__ zero_faces)
+                                                           int *__restrict__ band_cursor, float *__restrict__ zero_faces,
+                                                           int zero_listed)
 {
     extern __shared__ int s_band[];  // [2][n_bands] lines per band of this chunk's faces
     __shared__ int s_wcnt[VIS_CHUNK / 64];
@@ -374,7 +357,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *
         const int before = off + __popcll(m & ((1ull << lane) - 1ull));  // visible faces in front of fn
         slot_of[(size_t)b * F + fn] = v ? before : -1;
         if (v) emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W);
-        else if (zero_faces) zero_face(zero_faces + ((size_t)b * F + fn) * 9);
+        if (zero_faces && (!v || zero_listed)) zero_face(zero_faces + ((size_t)b * F + fn) * 9);
     }
     __syncthreads();
     int *row = chunk_band + ((size_t)b * n_chunks + chunk) * 2 * n_bands;
@@ -444,7 +427,8 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
                                                                const float *__restrict__ faces,
                                                                unsigned *__restrict__ rng, double *__restrict__ scratch,
                                                                int S, int *__restrict__ band_lines, int n_bands, int W,
-                                                               int lds_counters, float *__restrict__ zero_faces)
+                                                               int lds_counters, float *__restrict__ zero_faces,
+                                                               int zero_listed)
 {
     // This workgroup's lines per band are counted in LDS and only the non-zero counters go to the image's global ones:
     // one device-wide atomic per (face, edge, band) cost 315 us on config 5 (same-address atomics from all 8 XCDs).
@@ -473,7 +457,7 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_visible(const unsigned ch
     if (fn < F) {
         const int before = off + __popcll(m & ((1ull << lane) - 1ull));  // visible faces in front of fn
         slot_of[(size_t)b * F + fn] = v ? before : -1;
-        if (!v && zero_faces) zero_face(zero_faces + ((size_t)b * F + fn) * 9);
+        if (zero_faces && (!v || zero_listed)) zero_face(zero_faces + ((size_t)b * F + fn) * 9);
         if (v)
             emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch,
                          lds_counters ? s_band : band_lines + (size_t)b * 2 * n_bands, n_bands, W);
@@ -523,274 +507,7 @@ __device__ __forceinline__ double signed_eps(float dist, unsigned eps_hi, unsign
     return __hiloint2double((int)((0.0f < dist) ? eps_hi : (eps_hi ^ 0x80000000u)), (int)eps_lo);
 }
 
-// --------------------------------------------------------------------------------------------------
-// The line records of the band kernel.  Which pixels a sweep visits is decided here, with the reference's arithmetic, and
-// must not depend on the arithmetic mode of the terms.
-// One line record (rasterize.py:543-579, :604-609, :665-672; the reference's arithmetic: the crossing
-// points decide WHICH pixels are visited, which must not depend on the mode).  fv: the face's 9 floats; (e, axis, d0): the
-// line; ld = d0 - first line of its band; owner_of(d1): face index of pixel (d0, d1) along the axis.
-// in two steps, so that a caller can have the ownership reads of several lines in flight before it finishes any of them
-struct LineHead {
-    float p0x, p0y, p1x, p1y, p2x, p2y, d0f, d1_cross;
-    int direction, d1_in, d1_out;
-    bool live;  // both the in and the out pixel lie inside the image (:578-579)
-};
-
-__device__ __forceinline__ LineHead fast_line_head(const float *__restrict__ fv, int e, int axis, int d0, int S)
-{
-    const float fs = (float)S;
-    const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
-    float fp[6];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { fp[k] = to_pixel(fv[3 * k], fs); fp[3 + k] = to_pixel(fv[3 * k + 1], fs); }
-    const int ox = axis ? 3 : 0, oy = axis ? 0 : 3;  // p[num][dim] = pp[num][(dim + axis) % 2] (:556)
-    LineHead h;
-    h.p0x = fp[ox + i0]; h.p0y = fp[oy + i0]; h.p1x = fp[ox + i1]; h.p1y = fp[oy + i1];
-    h.p2x = fp[ox + i2]; h.p2y = fp[oy + i2];
-    if (axis == 0) h.direction = (h.p0x < h.p1x) ? -1 : 1; else h.direction = (h.p0x < h.p1x) ? 1 : -1;  // :559-564
-    h.d0f = (float)d0;
-    h.d1_cross = (h.p1y - h.p0y) / (h.p1x - h.p0x) * (h.d0f - h.p0x) + h.p0y;                  // :573
-    h.d1_in = (0 < h.direction) ? (int)floorf(h.d1_cross) : (int)ceilf(h.d1_cross);             // :574
-    h.d1_out = h.d1_in + h.direction;                                                           // :575
-    h.live = !(h.d1_in < 0 || S <= h.d1_in) && !(h.d1_out < 0 || S <= h.d1_out);                // :578-579
-    return h;
-}
-
-// owner: face index of the line's in pixel (d0, d1_in) (only read when h.live); k2s: what the two distance coefficients are
-// multiplied by up front -- 2 / S for the tolerance mode (:649 `* 2. / is` folded in), 1 for the exact one
-__device__ __forceinline__ BandLine fast_line_finish(const LineHead &h, int ld, int S, int rfn, int tgt, int owner, float k2s)
-{
-    const float p0x = h.p0x, p0y = h.p0y, p1x = h.p1x, p1y = h.p1y, p2x = h.p2x, p2y = h.p2y, d0f = h.d0f;
-    const int direction = h.direction, d1_in = h.d1_in, d1_out = h.d1_out;
-    BandLine r;
-    r.in_rng = 1; r.out_rng = 1; r.geo = 0; r.tgt = tgt;
-    r.cross = r.c0 = r.c1 = 0.0f;
-    r.fn = rfn;
-    if (h.live) {
-        int flags = (0 < direction) ? 8 : 0;
-        if (p1x != d0f) flags |= 2;
-        if (p0x != d0f) flags |= 4;
-        r.c0 = (p1x - p0x) / (p1x - d0f) * k2s;  // :649 leading factor, invariant along the sweep (x 2 / S: see k2s)
-        r.c1 = (p1x - p0x) / (d0f - p0x) * k2s;  // :654
-        if (owner == rfn) {                      // :604-609
-            const int lim = (0 < direction) ? S - 1 : 0;
-            const int o_from = max(min(d1_out, lim), 0), o_to = min(max(d1_out, lim), S - 1);
-            r.out_rng = o_from | (o_to << 16);
-            flags |= 1;
-        }
-        float d0_cross2;                         // :665-672
-        if ((d0f - p0x) * (d0f - p2x) < 0)
-            d0_cross2 = (p2y - p0y) / (p2x - p0x) * (d0f - p0x) + p0y;
-        else
-            d0_cross2 = (p1y - p2y) / (p1x - p2x) * (d0f - p2x) + p2y;
-        const int lim2 = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
-        const int i_from = max(min(d1_in, lim2), 0), i_to = min(max(d1_in, lim2), S - 1);
-        r.in_rng = i_from | (i_to << 16);
-        r.geo = d1_in | (ld << 16) | (flags << 24);
-        r.cross = h.d1_cross;
-    }
-    return r;
-}
-
-template <typename OwnerOf>
-__device__ __forceinline__ BandLine make_fast_line(const float *__restrict__ fv, int e, int axis, int d0, int ld, int S,
-                                                   int rfn, int tgt, OwnerOf owner_of, float k2s)
-{
-    const LineHead h = fast_line_head(fv, e, axis, d0, S);
-    return fast_line_finish(h, ld, S, rfn, tgt, h.live ? owner_of(h.d1_in) : -1, k2s);
-}
-
-// --------------------------------------------------------------------------------------------------
-// k_line_setup: the line records of every (visible face, edge, axis, line d0), written band by band into line_buf so that
-// a band workgroup finds its lines as one dense array: no face scan, no record compaction, no line setup inside the band
-// kernel (together ~40 % of its cycles when they ran there, on <= 256 of its 512 threads).
-//   One workgroup takes LS_FACES list positions of one image (dealt out in turn, see the kernel).  Binning without a
-//   device-wide atomic per line (1.2 M same-address atomics across the 8 L2s of the chip cost 230 us): (1) the workgroup
-//   counts its own lines per band in LDS, (2) reserves its block of each non-empty band with ONE global atomic (band_cursor),
-//   (3) computes the records and places each at band start + block base + an LDS cursor.  The order inside a band is
-//   irrelevant: every record is accumulated independently.  tgt = list position | v0 << 28 | v1 << 30.
-//   The band table (lines per band, where each band starts) is the sum of the rows k_compact_par left per chunk: every
-//   workgroup adds them up for itself, the image's first one also publishes the table for the band kernel.
-// Images whose lines exceed the buffer's capacity (lines_ok[b] == 0) are skipped here and take the scan path of k_bpm_fast
-// (every backward test forces that path as well: tests/test_hip_parity.py check_backward, NR_FLAG_K6_SCAN).
-constexpr int LS_UNROLL = 4;  // lines per thread and round of k_line_setup
-constexpr int LS_FACES = 32;  // list positions per workgroup (measured with a thread per item: 64 -> 43 us, 32 -> 29 us, 16 -> 29 us)
-
-// Adds up the n_sum rows chunk_band[b][.][i] of an image (k_compact_par) into tot[i], i < n2, and takes the exclusive prefix
-// start[i]; returns the image's total.  All 256 threads of the workgroup; tot / start are LDS arrays.
-__device__ __forceinline__ int band_sum_prefix(const int *__restrict__ rows, int n_sum, int n2, int *tot, int *start,
-                                               int *s_tmp)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < n2; i += 256) {
-        int t = 0;
-        for (int c = 0; c < n_sum; ++c) t += rows[(size_t)c * n2 + i];
-        tot[i] = t;
-    }
-    __syncthreads();
-    // thread t owns the entries [t * per, (t + 1) * per)
-    const int per = (n2 + 255) / 256, i0 = tid * per, i1 = min(n2, i0 + per);
-    int local = 0;
-    for (int i = i0; i < i1; ++i) local += tot[i];
-    int inc = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o, WAVE);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) s_tmp[wave] = inc;
-    __syncthreads();
-    int run = inc - local;
-    for (int w = 0; w < wave; ++w) run += s_tmp[w];
-    for (int i = i0; i < i1; ++i) {
-        start[i] = run;
-        run += tot[i];
-    }
-    const int total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
-    __syncthreads();
-    return total;
-}
-
-__global__ __launch_bounds__(256) void k_line_setup(const float *__restrict__ faces, const int32_t *__restrict__ fi_map,
-                                                    const int *__restrict__ vis_list, const int *__restrict__ vis_count,
-                                                    const unsigned *__restrict__ rng, const int *__restrict__ chunk_band,
-                                                    int n_sum, int *__restrict__ band_lines, int *__restrict__ band_start,
-                                                    int *__restrict__ band_cursor, int *__restrict__ lines_ok,
-                                                    BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W,
-                                                    int n_bands, float k2s)
-{
-    extern __shared__ int s_cnt[];  // [2 * n_bands] this workgroup's lines per band, then its fill cursors; [2 * n_bands] bases;
-    int *s_base = s_cnt + 2 * n_bands;  // [2 * n_bands] where the image's bands start in its buffer
-    int *s_start = s_base + 2 * n_bands;
-    __shared__ int s_tmp[4];
-    __shared__ unsigned s_rng[6 * LS_FACES];  // [position][axis * 3 + edge]
-    __shared__ int s_lp[6 * LS_FACES + 1];    // first line of each item in the workgroup's numbering; total behind
-    __shared__ int s_fn[LS_FACES];
-    __shared__ float s_face[9 * LS_FACES];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const bool first = blockIdx.x == 0;  // publishes the image's band table for the band kernel
-    // The ceil(n_vis / LS_FACES) workgroups that have work deal the list positions out in turn (position = workgroup + k *
-    // workgroups): neighbours in the list are neighbours in the mesh, and a block of 32 large faces has three times the lines
-    // of an average one -- the kernel is one round of workgroups and as slow as its slowest.
-    const int n_vis = vis_count[b];
-    const int n_wg = (n_vis + LS_FACES - 1) / LS_FACES;
-    const int pos0 = blockIdx.x, pstep = n_wg;  // position of slot p: pos0 + p * pstep
-    const int n_pos = (int)blockIdx.x < n_wg ? (n_vis - pos0 + pstep - 1) / pstep : 0;
-    if (n_pos == 0 && !first) return;
-    unsigned r_own = RNG_EMPTY;
-    int fn_own = 0;
-    if (tid < 6 * n_pos) {
-        const int p = tid / 6, ae = tid - 6 * p, axis = ae / 3, e = ae - 3 * axis;
-        r_own = rng[(((size_t)b * 2 + axis) * F + pos0 + p * pstep) * 3 + e];
-    }
-    if (tid < n_pos) fn_own = vis_list[(size_t)b * F + pos0 + tid * pstep];
-    int ok;
-    if (n_sum > 0) {
-        // the image's lines per band = the sum of its chunk rows; every workgroup derives the band starts itself
-        const int total = band_sum_prefix(chunk_band + (size_t)b * n_sum * 2 * n_bands, n_sum, 2 * n_bands, s_cnt, s_start, s_tmp);
-        ok = (size_t)total <= cap ? 1 : 0;
-        if (first) {
-            for (int i = tid; i < 2 * n_bands; i += blockDim.x) {
-                band_lines[(size_t)b * 2 * n_bands + i] = s_cnt[i];
-                band_start[(size_t)b * 2 * n_bands + i] = s_start[i];
-            }
-            if (tid == 0) lines_ok[b] = ok;
-        }
-    } else {  // k_band_scan has prepared the table (large meshes)
-        ok = lines_ok[b];
-        for (int i = tid; i < 2 * n_bands; i += blockDim.x) s_start[i] = band_start[(size_t)b * 2 * n_bands + i];
-    }
-    if (n_pos == 0 || !ok) return;
-    __syncthreads();
-    for (int i = tid; i < 2 * n_bands; i += blockDim.x) s_cnt[i] = 0;
-    if (tid < 6 * LS_FACES) s_rng[tid] = r_own;
-    if (tid < LS_FACES) s_fn[tid] = fn_own;
-    __syncthreads();
-    // the vertices of the workgroup's faces (requested here, consumed after the reservations)
-    float fv_a = 0.0f, fv_b = 0.0f;
-    {
-        const int p = tid / 9, k = tid - 9 * p;  // 256 threads: faces 0 .. 27 and 4 floats of face 28
-        if (p < n_pos) fv_a = faces[((size_t)b * F + s_fn[p]) * 9 + k];
-        const int t2 = tid + 256, p2 = t2 / 9, k2 = t2 - 9 * p2;
-        if (t2 < 9 * LS_FACES && p2 < n_pos) fv_b = faces[((size_t)b * F + s_fn[p2]) * 9 + k2];
-    }
-    // (1) lines per band of this workgroup's (face, axis, edge) items; first line number of each item
-    {
-        int lines = 0;
-        if (tid < 6 * n_pos) {
-            const int p = tid / 6, ae = tid - 6 * p, axis = ae / 3;
-            const unsigned pr = s_rng[tid];
-            const int lo = (int)(pr & 0xffffu), hi = (int)(pr >> 16);
-            for (int band = lo / W; band * W <= hi; ++band)  // lo > hi (RNG_EMPTY): no iteration
-                atomicAdd(s_cnt + axis * n_bands + band, min(hi, band * W + W - 1) - max(lo, band * W) + 1);
-            lines = hi >= lo ? hi - lo + 1 : 0;
-        }
-        const int lane = tid & 63, wave = tid >> 6;
-        int inc = lines;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, WAVE);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) s_tmp[wave] = inc;
-        __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wave; ++w) before += s_tmp[w];
-        if (tid < 6 * LS_FACES) s_lp[tid] = before + inc - lines;
-        if (tid == 6 * LS_FACES - 1) s_lp[6 * LS_FACES] = before + inc;
-    }
-    __syncthreads();
-    // (2) one reservation per non-empty band
-    for (int i = tid; i < 2 * n_bands; i += blockDim.x) {
-        const int c = s_cnt[i];
-        s_base[i] = c > 0 ? s_start[i] + atomicAdd(band_cursor + (size_t)b * 2 * n_bands + i, c) : 0;
-        s_cnt[i] = 0;
-    }
-    s_face[tid] = fv_a;
-    if (tid + 256 < 9 * LS_FACES) s_face[tid + 256] = fv_b;
-    __syncthreads();
-    // (3) the records.  The workgroup's lines are numbered through (s_lp: first line of each item) and dealt to the threads
-    // LS_UNROLL at a time: a thread first requests the ownership words of all its lines of the round, then finishes them (with
-    // a thread per item walking its lines, every line waited for its own read: ~10 round trips in the longest item).
-    const size_t img = (size_t)b * S * S;
-    BandLine *buf_b = line_buf + (size_t)b * cap;
-    const int n_items = 6 * n_pos, n_lines = s_lp[n_items];
-    for (int base = 0; base < n_lines; base += LS_UNROLL * 256) {
-        LineHead h[LS_UNROLL];
-        int item[LS_UNROLL], d0v[LS_UNROLL], own[LS_UNROLL];
-#pragma unroll
-        for (int u = 0; u < LS_UNROLL; u++) {
-            const int l = base + u * 256 + tid;
-            item[u] = -1;
-            own[u] = -1;
-            if (l < n_lines) {
-                int lo = 0, hi = n_items;  // last item with s_lp[item] <= l
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_lp[mid] <= l) lo = mid; else hi = mid;
-                }
-                item[u] = lo;
-                const int p = lo / 6, ae = lo - 6 * p, axis = ae / 3, e = ae - 3 * axis;
-                const int d0 = (int)(s_rng[lo] & 0xffffu) + (l - s_lp[lo]);
-                d0v[u] = d0;
-                float fv[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) fv[k] = s_face[9 * p + k];
-                h[u] = fast_line_head(fv, e, axis, d0, S);
-                if (h[u].live) own[u] = fi_map[axis ? img + (size_t)d0 * S + h[u].d1_in : img + (size_t)h[u].d1_in * S + d0];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LS_UNROLL; u++) {
-            if (item[u] < 0) continue;
-            const int p = item[u] / 6, ae = item[u] - 6 * p, axis = ae / 3, e = ae - 3 * axis;
-            const int band = d0v[u] / W, ld = d0v[u] - band * W;
-            const int tgt = (pos0 + p * pstep) | (e << 28) | (((e + 1) % 3) << 30);
-            const int bi = axis * n_bands + band;
-            buf_b[s_base[bi] + atomicAdd(s_cnt + bi, 1)] = fast_line_finish(h[u], ld, S, s_fn[p], tgt, own[u], k2s);
-        }
-    }
-}
+__global__ __launch_bounds__(256) void k_line_setup(LineSetupArgs a) { line_setup_body(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // exclusive prefix of an image's 2 * n_bands line counts (first wave of the block), the image's total and the verdict
 // whether its records fit the buffer; zeroes the fill cursors
@@ -1542,13 +1259,26 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     }
 }
 
+// add: grad_faces holds what K8 left for the face (zeros from the compaction, then the gather's sums: the fused backward whose
+// gather runs beside the line setup) and K6's rounded sums go on top -- the one float addition per element that the in-gather
+// finish makes, operands exchanged
 __global__ __launch_bounds__(256) void k_bpm_finalize(const double *__restrict__ scratch, const int *__restrict__ slot_of,
-                                                      float *__restrict__ grad_faces, int F, int n_faces_total)
+                                                      float *__restrict__ grad_faces, int F, int n_faces_total, int add)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_faces_total) return;
     const int pos = slot_of[i];
     float *o = grad_faces + (size_t)i * 9;
+    if (add) {
+        if (pos < 0) return;
+        const double *src = scratch + ((size_t)(i / F) * F + pos) * 6;
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            o[3 * v + 0] = (float)src[2 * v + 0] + o[3 * v + 0];
+            o[3 * v + 1] = (float)src[2 * v + 1] + o[3 * v + 1];
+        }
+        return;
+    }
     double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (pos >= 0) {
         const double *src = scratch + ((size_t)(i / F) * F + pos) * 6;
@@ -1727,7 +1457,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                                int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
                                hipStream_t st, const int **vis_list_out, const int **vis_count_out,
                                const double **defer_scratch, const int **defer_slot_of, void *zero_ptr, size_t zero_bytes,
-                               int *zeroed)
+                               int *zeroed, const SetupHook *hook)
 {
     if (zeroed) *zeroed = 0;
     if (vis_list_out) *vis_list_out = nullptr;
@@ -1804,7 +1534,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         n_sum = L.n_chunks;
         hipLaunchKernelGGL(k_compact_par, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK),
                            (size_t)2 * n_bands * sizeof(int), st, vflags, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng,
-                           scratch, S, chunk_band, n_bands, W, band_cursor, defer ? grad_faces : (float *)nullptr);
+                           scratch, S, chunk_band, n_bands, W, band_cursor, defer ? grad_faces : (float *)nullptr, hook ? 1 : 0);
         if (!use_records)
             hipLaunchKernelGGL(k_band_total, dim3((unsigned)B), dim3(256), 0, st, chunk_band, n_sum, band_lines, band_start,
                                lines_ok, n_bands);
@@ -1816,17 +1546,19 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         hipLaunchKernelGGL(k_compact_visible, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK),
                            lds_counters ? (size_t)2 * n_bands * sizeof(int) : 0, st, vflags, chunk_count, vis_list, vis_count,
                            slot_of, F, L.n_chunks, faces, rng, scratch, S, band_lines, n_bands, W, lds_counters,
-                           defer ? grad_faces : (float *)nullptr);
+                           defer ? grad_faces : (float *)nullptr, hook ? 1 : 0);
         hipLaunchKernelGGL(k_band_scan, dim3((unsigned)B), dim3(256), 0, st, band_lines, band_start, band_cursor, lines_ok,
                            n_bands, cap, 0);
     }
-    if (use_records) {
-        static LdsLimit ls_limit;
-        if (int rc = ls_limit.ensure((const void *)k_line_setup, (size_t)6 * n_bands * sizeof(int))) return rc;
-        hipLaunchKernelGGL(k_line_setup, dim3((unsigned)((F + LS_FACES - 1) / LS_FACES), (unsigned)B), dim3(256),
-                           (size_t)6 * n_bands * sizeof(int), st, faces, face_index_map, vis_list, vis_count, rng,
-                           (const int *)(ws + L.cband_off), n_sum, band_lines, band_start, band_cursor, lines_ok, line_buf, L.cap, F,
-                           S, W, n_bands, k2s);
+    {
+        const LineSetupArgs la = {faces, face_index_map, vis_list, vis_count, rng, (const int *)(ws + L.cband_off), n_sum, band_lines,
+                                  band_start, band_cursor, lines_ok, line_buf, L.cap, F, S, W, n_bands, k2s,
+                                  (unsigned)((F + LS_FACES - 1) / LS_FACES), (unsigned)B, (size_t)6 * n_bands * sizeof(int)};
+        if (hook) {  // the caller launches the line setup, together with its gather (nr_band_lines.h)
+            if (int rc = hook->launch(hook->ctx, use_records ? &la : nullptr, vis_list, vis_count, slot_of, st)) return rc;
+        } else if (use_records) {
+            if (int rc = run_line_setup(la, st)) return rc;
+        }
     }
     // lines per window: the packed piece scan keeps each class count in 16 bits (<= win * 2 * S / FSEG pieces)
     const int win_lines = min(win, max(4, min(BAND_WIN, (int)(65535ll * FSEG / (2ll * S))) & ~3));
@@ -1837,7 +1569,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         // 4 GB would be 2 MB for each of 2048 workgroups and go at 7 TB/s through a fill launch instead)
         const size_t band_wgs = (size_t)((S + W - 1) / W) * 2 * (size_t)B;
         // (per workgroup: a 256-thread workgroup takes half of what a 512-thread one does)
-        const bool zero_ok = zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
+        const bool zero_ok = !hook && zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
                              zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10) * (size_t)shape.threads / 512;
         const int mode = !exact ? K6_FAST : ((S & (S - 1)) == 0 ? K6_EXACT_POW2 : K6_EXACT);
         auto launch = [&](auto r, auto a, auto m, auto nt) {
@@ -1867,15 +1599,23 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         return launch_status();
     }
     hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, slot_of, grad_faces,
-                       F, n);
+                       F, n, 0);
     return launch_status();
 }
 
-void nr::run_bpm_finalize(const double *scratch, const int *slot_of, float *grad_faces, int B, int F, hipStream_t st)
+void nr::run_bpm_finalize(const double *scratch, const int *slot_of, float *grad_faces, int B, int F, hipStream_t st, bool add)
 {
     const int n = B * F;
     hipLaunchKernelGGL(k_bpm_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, slot_of, grad_faces,
-                       F, n);
+                       F, n, add ? 1 : 0);
+}
+
+int nr::run_line_setup(const LineSetupArgs &a, hipStream_t st)
+{
+    static LdsLimit ls_limit;
+    if (int rc = ls_limit.ensure((const void *)k_line_setup, a.lds_bytes)) return rc;
+    hipLaunchKernelGGL(k_line_setup, dim3(a.grid_x, a.grid_y), dim3(256), a.lds_bytes, st, a);
+    return launch_status();
 }
 
 NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
@@ -1888,6 +1628,33 @@ NR_API int nr_backward_pixel_map(const float *faces, const int32_t *face_index_m
                                   F, S, eps, return_rgb, return_alpha, flags, visible_faces, workspace, workspace_bytes,
                                   (hipStream_t)stream, nullptr, nullptr);
 }
+
+// The fused backward's hook into K6 (nr_band_lines.h SetupHook): where K6 would launch its line setup, the K7 / K8 gather goes
+// out with it in one grid (nr_backward_gather.hip, k_setup_gather).
+namespace {
+struct GatherCall {
+    const float *faces, *faces_z_ref, *weight_map, *depth_map, *grad_rgb_map, *grad_depth_map;
+    const int32_t *face_index_map;
+    float *grad_textures, *grad_faces;
+    int B, F, S, ts, flags;
+    double eps;
+    const FaceLight *lit;
+    bool called;
+    int depth_done;
+};
+
+int launch_setup_and_gather(void *ctx, const LineSetupArgs *ls, const int *vis_list, const int *vis_count, const int *slot_of,
+                            hipStream_t st)
+{
+    GatherCall &g = *static_cast<GatherCall *>(ctx);
+    g.called = true;
+    // (no K6 scratch to finish: the gather adds K8's sums onto the zeros of the compaction, K6's follow behind the band kernel)
+    return run_backward_textures(g.face_index_map, nullptr, nullptr, g.faces, g.faces_z_ref, g.weight_map, g.depth_map,
+                                 g.grad_rgb_map, g.grad_textures, g.B, g.F, g.S, g.ts, g.eps, g.flags, vis_list, vis_count, st,
+                                 g.grad_depth_map, g.grad_faces, &g.depth_done, nullptr, nullptr, nullptr, *g.lit, false, 1, ls,
+                                 slot_of);
+}
+}  // namespace
 
 // Fused backward: K6, K7 and K8 of one Rasterize.backward_gpu call (rasterize.py:849-889) behind one entry point.
 // Same results as calling the three stage functions in the reference's order; the visible-face lists built for
@@ -1925,7 +1692,40 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     const double *k6_scratch = nullptr;
     const int *k6_slot_of = nullptr;
     int tex_zeroed = 0;
-    if (use_rgb || use_alpha) {
+    bool k6_done = false;
+    if (fold && !(flags & NR_FLAG_SERIAL_BACKWARD)) {
+        // Default order: compaction | line setup + gather + zeros of grad_textures in one grid | band kernel | the faces the
+        // gather left out | K6's sums onto grad_faces.  (NR_FLAG_SERIAL_BACKWARD: line setup | band kernel with the fill on the
+        // side | gather with K6's finish -- one launch less, 20 us more at the headline size.)
+        GatherCall gc = {faces, faces_z_ref, weight_map, depth_map, grad_rgb_map, use_depth ? grad_depth_map : nullptr,
+                         face_index_map, grad_textures, grad_faces, B, F, S, ts, flags, eps, &fl, false, 0};
+        const SetupHook hook = {&launch_setup_and_gather, &gc};
+        if (int rc = run_backward_pixel_map(faces, face_index_map, rgb_map, use_alpha ? alpha_map : nullptr, grad_rgb_map,
+                                            grad_alpha_map, grad_faces, B, F, S, eps, 1, use_alpha, flags, visible_faces, workspace,
+                                            workspace_bytes, st, &vis_list, &vis_count, &k6_scratch, &k6_slot_of, nullptr, 0,
+                                            nullptr, &hook))
+            return rc;
+        if (gc.called) {
+            int dd = 0;
+            if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, faces_z_ref, weight_map, depth_map,
+                                               grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
+                                               use_depth ? grad_depth_map : nullptr, grad_faces, &dd, nullptr, nullptr, nullptr, fl,
+                                               false, 2))
+                return rc;
+            if (use_depth && !gc.depth_done)
+                if (int rc = run_backward_depth_map(faces, depth_map, face_index_map, nullptr, weight_map, grad_depth_map,
+                                                    grad_faces, B, F, S, vis_list, vis_count, st, visible_faces))
+                    return rc;
+            if (k6_scratch) run_bpm_finalize(k6_scratch, k6_slot_of, grad_faces, B, F, st, true);
+            return launch_status();
+        }
+        // the band pipeline did not run (global-memory kernel: grad_faces complete, no lists): the gathers below, as they are
+        k6_scratch = nullptr;
+        k6_slot_of = nullptr;
+        k6_done = true;
+    }
+    if (k6_done) {
+    } else     if (use_rgb || use_alpha) {
         if (int rc = run_backward_pixel_map(faces, face_index_map, use_rgb ? rgb_map : nullptr,
                                             use_alpha ? alpha_map : nullptr, grad_rgb_map, grad_alpha_map, grad_faces,
                                             B, F, S, eps, use_rgb, use_alpha, flags, visible_faces, workspace,

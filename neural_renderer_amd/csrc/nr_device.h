@@ -284,20 +284,24 @@ inline int launch_status()
 // stage runners shared between the per-stage ABI entry points and the fused nr_backward_rasterize.
 // vis_list / vis_count (optional): per-image sorted lists of the faces that own at least one pixel, as built
 // by the K6 band pipeline ([B][F] ints, [B] counts); when given, the gather kernels visit only those faces.
+struct SetupHook;      // nr_band_lines.h
+struct LineSetupArgs;  // nr_band_lines.h
 int run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                            const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                            float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
                            int flags, const unsigned char *visible_faces, void *workspace, size_t workspace_bytes,
                            hipStream_t st, const int **vis_list_out, const int **vis_count_out,
                            const double **defer_scratch = nullptr, const int **defer_slot_of = nullptr,
-                           void *zero_ptr = nullptr, size_t zero_bytes = 0, int *zeroed = nullptr);
+                           void *zero_ptr = nullptr, size_t zero_bytes = 0, int *zeroed = nullptr,
+                           const SetupHook *hook = nullptr);
 // zero_ptr / zero_bytes: a buffer the caller wants zero-filled before its next kernel (the fused backward's grad_textures);
 // *zeroed = 1 when the band kernel did it on the side (default kernel, 16-byte aligned, <= 256 MB), else the caller fills
 // defer_scratch / defer_slot_of (both or none): the caller will finish K6 itself for the LISTED faces -- rounding the double
 // sums of their list positions into grad_faces (run_backward_textures does, or run_bpm_finalize for all faces) -- so
 // k_bpm_finalize is not launched and the compaction kernel stores the zeros of the unlisted faces; NULLs come back when
 // the band pipeline did not run (global-memory fallback: grad_faces are complete).
-void run_bpm_finalize(const double *scratch, const int *slot_of, float *grad_faces, int B, int F, hipStream_t st);
+void run_bpm_finalize(const double *scratch, const int *slot_of, float *grad_faces, int B, int F, hipStream_t st,
+                      bool add = false);  // add: on top of what grad_faces holds, listed faces only (see the kernel)
 int run_backward_textures(const int32_t *face_index_map, const float *sampling_weight_map,
                           const int32_t *sampling_index_map, const float *faces, const float *faces_z_ref,
                           const float *weight_map,
@@ -305,7 +309,12 @@ int run_backward_textures(const int32_t *face_index_map, const float *sampling_w
                           int ts, double eps, int flags, const int *vis_list, const int *vis_count, hipStream_t st,
                           const float *g_depth_fused, float *grad_faces_fused, int *depth_done,
                           const double *k6_scratch, const int *slot_of, int *k6_finalized, const FaceLight &lit = FaceLight(),
-                          bool prefilled = false);  // prefilled: grad_textures is already zero (no fill launch)
+                          bool prefilled = false, int phase = 0, const struct LineSetupArgs *ls = nullptr,
+                          const int *zero_slot_of = nullptr);
+// prefilled: grad_textures is already zero (no fill launch).  phase: 0 everything; 1 the fills and the gathers; 2 what they leave
+// out (k_backward_big) -- the fused backward runs K6's band kernel between the two.  ls: K6's line-setup launch, to go into
+// the gather's launch (phase 0 / 1; launched here in any case); zero_slot_of: K6's face -> list position table, with which
+// that launch also stores grad_textures' zeros (the cubes of unlisted faces) instead of a fill in front
 // lit.light given: grad_textures is [B, lit.tex_faces, ts^3, 3] (zero-filled here; a face stores only when it owns a
 // pixel -- of a face and its reversed copy at most one does), lit.grad_light receives [B, F, 3]
 int face_light_args(const nr_face_light *lit, int F, bool backward, FaceLight &out);  // nr_forward.hip

@@ -637,6 +637,7 @@ __global__ __launch_bounds__(256) void k_resolve(ResolveArgs a)
 // with 16-byte stores (a quad never straddles segments or images: 4 | 64, 4 | S * S); the drawn segments are resolved one
 // pixel per lane as before, and the other waves of an undrawn stretch leave at once.  (Fused forward of the headline batch
 // 72.3 -> 66.2 us; workgroups of 512 / 1024 pixels with 2 / 4 passes per lane: 72.9 / 82.6, profiles/r04_fwd_variants.jsonl.)
+// (256 pixels per workgroup: 64 / 128 / 512 / 1024 were measured -- 74.7 / 73.7 / 76.5 / 84.5 us against 69-70)
 __global__ __launch_bounds__(256) void k_resolve_quads(ResolveArgs a)
 {
     reset_queue_counters(a);

@@ -15,8 +15,9 @@ SURVEY quirk Q1 under sharding: the reference samples textures with the vertex d
 textures (BASELINE configs 2 and 4) would differ from the unsharded run.  `broadcast_reference_faces` ships rank 0's
 first projected view to every rank once per step (F*36 bytes: 177 KB for the teapot); passed as `Rasterize.faces_z_ref` /
 `Renderer.faces_z_ref` / `rasterize(..., faces_z_ref=)` it makes sharded and unsharded images and texture gradients
-identical bit for bit and the vertex gradients identical up to the order of K6's double-precision atomics, i.e. the last
-bit of a heavily cancelling entry (tests/test_sharding_gpu.py).  With fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) nothing needs to be exchanged.
+identical bit for bit and the vertex gradients identical up to what two calls of K6 on the same data differ by (default
+arithmetic: float run sums grouped by the order of atomics, <= 1.2e-5 of the largest gradient; NR_FLAG_EXACT_GRADIENT: the same
+bits; tests/test_sharding_gpu.py).  With fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) nothing needs to be exchanged.
 """
 import os
 

@@ -59,7 +59,7 @@ def fwd():  # as the operator calls it: kept workspace with falling epochs, weig
 def bwd():
     _lib.check(lib.nr_backward_rasterize(faces.data_ptr(), None, fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(),
                                          am.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), gf.data_ptr(),
-                                         gt.data_ptr(), B, F, S, ts, 1e-3, 0, vis.data_ptr(), wsb.data_ptr(), wsb_b, stream), 'b')
+                                         gt.data_ptr(), B, F, S, ts, 1e-3, int(os.environ.get('BWD_FLAGS', 0)), vis.data_ptr(), wsb.data_ptr(), wsb_b, stream), 'b')
 
 
 def timed(fn, n=30):

@@ -71,7 +71,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_host_only_entry_points(lib_path):
     lib = _lib.load()
-    assert lib.nr_version() == 400 == _lib.NR_VERSION
+    assert lib.nr_version() == 401 == _lib.NR_VERSION
     import neural_renderer_amd
     v = _lib.NR_VERSION
     assert neural_renderer_amd.__version__ == '%d.%d.%d' % (v // 1000, v // 100 % 10, v % 100)

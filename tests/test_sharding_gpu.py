@@ -33,12 +33,13 @@ def _run_abi(faces, textures, g_rgb, g_alpha, z_ref, flags=0):
 
 def _same(parts, full, names):
     """Shards == batch: bit for bit for the images and grad_textures (atomic-free kernels); grad_faces consists of the same
-    per-pixel terms either way, but K6 adds its per-line partial sums with double-precision atomics whose order is not fixed,
-    so the float it rounds to may differ in the last bit for a heavily cancelling entry: compared to 1e-5 of the largest."""
+    per-pixel terms either way, but the default K6 arithmetic groups them into float run sums by the order of its atomics, which
+    is not fixed: two calls differ by up to 1.2e-5 of the largest gradient where a face's line sums cancel
+    (scripts/same_terms_probe.py), sharded or not: compared to 3e-5."""
     for k, name in enumerate(names):
         got = np.concatenate((parts[0][k], parts[1][k]))
         if name == 'grad_faces':
-            assert H.rel_err(got, full[k]) <= 1e-5, name
+            assert H.rel_err(got, full[k]) <= 3e-5, name
         else:
             np.testing.assert_array_equal(got, full[k], err_msg=name)
 
