@@ -99,11 +99,12 @@ extern "C" {
                                          reads it at covered pixels only -- and do not hand it out: 7 of 8 pixels of a teapot
                                          view are uncovered (44 of the map's 50 MB at the headline size). */
 #define NR_FLAG_SERIAL_BACKWARD 64     /* nr_backward_rasterize[_lit]: K6's line setup, its band kernel and the K7 / K8 gather as
-                                         launches of their own, one after the other (round 3's order).  Default (flag clear,
-                                         texture_size <= 13): the gather and the zeros of grad_textures share ONE launch with the
-                                         line setup, in front of the band kernel -- both only need the visible-face lists -- and
-                                         K6's sums are added onto grad_faces last.  Same values: one float addition per element
-                                         of grad_faces either way; a testing / measuring aid. */
+                                         launches of their own, one after the other -- the order every call of more than 96 k
+                                         faces (batch x faces) takes anyway.  Smaller calls with texture_size <= 13 put the
+                                         gather and the zeros of grad_textures into ONE launch with the line setup, in front of
+                                         the band kernel (both only need the visible-face lists), and add K6's sums onto
+                                         grad_faces last.  Same values: one float addition per element of grad_faces either
+                                         way; a testing / measuring aid. */
 
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):

@@ -77,7 +77,7 @@ __device__ __forceinline__ DepthConst depth_constants(const float f[9], int S)
 // kernels that use this walk.
 //   n_mine: candidates of this lane's face (0: none, the lane only keeps step); queue: 2 * QL words of LDS per queue group
 //   (QL = min(L, 64) lanes: the face's group, or one wave of it when L == 256).
-template <class Eval>
+template <int STEPS, class Eval>
 __device__ __forceinline__ void walk_owned_pixels(const Cand &cd, int n_mine, int fn, const int32_t *__restrict__ fi_img,
                                                   int S, int sub, int L, int *__restrict__ queue_base, Eval eval)
 {
@@ -88,15 +88,16 @@ __device__ __forceinline__ void walk_owned_pixels(const Cand &cd, int n_mine, in
     const int qshift = (tid & 63) & ~(QL - 1);
     const unsigned long long qmask = QL == 64 ? ~0ull : ((1ull << QL) - 1ull);
     int waiting = 0;
-    // Two candidate steps per round: both ownership words are requested before either is used (a face's walk is a chain of
-    // dependent round trips -- list, vertices, ownership, pixel data -- and a workgroup's time is that chain's, not its
-    // instructions'); the steps themselves run one after the other as before, so the order in which a lane meets its pixels
-    // is the candidate order still.
-    for (int i = sub;; i += 2 * L) {
-        bool more2[2], owned2[2];
-        int off2[2];
+    // STEPS candidate steps per round (1 or 2): with 2, both ownership words are requested before either is used -- a face's
+    // walk is a chain of dependent round trips (list, vertices, ownership, pixel data) and a workgroup's time is that chain's,
+    // not its instructions' (K8's gather 62 -> 58 us) -- where the second pair of registers does not cost a wave of occupancy
+    // (K7 + K8 with static taps: 95 -> 102 VGPRs, four waves per SIMD instead of five, 252 -> 261 us for the fused backward).
+    // The steps themselves run one after the other, so the order in which a lane meets its pixels is the candidate order.
+    for (int i = sub;; i += STEPS * L) {
+        bool more2[STEPS], owned2[STEPS];
+        int off2[STEPS];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < STEPS; ++h) {
             const int ii = i + h * L;
             more2[h] = ii < n_mine;
             int x = 0, y = 0, f = 0;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void walk_owned_pixels(const Cand &cd, int n_mine, in
         }
         bool done = false;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < STEPS; ++h) {
             if (done) break;
             const bool more = more2[h], owned = owned2[h];
             const int off = off2[h];
@@ -268,7 +269,7 @@ __device__ __forceinline__ void face_gather_body(const FaceGatherArgs &a, const 
             img = (size_t)b * S * S;
         }
     }
-    walk_owned_pixels(cd, any_box ? cd.n : 0, fn, face_index_map + img, S, sub, L, s_queue, [&](int off) {
+    walk_owned_pixels<(TS2 && DEPTH) ? 1 : 2>(cd, any_box ? cd.n : 0, fn, face_index_map + img, S, sub, L, s_queue, [&](int off) {
         const size_t p = img + (size_t)off;
         float wk[3] = {0.0f, 0.0f, 0.0f}, depth = 0.0f, gd = 0.0f;
         if (weight_map) { wk[0] = weight_map[3 * p]; wk[1] = weight_map[3 * p + 1]; wk[2] = weight_map[3 * p + 2]; }
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(256) void k_backward_depth_face(
             img = (size_t)b * S * S;
         }
     }
-    walk_owned_pixels(cd, any_box ? cd.n : 0, fn, face_index_map + img, S, sub, L, s_queue, [&](int off) {
+    walk_owned_pixels<2>(cd, any_box ? cd.n : 0, fn, face_index_map + img, S, sub, L, s_queue, [&](int off) {
         const size_t p = img + (size_t)off;
         const float depth = depth_map[p];
         const float w[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};

@@ -1693,10 +1693,16 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     const int *k6_slot_of = nullptr;
     int tex_zeroed = 0;
     bool k6_done = false;
-    if (fold && !(flags & NR_FLAG_SERIAL_BACKWARD)) {
-        // Default order: compaction | line setup + gather + zeros of grad_textures in one grid | band kernel | the faces the
-        // gather left out | K6's sums onto grad_faces.  (NR_FLAG_SERIAL_BACKWARD: line setup | band kernel with the fill on the
-        // side | gather with K6's finish -- one launch less, 20 us more at the headline size.)
+    // Small launches (up to 96 k faces in the call: 32 teapot views) take the order
+    //   compaction | line setup + gather + zeros of grad_textures in ONE grid | band kernel | the faces the gather left out |
+    //   K6's sums onto grad_faces
+    // where the line setup and the gather -- two chains of dependent round trips that need nothing of each other -- run side
+    // by side (8 views: backward 82 -> 72 us, 16: 111 -> 104, 32: 156 -> 152).  Larger ones keep
+    //   compaction | line setup | band kernel with the fill on the side | gather with K6's finish:
+    // there both launches are bound by how many workgroups the chip holds, a shared grid takes the sum of their times (64
+    // views: 254.7 us either way), and the fill inside the band kernel and the finish inside the gather are worth more
+    // (config 4: 0.80 vs 0.87 ms, 1024 views of 32 x 32: 0.72 vs 0.85, config 5 with its 4 GB of zeros: 1.57 vs 1.97).
+    if (fold && (size_t)B * F <= 98304 && !(flags & NR_FLAG_SERIAL_BACKWARD)) {
         GatherCall gc = {faces, faces_z_ref, weight_map, depth_map, grad_rgb_map, use_depth ? grad_depth_map : nullptr,
                          face_index_map, grad_textures, grad_faces, B, F, S, ts, flags, eps, &fl, false, 0};
         const SetupHook hook = {&launch_setup_and_gather, &gc};

@@ -41,6 +41,9 @@ FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 # (read once, here) or the `exact_gradient` attribute of a Rasterize instance: every term with the reference's own arithmetic,
 # sums in double (bound 2e-6).  Measured levels and costs of both: profiles/*_parity_summary.md.
 EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
+# (measuring aid, read once: NR_SERIAL_BACKWARD=1 makes the fused backward launch K6's line setup, its band kernel and the gather one
+# after the other instead of the first and the last in one grid -- include/nr_hip.h NR_FLAG_SERIAL_BACKWARD; same values)
+_BACKWARD_ORDER_FLAG = _lib.NR_FLAG_SERIAL_BACKWARD if int(os.environ.get('NR_SERIAL_BACKWARD', '0')) else 0
 
 
 _RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -239,7 +242,7 @@ def _forward_impl(cfg, faces, textures, light):
                 raise ValueError('background_color must have shape (3,) or (batch size, 3)')
         if return_alpha:
             r.alpha_map = torch.empty((B, S, S), dtype=f32, device=dev)
-        flags = _lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg.fix_batch_z else 0
+        flags = (_lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg.fix_batch_z else 0) | _BACKWARD_ORDER_FLAG
         if cfg.exact_gradient:
             flags |= _lib.NR_FLAG_EXACT_GRADIENT
         r.flags = flags
@@ -393,7 +396,7 @@ class _GraphEntry(object):
         if ws_bytes == 0:
             raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
         self.fwd_ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        self.flags = (_lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg.fix_batch_z else 0) | \
+        self.flags = (_lib.NR_FLAG_FIX_TEXTURE_BATCH_Z if cfg.fix_batch_z else 0) | _BACKWARD_ORDER_FLAG | \
                      (_lib.NR_FLAG_EXACT_GRADIENT if cfg.exact_gradient else 0)
         self.generation = 0
         self.pending = None  # generation of the forward whose residuals the buffers hold and whose backward may still come
