@@ -1693,11 +1693,11 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     const int *k6_slot_of = nullptr;
     int tex_zeroed = 0;
     bool k6_done = false;
-    // Small launches (up to 96 k faces in the call: 32 teapot views) take the order
+    // Small launches (up to 96 k faces in the call: 16 views of the 4928-face teapot) take the order
     //   compaction | line setup + gather + zeros of grad_textures in ONE grid | band kernel | the faces the gather left out |
     //   K6's sums onto grad_faces
     // where the line setup and the gather -- two chains of dependent round trips that need nothing of each other -- run side
-    // by side (8 views: backward 82 -> 72 us, 16: 111 -> 104, 32: 156 -> 152).  Larger ones keep
+    // by side (8 views: backward 82 -> 72 us, 16: 111 -> 104; 32: 156 -> 152, not taken).  Larger ones keep
     //   compaction | line setup | band kernel with the fill on the side | gather with K6's finish:
     // there both launches are bound by how many workgroups the chip holds, a shared grid takes the sum of their times (64
     // views: 254.7 us either way), and the fill inside the band kernel and the finish inside the gather are worth more

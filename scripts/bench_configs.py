@@ -86,6 +86,12 @@ def run(name, faces, textures, S, modes, eps, iters=10, graph=False):
 
 def main():
     only = [k for k in os.environ.get('ONLY', '').split(',') if k]  # e.g. ONLY=C2,C4
+    # like bench.py: the process on the cores of one L3 group (torch's hand-over of every backward to its device thread costs
+    # 8 us there and ~130 us across groups: the host-bound rows -- C2, C3, the shards -- measure the host otherwise); NO_PIN=1: off
+    if not os.environ.get('NO_PIN'):
+        group = nr.distributed.pin_to_l3_group(0, 0)
+        print(json.dumps({'note': 'process pinned to one L3 group' if group else 'L3 topology unreadable: not pinned',
+                          'cpus': len(group) if group else None}), flush=True)
     rng = np.random.default_rng(1234)
     if not only or 'H' in only:
         # headline scene, per mode, AA off (S 256) and AA on (S 512)

@@ -29,7 +29,9 @@ K6 = ['k_mark_visible', 'k_compact_par', 'k_count_visible', 'k_compact_visible',
 KERNEL_STAGES = [
     ('k_face_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
     ('k_large_raster', ['forward_face_index_map', 'fused_forward_rasterize']),
-    ('k_resolve', ['forward_face_index_map', 'fused_forward_rasterize']),
+    # (late round 4: the kept-workspace forward resolves with k_resolve_quads, the per-call-fill one with k_resolve)
+    ('k_resolve_quads', ['fused_forward_rasterize']),
+    ('k_resolve', ['forward_face_index_map']),
     # (round 4: the fused forward of bench.time_stages keeps its workspace with epochs like the operator: no fill there; the
     # fused backward's fill rides in k_bpm_fast)
     ('k_fill_bytes', ['forward_face_index_map']),
