@@ -15,6 +15,9 @@
 //     lane (K6 stored them before, rasterize.py:881-883): no atomics.
 // Per-pixel terms use the reference's arithmetic; the order of the additions differs (as it does between
 // any two runs of the reference, whose atomics are unordered).
+// Fused backward (nr_backward_rasterize): one gather serves K7 and K8, visits only the faces of K6's visible lists and either
+// finishes K6 in its epilogue (large calls) or shares ONE launch with K6's line setup and the zeros of grad_textures, in front of
+// K6's band kernel (calls of up to 96 k faces: k_setup_gather below).
 #include "nr_device.h"
 #include "nr_band_lines.h"
 #include <type_traits>

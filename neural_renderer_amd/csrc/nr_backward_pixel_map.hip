@@ -239,6 +239,9 @@ __global__ __launch_bounds__(WAVE) void k_bpm_global(
 //          of a teapot view: the object covers 12 % of the image).
 //   k_line_setup   every line's record (crossing point, in / out pixels, sweep ranges, the two distance coefficients:
 //          rasterize.py:573-579, :606-609, :665-672), written band by band into one buffer.
+//          (The records and the kernel's body live in nr_band_lines.h: in the fused backward of a small call the K7 / K8
+//          gather shares this launch -- nr_backward_gather.hip, k_setup_gather, through the SetupHook of
+//          run_backward_pixel_map.)
 //   k_bpm_fast<RGB, ALPHA, MODE>   one workgroup per (image, axis, band of W consecutive lines d0); workgroup ids are
 //          mapped so that all bands of an image run on one XCD (xcd_block).  It
 //          1. stages the band's W x S pixels in LDS, laid out [line][d1] so that a sweep is a contiguous LDS run

@@ -672,8 +672,8 @@ def test_fused_launch_order_does_not_change_the_backward(ts, modes):
     g_alpha = rng.normal(size=(3, 96, 96)).astype(np.float32) if alpha else None
     g_depth = rng.normal(size=(3, 96, 96)).astype(np.float32) if depth else None
     gf_s, gt_s = abi.backward_fused(fw, g_rgb, g_alpha, g_depth, k6_flags=SERIAL)
-    for flags in (0, K6_SCAN, EXACT):
-        gf_o, gt_o = abi.backward_fused(fw, g_rgb, g_alpha, g_depth, k6_flags=flags)
+    for flags, use_visible in ((0, True), (0, False), (K6_SCAN, True), (EXACT, True)):  # (False: K6 rebuilds the flags itself)
+        gf_o, gt_o = abi.backward_fused(fw, g_rgb, g_alpha, g_depth, k6_flags=flags, use_visible=use_visible)
         assert not np.isnan(abi.host(gf_o)).any()
         assert H.rel_err(abi.host(gf_s), abi.host(gf_o)) <= (SAME_TERMS if flags != EXACT else K6_BOUND_DEFAULT)
         np.testing.assert_array_equal(abi.host(gt_s), abi.host(gt_o))
