@@ -908,7 +908,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     // The line setup rides in the gather's launch (k_setup_gather) when there is a face-walking gather on the lists and the two
     // fit one launch's dynamic LDS; the zeros of grad_textures ride along too (plain path; zero_slot_of: K6's face -> position
     // table), else they are filled in front.
-    const bool face_kernel = ts <= 13 && !(sampling_weight_map && ts > 13);
+    const bool face_kernel = ts <= 13;  // (above: the per-pixel scatter)
     const size_t gather_lds = (ts2_static && !sampling_weight_map) ? 0 : (size_t)(256 / (ts <= 5 ? 16 : (ts <= 8 ? 64 : 256))) * n_tex * sizeof(double);
     const bool fuse = ls && vis_list && face_kernel && phase != 2 && ls->lds_bytes <= 32768 && gather_lds <= 49152;
     const bool zero_in_launch = fuse && !lit.light && zero_slot_of && !prefilled && ((size_t)grad_textures & 15) == 0;
