@@ -122,6 +122,15 @@ extern "C" {
 int nr_version(void);
 const char *nr_error_string(int code);
 
+/* Measurement hook (bench.py's `roofline`): with enable != 0 every K6 band-kernel launch of nr_backward_pixel_map /
+ * nr_backward_rasterize[_lit] is bracketed by a pair of HIP events recorded on the call's stream (events of the library's own,
+ * created on the first enable); nr_profile_band_kernel_ms() waits for the last pair and returns the time between them in
+ * milliseconds (< 0: no launch was bracketed, or an event call failed).  That is the duration of the path's dominant kernel
+ * alone, without the helper launches of its stage call, as `rocprofv3 --kernel-trace --stats` reports it.  Process-wide, not
+ * thread-safe, and the two event packets cost the stream a few microseconds per call: off outside measurements. */
+int nr_profile_band_kernel(int32_t enable);
+float nr_profile_band_kernel_ms(void);
+
 /* Scratch needed by the forward: the packed 64-bit z-buffer (depth bits << 32 | face index, one word per pixel) and the
  * queue of faces with large screen boxes.  The reference's `faces_inv` scratch (rasterize.py:240) is not materialised. */
 size_t nr_forward_workspace_bytes(int32_t batch_size, int32_t num_faces, int32_t image_size);

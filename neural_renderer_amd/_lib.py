@@ -33,6 +33,8 @@ _cam_p, _light_p, _fl_p = _c.POINTER(Camera), _c.POINTER(Light), _c.POINTER(Face
 SIGNATURES = {
     'nr_version': (_c.c_int, []),
     'nr_error_string': (_c.c_char_p, [_c.c_int]),
+    'nr_profile_band_kernel': (_c.c_int, [_i32]),
+    'nr_profile_band_kernel_ms': (_c.c_float, []),
     'nr_forward_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'nr_backward_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'nr_forward_face_index_map': (_c.c_int, [_vp] * 6 + [_i32, _i32, _i32, _f64, _f64, _vp, _sz, _vp]),

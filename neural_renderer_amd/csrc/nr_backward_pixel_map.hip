@@ -1454,6 +1454,39 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
     return bpm_layout(B, F, S).total;
 }
 
+// Measurement hook (include/nr_hip.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.
+namespace {
+struct BandKernelTimer {
+    bool on = false, recorded = false;
+    hipEvent_t start = nullptr, stop = nullptr;
+} g_band_timer;
+}  // namespace
+
+NR_API int nr_profile_band_kernel(int32_t enable)
+{
+    BandKernelTimer &t = g_band_timer;
+    if (enable && !t.start) {
+        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) {
+            t.start = t.stop = nullptr;
+            return launch_status();
+        }
+    }
+    t.on = enable != 0 && t.start != nullptr;
+    t.recorded = false;
+    return 0;
+}
+
+NR_API float nr_profile_band_kernel_ms(void)
+{
+    BandKernelTimer &t = g_band_timer;
+    float ms = -1.0f;
+    if (!t.recorded || hipEventSynchronize(t.stop) != hipSuccess || hipEventElapsedTime(&ms, t.start, t.stop) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0f;
+    }
+    return ms;
+}
+
 int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                                const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
                                float *grad_faces, int B, int F, int S, double eps, int return_rgb, int return_alpha,
@@ -1592,7 +1625,9 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
             if (mode == K6_EXACT_POW2) return by_threads(r, a, std::integral_constant<int, K6_EXACT_POW2>());
             return by_threads(r, a, std::integral_constant<int, K6_EXACT>());
         };
+        if (g_band_timer.on) g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess;
         rc = (rgb && alpha) ? by_mode(T(), T()) : (rgb ? by_mode(T(), N()) : by_mode(N(), T()));
+        if (g_band_timer.on && g_band_timer.recorded) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess;
         if (rc == 0 && zero_ok && zeroed) *zeroed = 1;
     }
     if (rc) return rc;

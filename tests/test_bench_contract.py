@@ -55,7 +55,11 @@ def test_bench_json_line():
     assert fl['face_light_ms'] > 0 and fl['lit_textures_ms'] > 0
     assert fl['max_rel_diff']['images'] <= 1e-6 and fl['max_rel_diff']['grad_textures'] <= 1e-5
     st = r['stages']['per_stage']
-    assert set(st) == set(d['stages_us']) - {'fused_forward_rasterize', 'fused_backward_rasterize'}
+    assert set(st) == set(d['stages_us']) - {'fused_forward_rasterize', 'fused_backward_rasterize', 'k6_band_kernel_alone',
+                                               'k6_band_kernel_alone_in_fused_backward'}
+    # the roofline figure is on the dominant kernel alone (events around its launch), the stage call beside it
+    assert 0 < r['avg_launch_us'] == d['stages_us']['k6_band_kernel_alone'] < r['stage_call']['avg_us']
+    assert r['stage_call']['avg_us'] == d['stages_us']['backward_pixel_map'] and r['in_fused_backward_us'] > 0
     assert all(0 < v['coverage_scaled_bytes'] <= v['algorithmic_bytes'] and v['frac'] < 1.0 for v in st.values())
     assert d['timing']['backend'] is None and d['timing']['rank0_hip_event_ms_per_step'] > 0
 
