@@ -1122,3 +1122,30 @@ def test_operator_does_not_leak_device_memory():
     gc.collect()
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() <= before + (1 << 16), (before, torch.cuda.memory_allocated())
+
+
+def test_band_kernel_timing_hook():
+    """nr_profile_band_kernel (include/nr_hip.h): off -> no reading; on -> the band kernel's launch of the last K6 call is bracketed
+    by the library's own events, staged and fused entry points alike, and the results do not change."""
+    from neural_renderer_amd import _lib
+    lib = _lib.load()
+    faces, _ = H.teapot_views(2, 64)
+    rng = np.random.default_rng(77)
+    textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
+    fw = abi.forward(faces, textures, 64, 0.1, 100.0, 1e-3, (0.1, 0.2, 0.3), 0, True, True, False)
+    g_rgb = rng.normal(size=(2, 64, 64, 3)).astype(np.float32)
+    g_alpha = rng.normal(size=(2, 64, 64)).astype(np.float32)
+    assert lib.nr_profile_band_kernel(0) == 0 and lib.nr_profile_band_kernel_ms() < 0
+    ref, _ = abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
+    assert lib.nr_profile_band_kernel(1) == 0
+    try:
+        assert lib.nr_profile_band_kernel_ms() < 0  # nothing bracketed yet
+        got, _ = abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
+        t_fused = lib.nr_profile_band_kernel_ms()
+        abi.backward(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
+        t_staged = lib.nr_profile_band_kernel_ms()
+    finally:
+        lib.nr_profile_band_kernel(0)
+    assert 0 < t_fused < 50 and 0 < t_staged < 50  # milliseconds; a 2-view 64 x 64 launch takes tens of microseconds
+    np.testing.assert_array_equal(abi.host(got), abi.host(ref))  # (exact mode: the same bits run to run)
+    assert lib.nr_profile_band_kernel_ms() < 0
