@@ -516,7 +516,8 @@ __global__ __launch_bounds__(256) void k_backward_big(
     const float *__restrict__ zbase, const float *__restrict__ weight_map, const float *__restrict__ depth_map, const float *__restrict__ g_rgb,
     float *__restrict__ grad_textures, int n_faces_total, int F, int S, int ts, double eps, int fix_batch_z,
     const int *__restrict__ vis_list, const int *__restrict__ vis_count, const float *__restrict__ g_depth,
-    float *__restrict__ grad_faces, const unsigned char *__restrict__ visible, FaceLight lit)
+    float *__restrict__ grad_faces, const unsigned char *__restrict__ visible, FaceLight lit,
+    const double *__restrict__ k6_scratch)
 {
     extern __shared__ __attribute__((aligned(16))) double s_tex[];  // [ts^3 * 3] texel sums of the face being walked
     __shared__ int s_list[256];
@@ -534,6 +535,19 @@ __global__ __launch_bounds__(256) void k_backward_big(
         if (vis_list) {
             ok = gi < vis_count[blockIdx.y];
             gi = ok ? (int)blockIdx.y * F + vis_list[(size_t)blockIdx.y * F + gi] : 0;
+        }
+        if (k6_scratch && ok && blockIdx.z == 0) {
+            // K6's last step for the listed faces rides in this launch (the fused backward whose gather ran in front of the band
+            // kernel: grad_faces holds the gather's K8 sums, or zeros): K6's double sums of the face's list position, rounded, go
+            // on top -- as float atomics, requested here beside the face's vertices: a face of this kernel's own also receives
+            // its K8 sums from one of the launch's workgroups (below), and the two additions onto the gather's zero commute.
+            const double *sc = k6_scratch + ((size_t)blockIdx.y * F + blockIdx.x * 256 + tid) * 6;
+            float *gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                atomicAdd(gf + 3 * v + 0, (float)sc[2 * v + 0]);
+                atomicAdd(gf + 3 * v + 1, (float)sc[2 * v + 1]);
+            }
         }
         bool big = false;
         if (ok && !vis_list && visible && !visible[gi]) ok = false;
@@ -684,7 +698,10 @@ __global__ __launch_bounds__(256) void k_backward_big(
             grad_textures[(size_t)gi * 24 + 3 * isc + c] = s_red[9 + tid];
         }
         }
-        if (DEPTH && tid < 9) grad_faces[(size_t)gi * 9 + tid] += s_red[tid];
+        if (DEPTH && tid < 9) {
+            if (k6_scratch) atomicAdd(grad_faces + (size_t)gi * 9 + tid, s_red[tid]);  // (see the top of the kernel)
+            else grad_faces[(size_t)gi * 9 + tid] += s_red[tid];
+        }
         __syncthreads();
     }
 }
@@ -902,9 +919,11 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     if (ts == 2 && !ts2_static) g_depth = nullptr;
     if (g_depth && depth_done) *depth_done = 1;
     // K6's finish folded into the gather (see the kernel): needs the lists, a face-per-group kernel and somewhere to store
-    const bool fold = vis_list && k6_scratch && slot_of && grad_faces && ts <= 13;
+    // (phase 2: the finish rides in k_backward_big's launch instead, on top of what the gather of phase 1 left in grad_faces)
+    const double *finish_k6 = (phase == 2 && vis_list && k6_scratch && grad_faces && ts <= 8) ? k6_scratch : nullptr;
+    const bool fold = phase != 2 && vis_list && k6_scratch && slot_of && grad_faces && ts <= 13;
     if (!fold) k6_scratch = nullptr, slot_of = nullptr;
-    if (fold && k6_finalized) *k6_finalized = 1;
+    if ((fold || finish_k6) && k6_finalized) *k6_finalized = 1;
     // The line setup rides in the gather's launch (k_setup_gather) when there is a face-walking gather on the lists and the two
     // fit one launch's dynamic LDS; the zeros of grad_textures ride along too (plain path; zero_slot_of: K6's face -> position
     // table), else they are filled in front.
@@ -973,7 +992,7 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     hipLaunchKernelGGL((k_backward_big<T, D, LITV>), grid, dim3(256), lds, st, face_index_map, sampling_weight_map,   \
                        sampling_index_map, (const float *)nullptr, faces, zbase, weight_map, depth_map, grad_rgb_map, \
                        grad_textures, n, F, S, ts, eps, fix, vis_list, vis_count, D ? g_depth : (const float *)nullptr, \
-                       D ? grad_faces : (float *)nullptr, (const unsigned char *)nullptr, lit)
+                       (D || finish_k6) ? grad_faces : (float *)nullptr, (const unsigned char *)nullptr, lit, finish_k6)
         if (st2) { if (g_depth) NR_BIG(2, true); else NR_BIG(2, false); }
         else { if (g_depth) NR_BIG(1, true); else NR_BIG(1, false); }
 #undef NR_BIG
@@ -1014,7 +1033,8 @@ int nr::run_backward_depth_map(const float *faces, const float *depth_map, const
     const dim3 grid_big = big_grid(vis_list != nullptr, B, F);
     hipLaunchKernelGGL((k_backward_big<0, true, false>), grid_big, dim3(256), 0, st, face_index_map, (const float *)nullptr,
                        (const int32_t *)nullptr, face_inv_map, faces, faces, weight_map, depth_map, (const float *)nullptr,
-                       (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces, visible, FaceLight());
+                       (float *)nullptr, n, F, S, 2, 0.0, 0, vis_list, vis_count, grad_depth_map, grad_faces, visible, FaceLight(),
+                       (const double *)nullptr);
     return launch_status();
 }
 

@@ -1732,8 +1732,8 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     int tex_zeroed = 0;
     bool k6_done = false;
     // Small launches (up to 96 k faces in the call: 16 views of the 4928-face teapot) take the order
-    //   compaction | line setup + gather + zeros of grad_textures in ONE grid | band kernel | the faces the gather left out |
-    //   K6's sums onto grad_faces
+    //   compaction | line setup + gather + zeros of grad_textures in ONE grid | band kernel | the faces the gather left
+    //   out + K6's sums onto grad_faces (one launch)
     // where the line setup and the gather -- two chains of dependent round trips that need nothing of each other -- run side
     // by side (8 views: backward 82 -> 72 us, 16: 111 -> 104; 32: 156 -> 152, not taken).  Larger ones keep
     //   compaction | line setup | band kernel with the fill on the side | gather with K6's finish:
@@ -1750,17 +1750,17 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
                                             nullptr, &hook))
             return rc;
         if (gc.called) {
-            int dd = 0;
+            int dd = 0, finalized = 0;  // (K6's sums go onto grad_faces in k_backward_big's launch when there is one)
             if (int rc = run_backward_textures(face_index_map, nullptr, nullptr, faces, faces_z_ref, weight_map, depth_map,
                                                grad_rgb_map, grad_textures, B, F, S, ts, eps, flags, vis_list, vis_count, st,
-                                               use_depth ? grad_depth_map : nullptr, grad_faces, &dd, nullptr, nullptr, nullptr, fl,
-                                               false, 2))
+                                               use_depth ? grad_depth_map : nullptr, grad_faces, &dd, k6_scratch, k6_slot_of,
+                                               &finalized, fl, false, 2))
                 return rc;
             if (use_depth && !gc.depth_done)
                 if (int rc = run_backward_depth_map(faces, depth_map, face_index_map, nullptr, weight_map, grad_depth_map,
                                                     grad_faces, B, F, S, vis_list, vis_count, st, visible_faces))
                     return rc;
-            if (k6_scratch) run_bpm_finalize(k6_scratch, k6_slot_of, grad_faces, B, F, st, true);
+            if (k6_scratch && !finalized) run_bpm_finalize(k6_scratch, k6_slot_of, grad_faces, B, F, st, true);
             return launch_status();
         }
         // the band pipeline did not run (global-memory kernel: grad_faces complete, no lists): the gathers below, as they are
