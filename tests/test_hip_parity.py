@@ -672,10 +672,11 @@ def test_fused_launch_order_does_not_change_the_backward(ts, modes):
     g_alpha = rng.normal(size=(3, 96, 96)).astype(np.float32) if alpha else None
     g_depth = rng.normal(size=(3, 96, 96)).astype(np.float32) if depth else None
     gf_s, gt_s = abi.backward_fused(fw, g_rgb, g_alpha, g_depth, k6_flags=SERIAL)
-    for flags, use_visible in ((0, True), (0, False), (K6_SCAN, True), (EXACT, True)):  # (False: K6 rebuilds the flags itself)
+    # (use_visible False: K6 rebuilds the flags itself; K6_GLOBAL: no band pipeline, hence no lists and no launch to share)
+    for flags, use_visible in ((0, True), (0, False), (K6_SCAN, True), (EXACT, True), (K6_GLOBAL, True)):
         gf_o, gt_o = abi.backward_fused(fw, g_rgb, g_alpha, g_depth, k6_flags=flags, use_visible=use_visible)
         assert not np.isnan(abi.host(gf_o)).any()
-        assert H.rel_err(abi.host(gf_s), abi.host(gf_o)) <= (SAME_TERMS if flags != EXACT else K6_BOUND_DEFAULT)
+        assert H.rel_err(abi.host(gf_s), abi.host(gf_o)) <= (SAME_TERMS if flags in (0, K6_SCAN) else K6_BOUND_DEFAULT)
         np.testing.assert_array_equal(abi.host(gt_s), abi.host(gt_o))
 
 
