@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void k_mark_visible(const int32_t *__restrict_
 // chasing list -> vertices each) and six zeroed double sums.
 __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int S, const float *__restrict__ faces,
                                              int *__restrict__ vis_list, unsigned *__restrict__ rng,
-                                             double *__restrict__ scratch, int *band_count, int n_bands, int W)
+                                             double *__restrict__ scratch, int *band_count, int n_bands, int W,
+                                             int *line_diff = nullptr)
 {
     vis_list[(size_t)b * F + pos] = fn;
     const float *f = faces + ((size_t)b * F + fn) * 9;
@@ -300,6 +301,16 @@ __device__ __forceinline__ void emit_visible(int b, int fn, int pos, int F, int 
         for (int axis = 0; axis < 2; axis++) {
             const unsigned r = axis ? rb : ra;
             const int lo = (int)(r & 0xffffu), hi = (int)(r >> 16);
+            if (line_diff) {
+                // (k_compact_par: +1 where the edge's lines begin, -1 behind their end; the workgroup's prefix sum turns the
+                // array into "edges on this line", whose sums over a band's lines are the counts -- two atomics per edge and
+                // axis instead of one per band crossed, a loop of ~5 dependent LDS atomics on one-line bands)
+                if (lo <= hi) {
+                    atomicAdd(line_diff + axis * (S + 1) + lo, 1);
+                    atomicAdd(line_diff + axis * (S + 1) + hi + 1, -1);
+                }
+                continue;
+            }
             for (int band = lo / W; band * W <= hi; ++band)  // lo > hi (RNG_EMPTY): no iteration
                 atomicAdd(band_count + axis * n_bands + band, min(hi, band * W + W - 1) - max(lo, band * W) + 1);
         }
@@ -336,13 +347,16 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *
                                                            double *__restrict__ scratch, int S,
                                                            int *__restrict__ chunk_band, int n_bands, int W,
                                                            int *__restrict__ band_cursor, float *__restrict__ zero_faces,
-                                                           int zero_listed)
+                                                           int zero_listed, int use_diff)
 {
-    extern __shared__ int s_band[];  // [2][n_bands] lines per band of this chunk's faces
+    extern __shared__ int s_band[];  // [2][n_bands] lines per band of this chunk's faces; use_diff: + [2][S + 1] line differences
     __shared__ int s_wcnt[VIS_CHUNK / 64];
     __shared__ int s_part[VIS_CHUNK / 64];
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) s_band[i] = 0;
+    int *s_diff = use_diff ? s_band + 2 * n_bands : nullptr;
+    if (use_diff)
+        for (int i = tid; i < 2 * (S + 1); i += VIS_CHUNK) s_diff[i] = 0;
     int part = 0;  // (per wave) visible faces of this wave's columns of the preceding chunks
     for (int c = 0; c < chunk; ++c) part += __popcll(__ballot(flags[(size_t)b * F + c * VIS_CHUNK + tid] != 0));
     const int fn = chunk * VIS_CHUNK + tid;
@@ -359,10 +373,40 @@ __global__ __launch_bounds__(VIS_CHUNK) void k_compact_par(const unsigned char *
     if (fn < F) {
         const int before = off + __popcll(m & ((1ull << lane) - 1ull));  // visible faces in front of fn
         slot_of[(size_t)b * F + fn] = v ? before : -1;
-        if (v) emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W);
+        if (v) emit_visible(b, fn, before, F, S, faces, vis_list, rng, scratch, s_band, n_bands, W, s_diff);
         if (zero_faces && (!v || zero_listed)) zero_face(zero_faces + ((size_t)b * F + fn) * 9);
     }
     __syncthreads();
+    if (use_diff) {
+        // line differences -> edges per line (inclusive prefix over the 2 (S + 1) entries; the entry behind an axis' last line
+        // takes the closing -1s, so the running sum is back at 0 where the second axis begins) -> lines per band
+        const int n2 = 2 * (S + 1), per = (n2 + VIS_CHUNK - 1) / VIS_CHUNK, i0 = tid * per, i1 = min(n2, i0 + per);
+        int local = 0;
+        for (int i = i0; i < i1; ++i) local += s_diff[i];
+        int inc = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, WAVE);
+            if (lane >= o) inc += t;
+        }
+        __syncthreads();  // (s_part / s_wcnt were read above by every thread: reuse s_wcnt for the wave totals)
+        if (lane == 63) s_wcnt[wave] = inc;
+        __syncthreads();
+        int run = inc - local;
+        for (int w = 0; w < wave; ++w) run += s_wcnt[w];
+        for (int i = i0; i < i1; ++i) {
+            run += s_diff[i];
+            s_diff[i] = run;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) {
+            const int axis = i >= n_bands, band = i - axis * n_bands;
+            int c = 0;
+            for (int l = band * W; l < min(S, band * W + W); ++l) c += s_diff[axis * (S + 1) + l];
+            s_band[i] = c;
+        }
+        __syncthreads();
+    }
     int *row = chunk_band + ((size_t)b * n_chunks + chunk) * 2 * n_bands;
     for (int i = tid; i < 2 * n_bands; i += VIS_CHUNK) row[i] = s_band[i];
     if (chunk == 0)  // the fill cursors of k_line_setup (it runs after this kernel)
@@ -1568,9 +1612,12 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     if (L.n_chunks <= SMALL_CHUNKS && n_bands <= 4096) {
         int *chunk_band = (int *)(ws + L.cband_off);
         n_sum = L.n_chunks;
+        // (line-difference counting while the two line arrays fit beside the band counters: raster sides up to 3583)
+        const int use_diff = (size_t)(2 * n_bands + 2 * (S + 1)) * sizeof(int) <= 40960 ? 1 : 0;
         hipLaunchKernelGGL(k_compact_par, dim3((unsigned)L.n_chunks, (unsigned)B), dim3(VIS_CHUNK),
-                           (size_t)2 * n_bands * sizeof(int), st, vflags, vis_list, vis_count, slot_of, F, L.n_chunks, faces, rng,
-                           scratch, S, chunk_band, n_bands, W, band_cursor, defer ? grad_faces : (float *)nullptr, hook ? 1 : 0);
+                           (size_t)(2 * n_bands + (use_diff ? 2 * (S + 1) : 0)) * sizeof(int), st, vflags, vis_list, vis_count,
+                           slot_of, F, L.n_chunks, faces, rng, scratch, S, chunk_band, n_bands, W, band_cursor,
+                           defer ? grad_faces : (float *)nullptr, hook ? 1 : 0, use_diff);
         if (!use_records)
             hipLaunchKernelGGL(k_band_total, dim3((unsigned)B), dim3(256), 0, st, chunk_band, n_sum, band_lines, band_start,
                                lines_ok, n_bands);
