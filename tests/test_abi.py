@@ -80,6 +80,8 @@ def test_host_only_entry_points(lib_path):
     assert lib.nr_forward_workspace_bytes(64, 4928, 256) >= 64 * 256 * 256 * 8 + 64 * 4928 * 4
     assert lib.nr_forward_workspace_bytes(0, 1, 1) == 0
     assert lib.nr_forward_workspace_bytes(1, 1, 20000) == 0
+    # the measurement hook: switched off it touches no device, and there is nothing to read
+    assert lib.nr_profile_band_kernel(0) == 0 and lib.nr_profile_band_kernel_ms() < 0
 
 
 def test_argument_errors_do_not_need_a_gpu(lib_path):
