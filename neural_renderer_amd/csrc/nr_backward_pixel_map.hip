@@ -1787,7 +1787,7 @@ NR_API int nr_backward_rasterize_lit(const nr_face_light *lit, const float *face
     // there both launches are bound by how many workgroups the chip holds, a shared grid takes the sum of their times (64
     // views: 254.7 us either way), and the fill inside the band kernel and the finish inside the gather are worth more
     // (config 4: 0.80 vs 0.87 ms, 1024 views of 32 x 32: 0.72 vs 0.85, config 5 with its 4 GB of zeros: 1.57 vs 1.97).
-    if (fold && (size_t)B * F <= 98304 && !(flags & NR_FLAG_SERIAL_BACKWARD)) {
+    if (fold && (size_t)B * F <= k6::SHARED_LAUNCH_MAX_FACES && !(flags & NR_FLAG_SERIAL_BACKWARD)) {
         GatherCall gc = {faces, faces_z_ref, weight_map, depth_map, grad_rgb_map, use_depth ? grad_depth_map : nullptr,
                          face_index_map, grad_textures, grad_faces, B, F, S, ts, flags, eps, &fl, false, 0};
         const SetupHook hook = {&launch_setup_and_gather, &gc};
