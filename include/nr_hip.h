@@ -106,6 +106,12 @@ extern "C" {
                                          grad_faces last.  Same values: one float addition per element of grad_faces either
                                          way; a testing / measuring aid. */
 
+#define NR_FLAG_K6_LEGACY 128          /* K6: keep the default arithmetic mode on the piece-per-lane band kernel of rounds 3-4
+                                         (k_bpm_fast) instead of the lane-parallel one (k_bpm_px, round 5: the pixels of a sweep
+                                         across the lanes, the line records through the scalar unit).  Same per-pixel terms,
+                                         summed in a different order; a testing / measuring aid.  The exact mode, the scan
+                                         path and rasters whose line does not fit k_bpm_px's LDS band run on k_bpm_fast anyway. */
+
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):
  * the reference samples textures with the vertex depths of BATCH ELEMENT 0 (`&faces[face_index * 9]`, rasterize.py:389,

@@ -68,6 +68,7 @@ NR_FLAG_K6_SCAN = 8
 NR_FLAG_ZBUF_EPOCH = 16  # + epoch number << 8 (include/nr_hip.h)
 NR_FLAG_SPARSE_WEIGHT_MAP = 32
 NR_FLAG_SERIAL_BACKWARD = 64
+NR_FLAG_K6_LEGACY = 128
 NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1
 NR_CAMERA_LOOK = 2

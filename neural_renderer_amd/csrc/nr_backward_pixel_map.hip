@@ -632,13 +632,13 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
         if (RGB) {
             *reinterpret_cast<float4 *>(px.g + 4 * (size_t)l) = make_float4(ga, gr, gg, gb);
             *reinterpret_cast<float4 *>(px.c + 4 * (size_t)l) = make_float4(al, r, g, bl);
-            if (fi < 0) *reinterpret_cast<float4 *>(px.bg) = make_float4(al, r, g, bl);  // same value from every such pixel
+            if (px.bg && fi < 0) *reinterpret_cast<float4 *>(px.bg) = make_float4(al, r, g, bl);  // same value from every such pixel
         } else {
             px.g[l] = ga;
             px.c[l] = al;
-            if (fi < 0) px.bg[0] = al;
+            if (px.bg && fi < 0) px.bg[0] = al;
         }
-        if (fi >= 0) atomicOr(px.cov + ld * px.CW + (d1 >> 5), 1u << (d1 & 31));
+        if (px.cov && fi >= 0) atomicOr(px.cov + ld * px.CW + (d1 >> 5), 1u << (d1 & 31));  // (k_bpm_px keeps no coverage bits)
     };
     // four adjacent pixels of a map row with one 16-byte load per field: the 4 columns of a vertical band (one thread per
     // row; pixel j -> line j, d1 = y) or 4 consecutive pixels of a horizontal band's line (one thread per quad; pixel j ->
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
 // The band kernel, NT threads per workgroup (band_shape below).  (launch bounds: what the LDS of a shape admits -- six waves
 // per SIMD for three 512-thread workgroups per CU, four for four 256-thread ones; the generic exact form carries a double
 // division: four)
-template <bool RGB, bool ALPHA, int MODE, int NT>
+template <bool RGB, bool ALPHA, int MODE, int NT, bool OVF = false>
 __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVES_256 : 6)) void k_bpm_fast(
     const float *__restrict__ faces, const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map,
     const float *__restrict__ alpha_map, const float *__restrict__ g_rgb, const float *__restrict__ g_alpha,
@@ -1169,8 +1169,12 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     // (The same mapping on the forward and gather kernels changed nothing or cost 5 %: their reads are not shared.)
     const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
     const unsigned total_wg = n_bands * 2u * (unsigned)B;
-    const unsigned logical = xcd_block(total_wg);
-    if (logical >= total_wg) return;
+    // OVF: the launch behind k_bpm_px that serves the images whose records exceed the line buffer -- normally none -- by the scan
+    // path: a small grid whose workgroups first take one cooperative look at the images' verdicts (none over the buffer: leave)
+    // and otherwise walk the bands in strides.  (An instantiation of its own: with the band loop around it the ordinary kernel
+    // came out at 116 registers instead of 89 and 7 % slower.)
+    constexpr bool overflow_only = OVF;
+    auto band_body = [&](const unsigned logical) {
     if (n_zero16) {
         // The fused backward's zero fill of grad_textures (the K7 gather behind this kernel stores only the listed faces'
         // cubes) rides along: every workgroup clears one slice before it looks at its band -- half of them have nothing
@@ -1182,7 +1186,10 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
     const size_t bidx = ((size_t)b * 2 + axis) * n_bands + band;
-    const int n_band_lines = band_lines[bidx];
+    // overflow_only: this launch stands behind k_bpm_px and serves only the images whose records exceed the line buffer, by the
+    // scan path; the band tables are k_bpm_px's (per line), not this kernel's shape
+    if (overflow_only && lines_ok[b] != 0) return;
+    const int n_band_lines = overflow_only ? 1 : band_lines[bidx];
     if (n_band_lines == 0) return;  // step 0: no visible face has a line here
 
     size_t off = 0;
@@ -1227,8 +1234,8 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     // one face per thread and the lines of the chunk that fall into this band are set up in place.  The scan path keeps
     // nothing in registers across the sweeps -- it recomputes its chunk's line counts for every window -- so that the kernel's
     // register budget is the records path's.
-    const bool use_rec = lines_ok[b] != 0;
-    const BandLine *recs = line_buf + (size_t)b * cap + band_start[bidx];
+    const bool use_rec = !overflow_only && lines_ok[b] != 0;
+    const BandLine *recs = line_buf + (size_t)b * cap + (use_rec ? band_start[bidx] : 0);
     const int n_vis = use_rec ? 0 : vis_count[b];
     const unsigned *rng_ba = rng + ((size_t)b * 2 + axis) * F * 3;
     int chunk = 0, win = 0;  // (scan path) first list position of the chunk; (both) first line of the next window
@@ -1303,6 +1310,295 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
             }
         });
         __syncthreads();
+    }
+    };
+    if constexpr (!OVF) {
+        const unsigned logical = xcd_block(total_wg);
+        if (logical < total_wg) band_body(logical);
+    } else {
+        int any = 0;
+        for (int i = tid; i < B; i += NT) any |= lines_ok[i] == 0;
+        if (!__syncthreads_or(any)) return;
+        for (unsigned logical = blockIdx.x; logical < total_wg; logical += gridDim.x) {
+            band_body(logical);
+            __syncthreads();  // (the next band re-uses the LDS)
+        }
+    }
+}
+
+// ==================================================================================================
+// k_bpm_px (round 5): the band kernel with the sweeps laid ACROSS the lanes.
+//
+// k_bpm_fast gives a lane a PIECE (15 pixels of one sweep) and walks it pixel by pixel out of LDS: every visit is an LDS read,
+// every piece a descriptor, a record decode and a flush, every window a chain of barriers (profiles/r04_pmc_k6.txt: half of the
+// wave-cycles parked, the LDS array 45 % busy with 47 % of it bank conflicts, 48 lane-slots per 13-instruction visit).  Here a
+// WAVE owns a band line: its lanes hold the line's pixels in REGISTERS -- 64 consecutive pixels per chunk, pxk::CH chunks = one
+// group of 256 pixels -- and the line's records come through the SCALAR unit one after the other (s_load: the records of a line
+// are contiguous because the line setup bins per line, band width 1).  A visit is the 17 instructions of k_bpm_fast's class M,
+// but its record constants are SGPR operands, its pixel data never leaves the registers, the sweep's range is a 64-bit lane
+// mask made by the scalar unit, and nothing is queued, classified or decoded.  Per record and wave:
+//   out sweep (rasterize.py:604-657)   every chunk the sweep overlaps is one masked visit of all 64 lanes; the two sums of the
+//       record are reduced across the lanes (v_permlane32_swap folds the pair into one register, four DPP row steps) and the
+//       four row sums added in double to the record's slot of the wave's window (ds_add_f64, four lanes);
+//   in sweep (:665-728)   nine in ten are <= 4 pixels: a lane takes a whole record (phase A, k_bpm_fast's class G loop: LDS
+//       reads, ownership test :707, per-pixel sign of +- eps), float sums of <= 15 terms, double above;
+//   flush   one lane per record adds the window's two sums to the double scratch (global_atomic_add_f64), as k_bpm_fast does.
+// Arithmetic of a visit: the tolerance mode of k_bpm_fast (fused multiply-adds, v_rcp_f32), with
+//   dist = sigma * (|c| * |t| + eps),  sigma = sign(c) * sign(t)  -- t = d1 - d1_cross keeps its sign along an out sweep, so
+//   sigma is a property of the record and is applied once to its sum (the rounding of fma(c, t, +-eps) is symmetric in sign:
+//   the same bits as k_bpm_fast's fma(c0k, t, e0)).
+// Images whose records exceed the line buffer (lines_ok == 0) are left to k_bpm_fast's scan path (launched behind this kernel
+// with overflow_only set).  The exact mode (NR_FLAG_EXACT_GRADIENT) stays with k_bpm_fast.
+namespace pxk {
+constexpr int NT = 256;           // threads per workgroup: four waves, a band line each
+constexpr int NW = NT / 64;
+constexpr int CH = 4;             // chunks of 64 pixels a wave holds in registers
+constexpr int GROUP = 64 * CH;    // pixels of a line per task
+constexpr int WIN = 64;           // records per window (phase A gives each a lane)
+constexpr int IN_SEG = 16;        // float terms per double addition of an in sweep (a piece of k_bpm_fast holds 15)
+constexpr int IN_BATCH = 4;       // pixels of an in sweep whose LDS reads are requested together
+constexpr size_t LDS_BUDGET = 40 * 1024;  // four workgroups per 160 KB CU
+}  // namespace pxk
+
+// LDS hand-over between the lanes of ONE wave (its LDS operations execute in order; the fences keep the compiler from moving
+// accesses across)
+__device__ __forceinline__ void wave_lds_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool RGB, bool ALPHA>
+__global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
+    const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
+    const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, double *__restrict__ scratch,
+    const int *__restrict__ band_lines, const int *__restrict__ band_start, const int *__restrict__ lines_ok,
+    const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, float eps_f, int B,
+    uint4 *__restrict__ zero16, size_t n_zero16)
+{
+    using namespace pxk;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
+    const unsigned total_wg = n_bands * 2u * (unsigned)B;
+    const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_fast)
+    if (logical >= total_wg) return;
+    if (n_zero16) {  // the fused backward's zero fill of grad_textures rides along (see k_bpm_fast)
+        const size_t per = (n_zero16 + total_wg - 1) / total_wg, z_lo = (size_t)logical * per, z_hi = min(n_zero16, z_lo + per);
+        for (size_t k = z_lo + tid; k < z_hi; k += NT) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
+    if (lines_ok[b] == 0) return;  // records beyond the buffer: k_bpm_fast's scan path serves this image
+    const int band_lo = band * W, nld = min(W, S - band_lo);
+    const size_t lt = ((size_t)b * 2 + axis) * S + band_lo;  // the band's lines in the per-line tables (band width 1)
+    int n_tot = 0;
+    for (int l = 0; l < nld; ++l) n_tot += band_lines[lt + l];
+    if (n_tot == 0) return;  // no visible face has a line here
+
+    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient / colour arrays: (alpha, r, g, b) or alpha alone
+    const int SP = S;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
+    FastPx px;
+    px.fi = (int *)carve((size_t)W * SP * 4);
+    px.g = (float *)carve((size_t)W * SP * NC * 4);
+    px.c = (float *)carve((size_t)W * SP * NC * 4);
+    px.bg = nullptr; px.cov = nullptr; px.CW = 0; px.span = nullptr;
+    double *s_acc = (double *)carve((size_t)NW * WIN * 16);
+    fast_stage<RGB, ALPHA, NT>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, (size_t)b * S * S, axis, band_lo, nld, S, SP);
+    __syncthreads();
+
+    int lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    float eps_v = eps_f;
+    asm volatile("" : "+v"(eps_v));  // (a VGPR: the visit's fma takes |c| from an SGPR, and one SGPR is all a VALU operation reads)
+    const int n_groups = (S + GROUP - 1) / GROUP;
+    // A band narrower than the workgroup has waves (small launches: the host narrows the bands to have enough workgroups) deals
+    // the records of a line to n_parts waves, in runs of WIN / n_parts: the critical path of a workgroup is its longest line.
+    const int n_parts = max(1, NW / (W * n_groups)), sub_win = WIN / n_parts;
+    double *acc = s_acc + wave * (WIN * 2);
+    const BandLine *recs_b = line_buf + (size_t)b * cap;
+    for (int vt = wave; vt < nld * n_groups * n_parts; vt += NW) {
+        const int task = vt / n_parts, part = vt - task * n_parts;
+        const int ld = task / n_groups, grp = task - ld * n_groups;
+        const int n_rec = band_lines[lt + ld];
+        if (n_rec == 0) continue;
+        const BandLine *recs = recs_b + band_start[lt + ld];
+        const int base = ld * SP, gb = grp * GROUP;
+        // ---- the group's pixels: gradients, colours, coordinate (a lane beyond the line repeats the last pixel; no mask reaches it)
+        float gq[CH][NC], cq[CH][NC], d1f[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int d1 = gb + 64 * j + lane, l = base + min(d1, S - 1);
+            d1f[j] = (float)d1;
+            if constexpr (RGB) {
+                const float4 g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
+                const float4 c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l);
+                gq[j][0] = g4.x; gq[j][NC - 3] = g4.y; gq[j][NC - 2] = g4.z; gq[j][NC - 1] = g4.w;
+                cq[j][0] = c4.x; cq[j][NC - 3] = c4.y; cq[j][NC - 2] = c4.z; cq[j][NC - 1] = c4.w;
+            } else {
+                gq[j][0] = px.g[l];
+                cq[j][0] = px.c[l];
+            }
+        }
+        for (int w0 = part * sub_win; w0 < n_rec; w0 += sub_win * n_parts) {
+            const int nw = min(sub_win, n_rec - w0);
+            // ---- phase A: lane = record.  The lane keeps its record for the flush, walks the record's in sweep, and prepares what
+            // phase B broadcasts from it: the reference colour of the OUT sweep (the in pixel, :594-601), |c0|, |c1|, the crossing
+            // point, and the sweep's pixel range with the chunks it touches.
+            int4 hh = make_int4(1, 1, 0, 0);
+            float4 qq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (lane < nw) {
+                const BandLine *R = recs + w0 + lane;
+                hh = *reinterpret_cast<const int4 *>(R);
+                qq = *reinterpret_cast<const float4 *>(&R->cross);
+            }
+            const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
+            const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
+            const bool has_out = o_from <= o_to && o_to >= gb && o_from < gb + GROUP;  // (:604: the in pixel is the face's)
+            float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (has_out) {
+                if constexpr (RGB) oref = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)(base + d1_in));
+                else oref.x = px.c[base + d1_in];
+            }
+            // the sweep inside this group: first pixel, last pixel (relative to the group), chunks touched
+            const int rel_from = max(o_from - gb, 0), rel_to = min(o_to - gb, GROUP - 1);
+            const int pk = has_out ? (rel_from | (rel_to - rel_from) << 8 | (rel_from >> 6) << 18 | (rel_to >> 6) << 16) : 0;
+            double in0 = 0.0, in1 = 0.0;
+            if (grp == 0) {
+                const int in_from = hh.x & 0xffff, in_to = hh.x >> 16;
+                if (in_from <= in_to) {
+                    // reference colour of the IN sweep: the out pixel (:697-700)
+                    const int lref = base + d1_in + ((flags & 8) ? 1 : -1);
+                    float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
+                    if constexpr (RGB) {
+                        const float4 q = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)lref);
+                        ra = q.x; rr = q.y; rg = q.z; rb = q.w;
+                    } else {
+                        ra = px.c[lref];
+                    }
+                    const float cross = qq.x, c0k = qq.y, c1k = qq.z;
+                    const int fnr = __float_as_int(qq.w);
+                    // (batches of IN_BATCH pixels whose LDS reads are requested together -- nine in-sweeps in ten are one batch;
+                    // IN_SEG float terms per double addition, like a piece of k_bpm_fast)
+                    for (int s0 = in_from; s0 <= in_to; s0 += IN_SEG) {
+                        const int s1 = min(s0 + IN_SEG - 1, in_to);
+                        float b0 = 0.0f, b1 = 0.0f;
+                        for (int q0 = s0; q0 <= s1; q0 += IN_BATCH) {
+                            int fi[IN_BATCH];
+                            float4 g4[IN_BATCH], c4[IN_BATCH];
+#pragma unroll
+                            for (int k = 0; k < IN_BATCH; ++k) {
+                                const int l = base + min(q0 + k, s1);
+                                fi[k] = px.fi[l];
+                                if constexpr (RGB) {
+                                    g4[k] = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
+                                    c4[k] = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l);
+                                } else {
+                                    g4[k] = make_float4(px.g[l], 0.0f, 0.0f, 0.0f);
+                                    c4[k] = make_float4(px.c[l], 0.0f, 0.0f, 0.0f);
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < IN_BATCH; ++k) {
+                                float diff;
+                                if constexpr (RGB) {
+                                    diff = ALPHA ? __builtin_fmaf(c4[k].y - rr, g4[k].y, (c4[k].x - ra) * g4[k].x) : (c4[k].y - rr) * g4[k].y;  // :709-716
+                                    diff = __builtin_fmaf(c4[k].z - rg, g4[k].z, diff);
+                                    diff = __builtin_fmaf(c4[k].w - rb, g4[k].w, diff);
+                                } else {
+                                    diff = (c4[k].x - ra) * g4[k].x;
+                                }
+                                // :707, :717 (a NaN diff goes through); a pixel beyond the batch's end repeats the last one: dropped
+                                const bool take = (q0 + k <= s1) & (fi[k] == fnr) & !(diff <= 0.0f);
+                                const float t = (float)(q0 + k) - cross;
+                                const float x0 = c0k * t, x1 = c1k * t;                               // :719 / :724 (2 / S folded into c)
+                                const float y0 = x0 + ((0.0f < x0) ? eps_v : -eps_v);                 // :720-721 / :725-726
+                                const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
+                                const float dm = take ? diff : 0.0f;
+                                // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
+                                b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
+                                b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
+                            }
+                        }
+                        in0 += (double)b0;
+                        in1 += (double)b1;
+                    }
+                }
+            }
+            reinterpret_cast<double2 *>(acc)[lane] = make_double2(0.0, 0.0);  // the window's out-sweep sums (magnitudes)
+            wave_lds_handover();
+            // ---- phase B: the window's out sweeps, one record after the other; the record's constants come from its lane of
+            // phase A (v_readlane: SGPR operands of the visits)
+            float v_ac0 = fabsf(qq.y), v_ac1 = fabsf(qq.z);
+            asm volatile("" : "+v"(v_ac0), "+v"(v_ac1));  // (computed here, once, not per record)
+            // (everything phase A requested has arrived: inside the loop nothing then waits for an LDS counter, behind which the
+            // four-lane atomics of the previous record would stand)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            for (unsigned long long todo = __ballot(has_out); todo; todo &= todo - 1) {
+                const int r = (int)__builtin_ctzll(todo);
+                const int spk = __builtin_amdgcn_readlane(pk, r);
+                const float cross = bcast_f(qq.x, r), ac0 = bcast_f(v_ac0, r), ac1 = bcast_f(v_ac1, r);
+                const float ra = bcast_f(oref.x, r);
+                float rr = 0.0f, rg = 0.0f, rb = 0.0f;
+                if constexpr (RGB) { rr = bcast_f(oref.y, r); rg = bcast_f(oref.z, r); rb = bcast_f(oref.w, r); }
+                const unsigned rel0 = (unsigned)(spk & 0xff), len = (unsigned)((spk >> 8) & 0xff);
+                float a0 = 0.0f, a1 = 0.0f;
+                // The chunks a sweep touches are a run jlo .. jhi.  (A straight-line block per possible run, so that the visits of a
+                // record's chunks could be interleaved, was built and measured: the compiler keeps the visits one after the other
+                // in either scheduling strategy, and the ten blocks cost 23 % more instructions -- 217 vs 172 us.)
+                const int jlo = (spk >> 18) & 3, jhi = (spk >> 16) & 3;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    if (j < jlo || j > jhi) continue;
+                    float d;                                                                   // :631-638
+                    if constexpr (RGB) {
+                        d = ALPHA ? __builtin_fmaf(cq[j][NC - 3] - rr, gq[j][NC - 3], (cq[j][0] - ra) * gq[j][0])
+                                  : (cq[j][NC - 3] - rr) * gq[j][NC - 3];
+                        d = __builtin_fmaf(cq[j][NC - 2] - rg, gq[j][NC - 2], d);
+                        d = __builtin_fmaf(cq[j][NC - 1] - rb, gq[j][NC - 1], d);
+                    } else {
+                        d = (cq[j][0] - ra) * gq[j][0];
+                    }
+                    // inside the sweep (one unsigned comparison) and :647 (a NaN diff goes through)
+                    const bool keep = ((unsigned)(64 * j + lane) - rel0 <= len) && !(d <= 0.0f);
+                    const float dm = keep ? d : 0.0f;
+                    const float t = d1f[j] - cross;
+                    const float y0 = __builtin_fmaf(ac0, fabsf(t), eps_v), y1 = __builtin_fmaf(ac1, fabsf(t), eps_v);  // :649-650 / :654-655
+                    a0 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y0), a0);                     // :651 (sign: the flush)
+                    a1 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y1), a1);                     // :656
+                }
+                // the rows of 16 lanes in float (a tree of depth 4), the four row sums of each in double onto the record's slot
+                a0 += dpp_row_shr_v<1>(a0); a1 += dpp_row_shr_v<1>(a1);
+                a0 += dpp_row_shr_v<2>(a0); a1 += dpp_row_shr_v<2>(a1);
+                a0 += dpp_row_shr_v<4>(a0); a1 += dpp_row_shr_v<4>(a1);
+                a0 += dpp_row_shr_v<8>(a0); a1 += dpp_row_shr_v<8>(a1);
+                if ((lane & 15) == 15) {
+                    // (lane_zero: an address the compiler cannot prove uniform -- for a uniform one its atomic optimizer replaces
+                    // the four-lane ds_add_f64 by a readlane loop of double additions, ~50 instructions per record)
+                    atomicAdd(&acc[2 * r + lane_zero], (double)a0);
+                    atomicAdd(&acc[2 * r + 1 + lane_zero], (double)a1);
+                }
+            }
+            wave_lds_handover();
+            // ---- flush: in sweep + out sweep of each record -> global double scratch [list position][vertex][x|y].
+            // Out sweep: grad -= diff / (sigma * |dist|), sigma = sign(c) * sign(t), sign(t) = the direction (t = d1 - d1_cross
+            // keeps its sign beyond the crossing point): the magnitudes were summed, the sign goes on here.  :648 / :653 (and
+            // :718 / :723): a contribution whose vertex sits on the line is not taken (its coefficient was Inf / NaN).
+            if (lane < nw) {
+                const double2 a = reinterpret_cast<const double2 *>(acc)[lane];
+                const bool tneg = !(flags & 8);
+                const bool neg0 = ((__float_as_uint(qq.y) >> 31) != 0) != tneg, neg1 = ((__float_as_uint(qq.z) >> 31) != 0) != tneg;
+                const double t0 = (flags & 2) ? in0 + (neg0 ? a.x : -a.x) : 0.0;
+                const double t1 = (flags & 4) ? in1 + (neg1 ? a.y : -a.y) : 0.0;
+                const int tgt = hh.w, pos = tgt & 0x0fffffff;
+                double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
+                if (t0 != 0.0) atomicAdd(dst + 2 * ((tgt >> 28) & 3), t0);
+                if (t1 != 0.0) atomicAdd(dst + 2 * ((tgt >> 30) & 3), t1);
+            }
+            wave_lds_handover();
+        }
     }
 }
 
@@ -1470,7 +1766,7 @@ struct LdsLimit {
     }
 };
 
-template <bool RGB, bool ALPHA, int MODE, int NT>
+template <bool RGB, bool ALPHA, int MODE, int NT, bool OVF = false>
 int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb,
                 const float *g_alpha, const int *vis_list, const int *vis_count, const unsigned *rng, double *scratch,
                 const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap,
@@ -1478,13 +1774,45 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
                 void *zero_ptr, size_t zero_bytes)
 {
     static LdsLimit limit;  // one per instantiation
-    auto kern = k_bpm_fast<RGB, ALPHA, MODE, NT>;
+    constexpr int overflow_only = OVF ? 1 : 0;
+    auto kern = k_bpm_fast<RGB, ALPHA, MODE, NT, OVF>;
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     // 1-D grid: the kernel maps ids to (image, axis, band) per XCD
-    hipLaunchKernelGGL(kern, dim3(xcd_grid(total_wg)), dim3(NT), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
+    const unsigned grid = overflow_only ? (total_wg < 256u ? total_wg : 256u) : xcd_grid(total_wg);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
                        eps, k2s, B, win_lines, qcap, (uint4 *)zero_ptr, zero_bytes / 16);
+    return 0;
+}
+
+// k_bpm_px's band: the widest power of two of lines (<= one per wave) whose pixels fit the LDS budget beside the waves'
+// windows; 0: the raster is too large for it (k_bpm_fast takes the launch)
+int px_band_config(int S, bool rgb, int B, size_t *lds_bytes)
+{
+    const size_t nc = rgb ? 4 : 1;
+    for (int W = pxk::NW; W >= 1; W >>= 1) {
+        // (small launches: narrower bands until there are k6::PX_MIN_WGS band workgroups; the waves of a workgroup then share
+        // the records of a line)
+        if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::PX_MIN_WGS) continue;
+        const size_t bytes = align_up((size_t)W * S * 4, 16) + 2 * align_up((size_t)W * S * nc * 4, 16) + (size_t)pxk::NW * pxk::WIN * 16;
+        if (bytes <= pxk::LDS_BUDGET) {
+            *lds_bytes = bytes;
+            return W;
+        }
+    }
+    return 0;
+}
+
+template <bool RGB, bool ALPHA>
+int launch_px(const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb, const float *g_alpha, double *scratch,
+              const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap, int B,
+              int F, int S, int W, size_t lds, double eps, hipStream_t st, void *zero_ptr, size_t zero_bytes)
+{
+    const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
+    hipLaunchKernelGGL((k_bpm_px<RGB, ALPHA>), dim3(xcd_grid(total_wg)), dim3(pxk::NT), lds, st, fi, rgb, alpha, g_rgb, g_alpha,
+                       scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, B, (uint4 *)zero_ptr,
+                       zero_bytes / 16);
     return 0;
 }
 
@@ -1561,8 +1889,19 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const BandShape shape = band_shape(S);
     int w_max = shape.w_max;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
-    const int W = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
-    if (W == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
+    const int W_fast = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
+    // The lane-parallel band kernel (k_bpm_px) takes the default arithmetic mode on line records; k_bpm_fast keeps the exact
+    // mode, the scan path, rasters beyond k_bpm_px's LDS band and NR_FLAG_K6_LEGACY (a testing / measuring aid).  With
+    // k_bpm_px the band tables and the line records are binned per LINE (band width 1).
+    size_t px_lds = 0;
+    // (eps must be positive as a float: a lane outside a sweep multiplies 0 by 1 / (|c t| + eps), and t = 0 -- the crossing
+    // point on a pixel centre -- would make that 0 * Inf)
+    const int W_px = (exact || (flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY)) || B > 65535 || S > 3072 || W_fast == 0 ||
+                      !((float)eps >= 1e-30f))
+                         ? 0 : px_band_config(S, rgb, B, &px_lds);
+    const bool use_px = W_px > 0;
+    const int W = use_px ? 1 : W_fast;  // the band width of the tables
+    if (W_fast == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
         const dim3 grid((unsigned)n), block(WAVE);
         if (rgb && alpha)
             hipLaunchKernelGGL((k_bpm_global<true, true>), grid, block, 0, st, faces, face_index_map, rgb_map,
@@ -1650,15 +1989,25 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         // (a fill that rides in the band kernel: 16-byte words, and a slice per workgroup that is small next to the
         // workgroup's own work -- k6::FOLD_KB per band workgroup: 4 KB at the headline size, 61 KB on config 4; config 5's
         // 4 GB would be 2 MB for each of 2048 workgroups and go at 7 TB/s through a fill launch instead)
-        const size_t band_wgs = (size_t)((S + W - 1) / W) * 2 * (size_t)B;
+        const int W_band = use_px ? W_px : W_fast;  // lines per band workgroup of the kernel that carries the fill
+        const size_t band_wgs = (size_t)((S + W_band - 1) / W_band) * 2 * (size_t)B;
         // (per workgroup: a 256-thread workgroup takes half of what a 512-thread one does)
         const bool zero_ok = !hook && zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
-                             zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10) * (size_t)shape.threads / 512;
+                             zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10) * (size_t)(use_px ? pxk::NT : shape.threads) / 512;
         const int mode = !exact ? K6_FAST : ((S & (S - 1)) == 0 ? K6_EXACT_POW2 : K6_EXACT);
         auto launch = [&](auto r, auto a, auto m, auto nt) {
-            return launch_fast<decltype(r)::value, decltype(a)::value, decltype(m)::value, decltype(nt)::value>(
+            constexpr bool R = decltype(r)::value, A = decltype(a)::value;
+            constexpr int M = decltype(m)::value, NTH = decltype(nt)::value;
+            if constexpr (M == K6_FAST) {
+                // (behind k_bpm_px: only the images whose records exceed the line buffer, by the scan path, no fill)
+                if (use_px)
+                    return launch_fast<R, A, M, NTH, true>(
+                        faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
+                        band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W_fast, lds, eps, k2s, win_lines, qcap, st, nullptr, 0);
+            }
+            return launch_fast<R, A, M, NTH>(
                 faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
-                band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W, lds, eps, k2s, win_lines, qcap, st,
+                band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W_fast, lds, eps, k2s, win_lines, qcap, st,
                 zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
         };
         using T = std::true_type;
@@ -1673,8 +2022,18 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
             return by_threads(r, a, std::integral_constant<int, K6_EXACT>());
         };
         if (g_band_timer.on) g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess;
-        rc = (rgb && alpha) ? by_mode(T(), T()) : (rgb ? by_mode(T(), N()) : by_mode(N(), T()));
-        if (g_band_timer.on && g_band_timer.recorded) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess;
+        rc = 0;
+        if (use_px) {
+            auto lp = [&](auto r, auto a) {
+                return launch_px<decltype(r)::value, decltype(a)::value>(
+                    face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, scratch, band_lines, band_start, lines_ok,
+                    line_buf, L.cap, B, F, S, W_px, px_lds, eps, st, zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
+            };
+            rc = (rgb && alpha) ? lp(T(), T()) : (rgb ? lp(T(), N()) : lp(N(), T()));
+        }
+        if (g_band_timer.on && g_band_timer.recorded && use_px) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess;
+        if (rc == 0) rc = (rgb && alpha) ? by_mode(T(), T()) : (rgb ? by_mode(T(), N()) : by_mode(N(), T()));
+        if (g_band_timer.on && g_band_timer.recorded && !use_px) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess;
         if (rc == 0 && zero_ok && zeroed) *zeroed = 1;
     }
     if (rc) return rc;

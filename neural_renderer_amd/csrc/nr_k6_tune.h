@@ -39,6 +39,10 @@
 #define NR_K6_LDS_BUDGET (53 * 1024)
 #endif
 
+#ifndef NR_PX_MIN_WGS       // k_bpm_px: bands are narrowed (4 -> 2 -> 1 lines) while the launch has fewer band workgroups than this
+#define NR_PX_MIN_WGS 8192
+#endif
+
 #ifndef NR_SHARED_LAUNCH_MAX_FACES  // fused backward: calls of up to this many faces (batch x faces) put the line setup and the
 #define NR_SHARED_LAUNCH_MAX_FACES 98304  // K7 / K8 gather into one launch (nr_backward_rasterize_lit; measured: LAB-NOTEBOOK, late round 4)
 #endif
@@ -56,6 +60,7 @@ constexpr int MINWAVES_256 = NR_K6_MINWAVES_256;
 constexpr int WMAX = NR_K6_WMAX;
 constexpr int FOLD_KB = NR_K6_FOLD_KB;
 constexpr unsigned long LDS_BUDGET = NR_K6_LDS_BUDGET;
+constexpr unsigned long PX_MIN_WGS = NR_PX_MIN_WGS;
 constexpr unsigned long SHARED_LAUNCH_MAX_FACES = NR_SHARED_LAUNCH_MAX_FACES;
 }  // namespace k6
 }  // namespace nr

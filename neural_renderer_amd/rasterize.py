@@ -44,6 +44,8 @@ EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
 # (measuring aid, read once: NR_SERIAL_BACKWARD=1 makes the fused backward launch K6's line setup, its band kernel and the gather one
 # after the other instead of the first and the last in one grid -- include/nr_hip.h NR_FLAG_SERIAL_BACKWARD; same values)
 _BACKWARD_ORDER_FLAG = _lib.NR_FLAG_SERIAL_BACKWARD if int(os.environ.get('NR_SERIAL_BACKWARD', '0')) else 0
+# (measuring aid, read once: NR_K6_LEGACY=1 keeps K6's default mode on the piece-per-lane band kernel -- NR_FLAG_K6_LEGACY)
+_BACKWARD_ORDER_FLAG |= _lib.NR_FLAG_K6_LEGACY if int(os.environ.get('NR_K6_LEGACY', '0')) else 0
 
 
 _RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)

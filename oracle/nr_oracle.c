@@ -208,6 +208,120 @@ API void oracle_forward_face_index_map(const float *faces, const float *faces_in
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * K3: rasterize.py:102-236 -- the "unsafe" visibility kernel (USE_UNSAFE_IMPLEMENTATION, use_unsafe_rasterizer()): one
+ * thread per face scan-converts its triangle column by column and updates the maps under a per-pixel spin lock.
+ * This is the race-free SEQUENTIAL emulation: faces of an image in ascending order, each pixel update atomic.  Any
+ * serialisation of the lock is a valid execution of the reference; this one resolves depth ties to the lowest face
+ * index (the strict `<` of :206), like the safe path (on the GPU the lock order decides).
+ * What differs from K1+K2 by construction: vertices are permuted by x (pi[], :123-131) before face_inv is formed
+ * (:147-155) and weights / face_inv are written back through the permutation (:210, :213-214); coverage comes from the
+ * column / row spans of edge interpolation (:158-181) instead of the three edge functions (:310-312); a face whose
+ * leftmost and rightmost vertex share x is dropped (:144).  No test of the reference covers it ("parity unpinned" in the
+ * reference; pinned here against the safe path by tests/test_oracle_golden.py with SURVEY Appendix B's bounds).
+ * Outputs pre-initialised by the caller like forward_gpu does (:478-496); face_inv_map may be NULL when !return_depth.
+ */
+API void oracle_forward_face_index_map_unsafe(const float *faces, int32_t *face_index_map, float *weight_map,
+                                              float *depth_map, float *face_inv_map, int batch_size, int num_faces,
+                                              int image_size, double near, double far, int return_depth)
+{
+    const int is = image_size;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(NTHREADS)
+    for (int bn = 0; bn < batch_size; bn++) {
+        for (int fn = 0; fn < num_faces; fn++) {
+            const float *face = faces + ((long)bn * num_faces + fn) * 9; /* :117 */
+            if (is_backside(face)) continue;                              /* :120 */
+
+            /* :123-131 pi[0], pi[1], pi[2] = leftmost, middle, rightmost points */
+            int pi[3];
+            if (face[0] < face[3]) {
+                if (face[6] < face[0]) pi[0] = 2; else pi[0] = 0;
+                if (face[3] < face[6]) pi[2] = 2; else pi[2] = 1;
+            } else {
+                if (face[6] < face[3]) pi[0] = 2; else pi[0] = 1;
+                if (face[0] < face[6]) pi[2] = 2; else pi[2] = 0;
+            }
+            pi[1] = 0; /* (:131 leaves it unset when pi[0] == pi[2], which the branches above never produce) */
+            for (int k = 0; k < 3; k++)
+                if (pi[0] != k && pi[2] != k) pi[1] = k;
+
+            /* :134-143 */
+            float p[3][3];
+            for (int num = 0; num < 3; num++)
+                for (int dim = 0; dim < 3; dim++) {
+                    if (dim != 2)
+                        p[num][dim] = (float)(0.5 * (double)(face[3 * pi[num] + dim] * (float)is + (float)is - 1.0f));
+                    else
+                        p[num][dim] = face[3 * pi[num] + dim];
+                }
+            if (p[0][0] == p[2][0]) continue; /* :144 line, not triangle */
+
+            /* :147-155 */
+            float face_inv[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                                 p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                                 p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+            const float face_inv_denominator =
+                (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]));
+            for (int k = 0; k < 9; k++) face_inv[k] /= face_inv_denominator;
+
+            /* :158-160 from left to right */
+            const int xi_min = f2i(fmax((double)ceilf(p[0][0]), 0.));
+            const int xi_max = f2i(fmin((double)p[2][0], is - 1.));
+            for (int xi = xi_min; xi <= xi_max; xi++) {
+                /* :162-176 */
+                float yi1, yi2;
+                if ((float)xi <= p[1][0]) {
+                    if (p[1][0] - p[0][0] != 0)
+                        yi1 = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * ((float)xi - p[0][0]) + p[0][1];
+                    else
+                        yi1 = p[1][1];
+                } else {
+                    if (p[2][0] - p[1][0] != 0)
+                        yi1 = (p[2][1] - p[1][1]) / (p[2][0] - p[1][0]) * ((float)xi - p[1][0]) + p[1][1];
+                    else
+                        yi1 = p[1][1];
+                }
+                yi2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * ((float)xi - p[0][0]) + p[0][1];
+
+                /* :179-181 from up to bottom */
+                const int yi_min = f2i(fmax(0., (double)ceilf(fminf(yi1, yi2))));
+                const int yi_max = f2i(fmin((double)fmaxf(yi1, yi2), is - 1.));
+                for (int yi = yi_min; yi <= yi_max; yi++) {
+                    const long index = (long)bn * is * is + (long)yi * is + xi; /* :183 */
+
+                    /* :186-188 */
+                    float w[3];
+                    for (int k = 0; k < 3; k++)
+                        w[k] = face_inv[3 * k + 0] * (float)xi + face_inv[3 * k + 1] * (float)yi + face_inv[3 * k + 2];
+
+                    /* :191-196 */
+                    float w_sum = 0;
+                    for (int k = 0; k < 3; k++) {
+                        w[k] = (float)fmin(fmax((double)w[k], 0.), 1.);
+                        w_sum += w[k];
+                    }
+                    for (int k = 0; k < 3; k++) w[k] /= w_sum;
+
+                    /* :199-200 */
+                    const float zp = (float)(1. / (double)(w[0] / p[0][2] + w[1] / p[1][2] + w[2] / p[2][2]));
+                    if ((double)zp <= near || far <= (double)zp) continue;
+
+                    /* :203-223, the lock taken at once */
+                    if (zp < depth_map[index]) {
+                        depth_map[index] = zp;
+                        face_index_map[index] = fn;
+                        for (int k = 0; k < 3; k++) weight_map[3 * index + pi[k]] = w[k]; /* :210 */
+                        if (return_depth)
+                            for (int k = 0; k < 3; k++)
+                                for (int l = 0; l < 3; l++)
+                                    face_inv_map[9 * index + 3 * pi[l] + k] = face_inv[3 * l + k]; /* :213-214 */
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * K2, cache-blocked evaluation order (same arguments, same results bit for bit as oracle_forward_face_index_map;
  * tests/test_oracle_threads.py asserts that).  The literal loop streams all faces once per pixel, which for a
  * 655 360-face mesh is 23.6 MB per pixel; here a thread takes PB consecutive pixels of a row and scans the faces once
@@ -640,4 +754,4 @@ API void oracle_backward_depth_map(const float *faces, const float *depth_map, c
     }
 }
 
-API int oracle_version(void) { return 3; }
+API int oracle_version(void) { return 4; }

@@ -50,7 +50,7 @@ def lib():
     if _lib is None:
         build()
         _lib = ctypes.CDLL(_LIB)
-        if _lib.oracle_version() < 3:  # a stale prebuilt library
+        if _lib.oracle_version() < 4:  # a stale prebuilt library
             build(force=True)
             _lib = ctypes.CDLL(_LIB)
         env = os.environ.get('NR_ORACLE_THREADS')
@@ -117,6 +117,9 @@ class Rasterize(object):
         self.fix_batch_z = bool(fix_batch_z)
         self.visits = None
         self.blocked = None  # None: by size; True / False: force the cache-blocked / literal K2 loop order
+        # True: visibility by the reference's "unsafe" kernel K3 (rasterize.py:102-236, USE_UNSAFE_IMPLEMENTATION) in its race-free
+        # sequential emulation instead of K1 + K2 (nr_oracle.c: oracle_forward_face_index_map_unsafe)
+        self.unsafe = False
 
     def __call__(self, faces, textures=None):
         L = lib()
@@ -142,15 +145,21 @@ class Rasterize(object):
         self.alpha_map = np.zeros((bs, s, s), np.float32) if self.return_alpha else None
         self.face_inv_map = np.zeros((bs, s, s, 3, 3), np.float32) if self.return_depth else None
 
-        # :499 forward_face_index_map_gpu (safe path: K1 then K2)
+        # :499 forward_face_index_map_gpu (safe path: K1 then K2; `unsafe`: K3, :102-236)
         self.faces_inv = np.zeros_like(self.faces)
-        L.oracle_forward_face_inv(_p(self.faces, _f32p), _p(self.faces_inv, _f32p), bs, nf, s)
-        blocked = self.blocked if self.blocked is not None else bs * s * s * nf >= BLOCKED_K2_THRESHOLD
-        k2 = L.oracle_forward_face_index_map_blocked if blocked else L.oracle_forward_face_index_map
-        k2(
-            _p(self.faces, _f32p), _p(self.faces_inv, _f32p), _p(self.face_index_map, _i32p),
-            _p(self.weight_map, _f32p), _p(self.depth_map, _f32p), _p(self.face_inv_map, _f32p),
-            bs, nf, s, ctypes.c_double(self.near), ctypes.c_double(self.far), int(self.return_depth))
+        if self.unsafe:
+            L.oracle_forward_face_index_map_unsafe(
+                _p(self.faces, _f32p), _p(self.face_index_map, _i32p), _p(self.weight_map, _f32p), _p(self.depth_map, _f32p),
+                _p(self.face_inv_map, _f32p), bs, nf, s, ctypes.c_double(self.near), ctypes.c_double(self.far),
+                int(self.return_depth))
+        else:
+            L.oracle_forward_face_inv(_p(self.faces, _f32p), _p(self.faces_inv, _f32p), bs, nf, s)
+            blocked = self.blocked if self.blocked is not None else bs * s * s * nf >= BLOCKED_K2_THRESHOLD
+            k2 = L.oracle_forward_face_index_map_blocked if blocked else L.oracle_forward_face_index_map
+            k2(
+                _p(self.faces, _f32p), _p(self.faces_inv, _f32p), _p(self.face_index_map, _i32p),
+                _p(self.weight_map, _f32p), _p(self.depth_map, _f32p), _p(self.face_inv_map, _f32p),
+                bs, nf, s, ctypes.c_double(self.near), ctypes.c_double(self.far), int(self.return_depth))
         # :500 forward_texture_sampling
         if self.return_rgb:
             L.oracle_forward_texture_sampling(

@@ -119,15 +119,16 @@ def main():
         ga = abi.dev(g_alpha, torch.float32) if alpha else None
         for tag in variants:
             lib = use_library(tag)
-            for flags in (0, 2):
-                if flags and tag:
+            # K6_FLAGS: the flag words to run (0 default kernel, 2 NR_FLAG_EXACT_GRADIENT, 128 NR_FLAG_K6_LEGACY, 8 NR_FLAG_K6_SCAN)
+            for flags in [int(x) for x in os.environ.get('K6_FLAGS', '0 2').split()]:
+                if (flags & 2) and tag:
                     continue  # the knobs do not touch the exact mode
                 gf, us = k6_stage(lib, fw, gr, ga, flags, iters)
                 ok = np.abs(ref) > 0
                 err = np.abs(gf.astype(np.float64) - ref)
                 print(json.dumps({
                     'scene': name, 'B': int(faces.shape[0]), 'F': int(faces.shape[1]), 'S': S, 'variant': tag or 'product',
-                    'mode': 'exact' if flags else 'default', 'eps': eps, 'stage_us': us,
+                    'mode': 'exact' if flags & 2 else 'default', 'flags': flags, 'eps': eps, 'stage_us': us,
                     'err_floor_metric': H.rel_err(gf, ref), 'max_abs_err': float(err.max()), 'max_abs': float(np.abs(ref).max()),
                     'frac_within_1e-4_elementwise': float(np.mean(err[ok] <= 1e-4 * np.abs(ref[ok]))),
                     'frac_within_1e-5_elementwise': float(np.mean(err[ok] <= 1e-5 * np.abs(ref[ok]))),

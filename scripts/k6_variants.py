@@ -34,14 +34,15 @@ for shape in os.environ.get('SHAPES', '8x256 16x256 32x256 64x256').split():
         gt = torch.empty_like(textures)
         wsb = lib.nr_backward_workspace_bytes(B, F, S, 1, 1)
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        kfl = int(os.environ.get('K6V_FLAGS', 0))  # e.g. 128: NR_FLAG_K6_LEGACY
         calls = {
             'k6': lambda: lib.nr_backward_pixel_map(faces.data_ptr(), r.face_index_map.data_ptr(), r.rgb_map.data_ptr(),
                                                     r.alpha_map.data_ptr(), g_rgb.data_ptr(), g_alpha.data_ptr(), gf.data_ptr(), B, F,
-                                                    S, 1e-3, 1, 1, 0, r.visible.data_ptr(), ws.data_ptr(), wsb, st),
+                                                    S, 1e-3, 1, 1, kfl, r.visible.data_ptr(), ws.data_ptr(), wsb, st),
             'bwd': lambda: lib.nr_backward_rasterize(faces.data_ptr(), None, r.face_index_map.data_ptr(), r.weight_map.data_ptr(),
                                                      r.depth_map.data_ptr(), r.rgb_map.data_ptr(), r.alpha_map.data_ptr(),
                                                      g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(),
-                                                     gt.data_ptr(), B, F, S, ts, 1e-3, 0, r.visible.data_ptr(), ws.data_ptr(), wsb, st)}
+                                                     gt.data_ptr(), B, F, S, ts, 1e-3, kfl, r.visible.data_ptr(), ws.data_ptr(), wsb, st)}
         for name, call in calls.items():
             for _ in range(3):
                 _lib.check(call(), name)

@@ -28,6 +28,7 @@ EXACT = 2  # _lib.NR_FLAG_EXACT_GRADIENT
 K6_GLOBAL = 4  # _lib.NR_FLAG_K6_GLOBAL
 K6_SCAN = 8    # _lib.NR_FLAG_K6_SCAN
 SERIAL = 64    # _lib.NR_FLAG_SERIAL_BACKWARD
+K6_LEGACY = 128  # _lib.NR_FLAG_K6_LEGACY: the default mode on the piece-per-lane band kernel (k_bpm_fast) instead of k_bpm_px
 
 
 def report(test, **values):
@@ -284,6 +285,17 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
             gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                   use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
             assert H.rel_err(abi.host(gf3), gf) <= SAME_TERMS
+            # ... and the two band kernels of the default mode against each other (flags 0: the lane-parallel k_bpm_px where its
+            # band fits; NR_FLAG_K6_LEGACY: k_bpm_fast on line records) -- and the legacy kernel against the oracle as well
+            if not (flags & (EXACT | K6_GLOBAL | K6_SCAN | K6_LEGACY)):
+                gf4, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
+                                      use_face_inv_map=residual_maps, k6_flags=flags | K6_LEGACY)
+                gf4 = abi.host(gf4)
+                err_l = H.rel_err(gf4, ref_d)
+                report('check_backward_legacy_kernel', S=S, modes=list(modes), flags=flags | K6_LEGACY, err_vs_double_sum=err_l,
+                       px_vs_legacy=H.rel_err(gf4, gf))
+                assert err_l <= bound, 'grad_faces (k_bpm_fast) vs double-summed oracle: %g' % err_l
+                assert H.rel_err(gf4, gf) <= SAME_TERMS
     if rgb:
         gt = abi.host(gt)
         assert not np.isnan(gt).any(), 'grad_textures has unwritten elements'
@@ -520,6 +532,38 @@ def test_global_memory_k6_fallback():
     ref_d, _ = fn.backward(g_rgb, g_alpha, None, accumulate_double=True)
     gf, _ = abi.backward(fw, g_rgb, g_alpha, None, k6_flags=K6_GLOBAL)
     assert H.rel_err(abi.host(gf), ref_d) <= K6_BOUND_EXACT
+
+
+@pytest.mark.parametrize('S', [64, 256])
+def test_unsafe_rasterizer_against_the_k3_oracle(S):
+    """SURVEY 8 row a3': with `use_unsafe_rasterizer(True)` the reference runs K3 (rasterize.py:102-236: per-face scan
+    conversion, x-sorted face_inv, spin-lock z-buffer).  The one rasterizer of this library serves that switch too; against
+    the oracle's restatement of K3 (sequential emulation, pinned by tests/test_oracle_golden.py) on the teapot under the
+    default camera it must give the same face indices and coverage, depth within 2.6e-6 and weights within 1e-4 -- the
+    differences SURVEY Appendix B measured between the reference's two kernels (K3 builds face_inv from the x-sorted vertices)."""
+    import neural_renderer_amd as nr
+    v, f = H.teapot()
+    faces = O.Renderer().project(v[None], f[None])
+    k3 = O.Rasterize(S, 0.1, 100, 1e-4, None, False, True, True)
+    k3.unsafe = True
+    _, ref_alpha, ref_depth = k3(faces)
+    try:
+        nr.use_unsafe_rasterizer(True)
+        fn = nr.Rasterize(S, 0.1, 100, 1e-4, (0, 0, 0), False, True, True)
+        _, alpha, depth = fn(torch.tensor(faces, device='cuda'))
+        fi = fn.face_index_map.cpu().numpy()
+        wm = fn.weight_map.cpu().numpy()
+        fim = fn.face_inv_map.cpu().numpy()
+    finally:
+        nr.use_unsafe_rasterizer(False)
+    assert int((fi != k3.face_index_map).sum()) == 0
+    np.testing.assert_array_equal(alpha.cpu().numpy(), ref_alpha)
+    d_err = float(np.abs(depth.cpu().numpy() - ref_depth).max())
+    w_err = float(np.abs(wm - k3.weight_map).max())
+    report('unsafe_vs_k3_oracle', S=S, depth_abs=d_err, weight_abs=w_err)
+    assert d_err <= 2.7e-6
+    assert w_err <= 1.1e-4
+    assert float(np.abs(fim - k3.face_inv_map).max()) <= 1e-5 * float(np.abs(k3.face_inv_map).max())
 
 
 def test_unsafe_rasterizer_flag_is_equivalent(monkeypatch):

@@ -35,6 +35,30 @@ def test_silhouette_matches_blender(teapot_batch):
     assert int(img.sum()) == 7580
 
 
+@pytest.mark.parametrize('S', [64, 256])
+def test_unsafe_kernel_restatement_against_the_safe_path_and_the_blender_silhouette(teapot_batch, S):
+    """SURVEY 8 row a3' / Appendix B: the reference's "unsafe" visibility kernel K3 (rasterize.py:102-236) has no test of its
+    own.  Its sequential emulation (nr_oracle.c: oracle_forward_face_index_map_unsafe) is pinned here the way the survey's
+    throw-away restatement was: on the teapot under the default camera it draws exactly the pixels of the safe path (at 256^2:
+    of the Blender render the reference ships), picks the same faces, and differs in depth / weights only through its
+    x-sorted face_inv -- <= 1.2e-6 / 2.3e-5 at 64^2 and <= 2.6e-6 / 1.0e-4 at 256^2 in the survey."""
+    v, f = teapot_batch
+    faces = O.Renderer().project(v, f)
+    safe = O.Rasterize(S, 0.1, 100, 1e-4, None, False, True, True)
+    safe(faces)
+    k3 = O.Rasterize(S, 0.1, 100, 1e-4, None, False, True, True)
+    k3.unsafe = True
+    k3(faces)
+    assert int(((safe.face_index_map >= 0) != (k3.face_index_map >= 0)).sum()) == 0
+    assert int((safe.face_index_map != k3.face_index_map).sum()) == 0
+    assert float(np.abs(safe.depth_map - k3.depth_map).max()) <= (1.3e-6 if S == 64 else 2.7e-6)
+    assert float(np.abs(safe.weight_map - k3.weight_map).max()) <= (2.4e-5 if S == 64 else 1.1e-4)
+    scale = float(np.abs(safe.face_inv_map).max())
+    assert float(np.abs(safe.face_inv_map - k3.face_inv_map).max()) <= 1e-5 * scale  # written back through pi[] (:213-214)
+    if S == 256:
+        assert int((k3.alpha_map[0][::-1] != H.golden()['teapot_blender'].astype(np.float32)).sum()) == 0
+
+
 def test_silhouette_batch_of_four_with_empty_slots():
     # reference tests/utils.py:7-24: payload in slot 2, all-zero (degenerate) geometry in slots 0, 1, 3
     v, f = H.teapot()
