@@ -80,21 +80,73 @@ def build_scene(device, batch, first_view, total_views, image_size, texture_size
     return faces.contiguous(), textures.contiguous()
 
 
-def upstream_gradients(faces, textures, S, eps, seed, all_ones=False, z_ref=None):
+def icosphere(level):
+    """Subdivided icosahedron on the unit sphere: vertices [Nv,3] float32, faces [Nf,3] int32 (20 * 4^level faces)."""
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        mid, nf = {}, []
+
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, np.float32), np.array(f, np.int32)
+
+
+C4_MESHES = 512  # BASELINE.json configs[3]: 512 random meshes of ~5k faces, sharded over the GPUs
+
+
+def build_scene_c4(device, first, count, texture_size=4):
+    """BASELINE.json configs[3] / SURVEY 8d C4, meshes [first, first + count) of the 512: an icosphere of 5 120 faces with
+    seeded per-vertex radial noise around radius 0.55 and a random rotation per mesh, seen from eye (0.3, 0.4, -2.6) through the
+    product's look_at / perspective(30) / vertices_to_faces glue with fill_back (10 240 faces per mesh), texture_size 4 textures
+    ~ U(0, 1).  Mesh m depends on (1234, m) only: every rank builds exactly its shard."""
+    import neural_renderer_amd as nr
+    v0, f0 = icosphere(4)
+    verts, tex = [], []
+    for m in range(first, first + count):
+        rng = np.random.default_rng([1234, m])
+        v = v0 * (0.55 + 0.12 * rng.normal(size=(v0.shape[0], 1))).astype(np.float32)
+        q = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+        verts.append((v @ q).astype(np.float32))
+        tex.append(rng.uniform(0, 1, (2 * f0.shape[0], texture_size, texture_size, texture_size, 3)).astype(np.float32))
+    vertices = torch.from_numpy(np.stack(verts)).to(device)
+    faces_i = torch.from_numpy(f0).to(device)[None].repeat(count, 1, 1)
+    faces_i = torch.cat((faces_i, torch.flip(faces_i, dims=[2])), dim=1)  # fill_back
+    eye = torch.tensor([[0.3, 0.4, -2.6]], dtype=torch.float32, device=device).repeat(count, 1)
+    vertices = nr.perspective(nr.look_at(vertices, eye), 30.)
+    faces = nr.vertices_to_faces(vertices, faces_i)
+    return faces.contiguous(), torch.from_numpy(np.stack(tex)).to(device).contiguous()
+
+
+def upstream_gradients(faces, textures, S, eps, seed, all_ones=False, z_ref=None, modes=(True, True, True)):
     """g = 2 (image - ref) with a seeded uniform reference (dense, both signs); all_ones: the gradient of
     sum(images) as in the reference's misc/measure_time.py:60 (K6's `diff_grad <= 0` branch then skips half the work)."""
     import neural_renderer_amd as nr
     dev = faces.device
     gen = torch.Generator(device='cpu').manual_seed(seed)
     with torch.no_grad():
-        fn = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+        fn = nr.Rasterize(S, 0.1, 100, eps, (0, 0, 0), *modes)
         fn.faces_z_ref = z_ref
-        rgb0, alpha0, depth0 = fn(faces, textures)
+        rgb0, alpha0, depth0 = fn(faces, textures) if modes[0] else fn(faces)
         if all_ones:
-            return torch.ones_like(rgb0), torch.ones_like(alpha0), torch.ones_like(depth0)
-        g_rgb = (2 * (rgb0 - torch.rand(rgb0.shape, generator=gen).to(dev))).contiguous()
-        g_alpha = (2 * (alpha0 - torch.rand(alpha0.shape, generator=gen).to(dev))).contiguous()
-        g_depth = (2 * (depth0 / 100.0 - torch.rand(depth0.shape, generator=gen).to(dev)) / 100.0).contiguous()
+            return tuple(None if o is None else torch.ones_like(o) for o in (rgb0, alpha0, depth0))
+        # (a disabled output has no gradient: None, like the reference's grad_outputs, rasterize.py:858-878)
+        g_rgb = None if rgb0 is None else (2 * (rgb0 - torch.rand(rgb0.shape, generator=gen).to(dev))).contiguous()
+        g_alpha = None if alpha0 is None else (2 * (alpha0 - torch.rand(alpha0.shape, generator=gen).to(dev))).contiguous()
+        g_depth = None if depth0 is None else (2 * (depth0 / 100.0 - torch.rand(depth0.shape, generator=gen).to(dev)) / 100.0).contiguous()
     return g_rgb, g_alpha, g_depth
 
 
@@ -103,6 +155,13 @@ STAGE_KERNEL = {
     'forward_face_index_map': 'k_face_raster', 'forward_texture_sampling': 'k_shade', 'backward_pixel_map': 'k_bpm_fast',
     'backward_textures': 'k_backward_textures_face', 'backward_depth_map': 'k_backward_depth_face',
 }
+
+
+def k6_band_kernel(B, F, S, rgb, alpha, exact):
+    """Which of K6's two band kernels the library launches for a call of this shape in this mode (the rule of
+    run_backward_pixel_map, csrc/nr_backward_pixel_map.hip; thresholds: csrc/nr_k6_tune.h NR_PX_MIN_FACES / NR_PX_DENSE_FACES)."""
+    px = (not exact) and B * F >= 262144 and (S >= 512 or not (rgb and alpha) or F >= 8192) and S <= (1024 if rgb else 3072)
+    return 'k_bpm_px' if px else 'k_bpm_fast'
 
 
 def algorithmic_bytes(B, F, S, ts):
@@ -141,6 +200,12 @@ def whole_step_bytes(B, F, S, ts):
     92 B per pixel; per face 36 (faces, forward) + 36 (faces, backward) + 36 (grad_faces) + 24 ts^3 (textures read,
     grad_textures written)."""
     return 92 * B * S * S + (108 + 24 * ts ** 3) * B * F
+
+
+def whole_step_bytes_rgb(B, F, S, ts):
+    """SURVEY 8d, rgb only (config 4): 76 B per pixel (forward writes rgb 12 + face_index 4 + weight 12 + depth 4, backward reads
+    g_rgb 12 + rgb 12 + the residuals 20) + (108 + 24 ts^3) B per face."""
+    return 76 * B * S * S + (108 + 24 * ts ** 3) * B * F
 
 
 def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flags=0):
@@ -213,23 +278,35 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flag
         e1.record()
         torch.cuda.synchronize(dev)
         out[name] = e0.elapsed_time(e1) * 1e3 / iters  # us
-    # The path's dominant kernel ALONE (K6's band kernel, without the helper launches of its stage call): the library brackets
-    # its launch with a pair of HIP events on the launch stream when asked to (nr_profile_band_kernel, include/nr_hip.h).  Calls
-    # are issued back to back, the last call's pair is read, five samples; once inside the stage call, once inside the fused
-    # backward (where the band workgroups also zero-fill grad_textures).
-    if hasattr(lib, 'nr_profile_band_kernel'):
+    # The path's dominant kernel ALONE (K6's band kernel, without the helper launches of its stage call): the MEASUREMENT build of
+    # the library (libnr_hip_prof.so: the same sources with the timing hook of include/nr_hip_profile.h compiled in) brackets its
+    # launch with a pair of HIP events on the launch stream.  Calls are issued back to back, the last call's pair is read, five
+    # samples; once inside the stage call, once inside the fused backward (where the band workgroups also zero-fill grad_textures).
+    try:
+        plib = _lib.load_profile()
+    except Exception:  # (no measurement build in the tree: the stage call's own duration stands in)
+        plib = None
+    if plib is not None:
+        pcalls = {
+            'backward_pixel_map': lambda: plib.nr_backward_pixel_map(
+                faces.data_ptr(), fi.data_ptr(), rgb.data_ptr(), am.data_ptr(), g_rgb.data_ptr(), g_alpha.data_ptr(),
+                gf.data_ptr(), B, F, S, eps, 1, 1, k6_flags, vis.data_ptr(), bws.data_ptr(), bwsb, st),
+            'fused_backward_rasterize': lambda: plib.nr_backward_rasterize(
+                faces.data_ptr(), None, fi.data_ptr(), wm.data_ptr(), dm.data_ptr(), rgb.data_ptr(), am.data_ptr(),
+                g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(), gt.data_ptr(), B, F, S, ts, eps, k6_flags,
+                vis.data_ptr(), bws.data_ptr(), bwsb, st)}
         for key, name in (('k6_band_kernel_alone', 'backward_pixel_map'), ('k6_band_kernel_alone_in_fused_backward', 'fused_backward_rasterize')):
             samples = []
-            _lib.check(lib.nr_profile_band_kernel(1), 'profile hook')
+            _lib.check(plib.nr_profile_band_kernel(1), 'profile hook')
             try:
                 for _ in range(5):
                     for _ in range(max(iters, 3)):
-                        calls[name]()
-                    ms = lib.nr_profile_band_kernel_ms()
+                        pcalls[name]()
+                    ms = plib.nr_profile_band_kernel_ms()
                     if ms >= 0:
                         samples.append(ms * 1e3)
             finally:
-                lib.nr_profile_band_kernel(0)
+                plib.nr_profile_band_kernel(0)
             if samples:
                 out[key] = sum(samples) / len(samples)
     return out
@@ -469,7 +546,7 @@ def host_floor(device, steps=300):
     return out
 
 
-def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views, light=False):
+def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views, light=False, modes=(True, True, True), what='teapot views'):
     """The C oracle on this host: one thread on `sample_views` views (the contract's `value`, kind "port"), all cores on
     the whole batch, and the naive NumPy per-pixel loop on BASELINE configs[0]."""
     from oracle import oracle as O
@@ -478,13 +555,13 @@ def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views,
     def run(n_views, threads, blocked):
         f = faces[:n_views].cpu().numpy()
         t = textures[:n_views].cpu().numpy()
-        gr, ga, gd = (x[:n_views].cpu().numpy() for x in (g_rgb, g_alpha, g_depth))
+        gr, ga, gd = (None if x is None else x[:n_views].cpu().numpy() for x in (g_rgb, g_alpha, g_depth))
         O.set_threads(threads)
         try:
             t0 = time.perf_counter()
-            fn = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+            fn = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), *modes)
             fn.blocked = blocked
-            fn(f, t)
+            fn(f, t) if modes[0] else fn(f)
             t1 = time.perf_counter()
             fn.backward(gr, ga, gd)
             t2 = time.perf_counter()
@@ -495,11 +572,11 @@ def cpu_baseline(faces, textures, S, eps, g_rgb, g_alpha, g_depth, sample_views,
     v1, f1, b1 = run(sample_views, 1, False)
     out = {
         'value': v1, 'unit': 'Mpixel/s', 'cores': 1, 'kind': 'port',
-        'sample': '%d of the %d teapot views, %dx%d, rgb+alpha+depth fwd+bwd, oracle/nr_oracle.c (gcc -O2, literal loop '
-                  'order), fwd %.2f s bwd %.2f s' % (sample_views, faces.shape[0], S, S, f1, b1),
+        'sample': '%d of the %d %s, %dx%d, %s fwd+bwd, oracle/nr_oracle.c (gcc -O2, literal loop '
+                  'order), fwd %.2f s bwd %.2f s' % (sample_views, faces.shape[0], what, S, S, '+'.join(n for n, m in zip(('rgb', 'alpha', 'depth'), modes) if m), f1, b1),
         'host_cpus': os.cpu_count(),
     }
-    n_all = int(faces.shape[0])
+    n_all = min(int(faces.shape[0]), 64)
     va, fa, ba = run(n_all, 0, True)
     out['all_cores'] = {
         'value': va, 'unit': 'Mpixel/s', 'cores': O.get_threads(), 'kind': 'port',
@@ -533,16 +610,16 @@ def build_scene_cpu_view(S):
     return O.vertices_to_faces(vv, f[None]).astype(np.float32)
 
 
-def grad_check(nr_fn_fi, faces, textures, S, eps, g_rgb, g_alpha, g_depth, n_views):
+def grad_check(nr_fn_fi, faces, textures, S, eps, g_rgb, g_alpha, g_depth, n_views, modes=(True, True, True)):
     """Parity of the benchmarked batch: face_index_map mismatches and gradient errors against the oracle (sums of the
     reference's float terms carried in double), `n_views` views."""
     from oracle import oracle as O
     O.build()
-    ref = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), True, True, True)
+    ref = O.Rasterize(S, 0.1, 100, eps, (0, 0, 0), *modes)
     ref.blocked = True
     ref(faces[:n_views].detach().cpu().numpy(), textures[:n_views].detach().cpu().numpy())
-    r_gf, r_gt = ref.backward(g_rgb[:n_views].cpu().numpy(), g_alpha[:n_views].cpu().numpy(),
-                              g_depth[:n_views].cpu().numpy(), accumulate_double=True)
+    r_gf, r_gt = ref.backward(*(None if g is None else g[:n_views].cpu().numpy() for g in (g_rgb, g_alpha, g_depth)),
+                              accumulate_double=True)
     gf, gt = faces.grad[:n_views].cpu().numpy(), textures.grad[:n_views].cpu().numpy()
     fi = nr_fn_fi[:n_views].cpu().numpy()
 
@@ -600,7 +677,17 @@ def main():
     ap.add_argument('--no-shard-rows', action='store_true', help='skip the 32 / 16 / 8-view rows of a 1-GPU run')
     ap.add_argument('--light', action='store_true', help='headline step + stage timings only (no extra rows, no Renderer '
                                                          'end-to-end, oracle check on 2 views)')
+    ap.add_argument('--workload', choices=('teapot', 'c4'), default='teapot',
+                    help='teapot: the metric\'s configuration (BASELINE.json configs[1] at batch 64); c4: BASELINE.json configs[3], '
+                         '512 random meshes x 10 240 faces, texture_size 4, 256x256 textured RGB, the meshes split over the GPUs '
+                         '(--gather: the all-gather of the rendered shards the configuration names)')
     args = ap.parse_args()
+    c4 = args.workload == 'c4'
+    if c4:  # (the job is the configuration's 512 meshes, 4 x 4 x 4 textures, RGB only; the headline's extra rows do not apply)
+        args.batch = C4_MESHES if args.batch == 64 else args.batch
+        args.texture_size = 4 if args.texture_size == 2 else args.texture_size
+        args.light = True
+    modes = (True, False, False) if c4 else (True, True, True)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -637,14 +724,14 @@ def main():
     B = stop - start
     if B < 1:
         raise SystemExit('--batch %d gives rank %d of %d no view' % (G, rank, world))
-    faces, textures = build_scene(dev, B, start, G, S, ts)
+    faces, textures = build_scene_c4(dev, start, B, ts) if c4 else build_scene(dev, B, start, G, S, ts)
     F = faces.shape[1]
     faces.requires_grad_(True)
     textures.requires_grad_(True)
     # textures are sampled with the depths of GLOBAL view 0 -- one 177 KB broadcast before the timed region
     # makes the shards of an N > 1 run the same computation as the unsharded batch (tests/test_sharding_gpu.py)
     z_ref = nrd.broadcast_reference_faces(faces.detach()) if (world > 1 or nrd._force()) else None
-    g_rgb, g_alpha, g_depth = upstream_gradients(faces, textures, S, eps, 1234 + rank, z_ref=z_ref)
+    g_rgb, g_alpha, g_depth = upstream_gradients(faces, textures, S, eps, 1234 + rank, z_ref=z_ref, modes=modes)
 
     gather = args.gather and dist is not None
     last = {}
@@ -653,13 +740,13 @@ def main():
         def step():
             f.grad = None
             t.grad = None
-            fn = nr.Rasterize(size, 0.1, 100, eps, (0, 0, 0), True, True, True)
+            fn = nr.Rasterize(size, 0.1, 100, eps, (0, 0, 0), *modes)
             fn.exact_gradient = args.exact if exact is None else exact
             fn.faces_z_ref = ref
-            rgb, alpha, depth = fn(f, t)
+            outs = fn(f, t)
             if with_gather:  # the downstream loss wants the whole batch: one all-gather of the rendered shards (RCCL / xGMI)
-                last['gathered'] = nrd.all_gather_images(rgb.detach(), total=total)
-            torch.autograd.backward([rgb, alpha, depth], list(grads))
+                last['gathered'] = nrd.all_gather_images(outs[0].detach(), total=total)
+            torch.autograd.backward([o for o in outs if o is not None], [g for g in grads if g is not None])
             last['fi'] = fn.face_index_map
         return step
 
@@ -719,6 +806,12 @@ def main():
             seconds = float(t.item())
         return seconds, ev_ms, n_pre
 
+    # `cold`: the driver's protocol as it stands -- W warm-up steps, K timed steps, no pre-warm -- measured FIRST in the process,
+    # on a device that idled through the set-up (ramping clocks: typically 5-10 % above the pre-warmed figure below)
+    keep_prewarm, args.prewarm_ms = args.prewarm_ms, 0.0
+    cold_elapsed, _, _ = timed(run, local_step if gather else run)
+    args.prewarm_ms = keep_prewarm
+    cold_ms = cold_elapsed / args.steps * 1e3
     elapsed, event_ms_per_step, prewarm_steps = timed(run, local_step if gather else run)
     eager_ms = None
     if mode == 'hipgraph':  # also report the eager number
@@ -731,11 +824,11 @@ def main():
     # The job of rounds 1-3 at N > 1: G views PER GPU (rank r: views [r G, (r + 1) G) of N G azimuths), same protocol.
     weak = None
     if world > 1 or nrd._force():
-        wf, wt = build_scene(dev, G, rank * G, world * G, S, ts)
+        wf, wt = build_scene_c4(dev, rank * G, G, ts) if c4 else build_scene(dev, G, rank * G, world * G, S, ts)
         wf.requires_grad_(True)
         wt.requires_grad_(True)
         wz = nrd.broadcast_reference_faces(wf.detach())
-        wg = upstream_gradients(wf, wt, S, eps, 4242 + rank, z_ref=wz)
+        wg = upstream_gradients(wf, wt, S, eps, 4242 + rank, z_ref=wz, modes=modes)
         w_step = make_step(wf, wt, S, wg, with_gather=gather, ref=wz, total=world * G)
         w_local = make_step(wf, wt, S, wg, ref=wz)
         w_elapsed, _, _ = timed(w_step, w_local)
@@ -750,10 +843,13 @@ def main():
         torch.cuda.synchronize(dev)
         with on_all_cores():
             check = grad_check(last['fi'], faces, textures, S, eps, g_rgb, g_alpha, g_depth,
-                               min(B, 2 if args.light else args.check_views))
+                               min(B, 2 if args.light else args.check_views), modes=modes)
 
         k6_flags = 2 if args.exact else 0
-        stages = time_stages(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth, args.stage_iters, k6_flags)
+        # (the per-stage microbenchmark drives every stage entry point: with all three upstream gradients whatever the step's mode)
+        sg = (g_rgb, g_alpha, g_depth) if all(modes) else upstream_gradients(faces.detach(), textures.detach(), S, eps, 99 + rank, z_ref=z_ref)
+        stages = time_stages(faces.detach(), textures.detach(), S, eps, sg[0], sg[1], sg[2], args.stage_iters, k6_flags)
+        del sg
         stage_bytes = algorithmic_bytes(B, F, S, ts)
         dominant = max(stage_bytes, key=lambda k: stages[k])
         # `achieved`: the dominant stage's algorithmic bytes over the duration of its dominant KERNEL alone, measured live with
@@ -763,16 +859,26 @@ def main():
         launch_us = kernel_us or stages[dominant]
         achieved = stage_bytes[dominant] / (launch_us * 1e-6) / 1e9
         prof = profile_records().get('pmc', {})
-        traffic_rec = prof.get(dominant, {}) if B == 64 else {}  # (the committed counters are launches of 64 views)
-        step_bytes = whole_step_bytes(G, F, S, ts)  # the whole job's compulsory bytes against the whole job's step time
+        # (the committed counters are launches of the headline shape: 64 teapot views at 256 x 256)
+        traffic_rec = prof.get(dominant, {}) if (B == 64 and S == 256 and not c4) else {}
+        # HBM bytes of the dominant KERNEL alone (the scope of `avg_launch_us`) and of the whole stage call (the scope of `stage_call`)
+        kname = STAGE_KERNEL.get(dominant, dominant)
+        if dominant == 'backward_pixel_map':  # (the stage microbenchmark calls K6 with rgb + alpha)
+            kname = k6_band_kernel(B, F, S, True, True, args.exact)
+        krec = {k: v for k, v in traffic_rec.get('kernels', {}).items() if k.startswith(kname)}
+        kernel_traffic = sum(v['fetch'] + v['write'] for v in krec.values()) if krec else None
+        stage_traffic = traffic_rec.get('hbm_bytes_per_launch')
+        step_bytes = (whole_step_bytes_rgb if c4 else whole_step_bytes)(G, F, S, ts)  # the whole job's compulsory bytes against its step time
         roofline = {
-            'bound': 'hbm', 'kernel': STAGE_KERNEL.get(dominant, dominant) + (' (exact mode)' if args.exact and dominant == 'backward_pixel_map' else ''),
+            'bound': 'hbm', 'kernel': kname + (' (exact mode)' if args.exact and dominant == 'backward_pixel_map' else ''),
             'stage': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,
-            'traffic_from_profiles': {
-                'hbm_bytes_per_launch': traffic_rec.get('hbm_bytes_per_launch'), 'source': 'profiles/pmc_latest.json',
-                'note': 'FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_profile_round.sh on the committed build; NOT measured '
-                        'in this run (counters cannot be collected inside a timed run)'},
+            'traffic': kernel_traffic,
+            'traffic_ratio': (kernel_traffic / stage_bytes[dominant]) if kernel_traffic else None,
+            'traffic_scope': 'HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) of the dominant kernel '
+                             'ALONE per launch -- the scope of avg_launch_us; the whole stage call with its helper launches: stage_call.traffic',
+            'traffic_source': {'file': 'profiles/pmc_latest.json',
+                               'note': 'separate --pmc passes of scripts/gpu_profile_round.sh on the committed build (counters cannot be '
+                                       'collected inside a timed run); null when this run is not the profiled shape (64 teapot views, 256 x 256)'},
             'algorithmic_bytes_per_launch': stage_bytes[dominant], 'avg_launch_us': launch_us,
             'timing': ('HIP events recorded by the library on the launch stream right in front of and behind the launch of the '
                        'dominant kernel (nr_profile_band_kernel: K6\'s band kernel inside nr_backward_pixel_map, calls issued back to '
@@ -784,9 +890,12 @@ def main():
             'stage_call': {'what': 'the whole stage call nr_%s, helper launches included (HIP events around the call; '
                                    'profiles/README.md lists the per-kernel rocprofv3 durations it adds up from)' % dominant,
                            'avg_us': stages[dominant], 'achieved': stage_bytes[dominant] / (stages[dominant] * 1e-6) / 1e9,
-                           'frac': stage_bytes[dominant] / (stages[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                           'frac': stage_bytes[dominant] / (stages[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           'traffic': stage_traffic, 'traffic_ratio': (stage_traffic / stage_bytes[dominant]) if stage_traffic else None},
             'whole_step': {
-                'algorithmic_bytes': step_bytes, 'definition': 'SURVEY 8d: 92 B/pixel + (108 + 24 ts^3) B/face for rgb+alpha+depth',
+                'algorithmic_bytes': step_bytes,
+                'definition': 'SURVEY 8d: 76 B/pixel + (108 + 24 ts^3) B/face for rgb only' if c4 else
+                              'SURVEY 8d: 92 B/pixel + (108 + 24 ts^3) B/face for rgb+alpha+depth',
                 'achieved': step_bytes / (ms_per_step * 1e-3) / 1e9,
                 'frac': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
@@ -812,7 +921,7 @@ def main():
                 'ns_per_wave_instr_per_simd': NS_PER_WAVE_INSTR, 'simds': NUM_SIMDS, 'issue_floor_us': floor_us,
                 'stage_us': stages['backward_pixel_map'], 'frac': floor_us / stages['backward_pixel_map'],
                 'source': 'SQ_INSTS_VALU from profiles/pmc_latest.json (' + str(valu.get('source')) + '); stage time measured in this run'}
-        extra_rows, e2e = [], None
+        extra_rows, e2e, exact_row = [], None, None
         if not args.light:
             # anti-aliasing on: raster 2 x image_size (the Renderer default), same views
             faces2 = faces.detach().clone().requires_grad_(True)
@@ -829,6 +938,9 @@ def main():
                                'mpixel_per_s_raster': B * S * S / (ms3 * 1e-3) / 1e6})
             if not args.exact:  # the bit-faithful K6 mode on the headline batch (NR_FLAG_EXACT_GRADIENT)
                 ms5 = time_step(make_step(faces, textures, S, (g_rgb, g_alpha, g_depth), exact=True), dev, args.steps, 2)
+                exact_row = {'ms_per_step': ms5, 'value': G * S * S / (ms5 * 1e-3) / 1e6, 'unit': 'Mpixel/s',
+                             'what': 'the same step with NR_FLAG_EXACT_GRADIENT: K6 with the reference\'s own arithmetic per term, '
+                                     'sums in double (bound 2e-6 against the exactly summed reference terms)'}
                 extra_rows.append({'row': 'headline step with NR_FLAG_EXACT_GRADIENT (K6 with the reference\'s own arithmetic per term)',
                                    'ms_per_step': ms5, 'mpixel_per_s_raster': B * S * S / (ms5 * 1e-3) / 1e6})
             # the same step through the operator's chainer.Function protocol (forward_gpu / backward_gpu: no autograd graph, no
@@ -875,15 +987,21 @@ def main():
             # (N > 1: rank 0's shard, one thread and all cores; the naive-NumPy row only in the 1-GPU run)
             with on_all_cores():
                 cpu = cpu_baseline(faces.detach(), textures.detach(), S, eps, g_rgb, g_alpha, g_depth,
-                                   min(args.cpu_sample_views, B), light=args.light or world > 1)
+                                   min(2 if c4 else args.cpu_sample_views, B), light=args.light or world > 1, modes=modes,
+                                   what='config-4 meshes' if c4 else 'teapot views')
         line = {
-            'metric': 'rasterize fwd+bwd Mpixels/sec @256x256 batch=64', 'value': value, 'unit': 'Mpixel/s',
+            'metric': ('rasterize fwd+bwd Mpixels/sec @256x256, BASELINE configs[3]: 512 meshes x ~5k faces sharded over the GPUs'
+                       if c4 else 'rasterize fwd+bwd Mpixels/sec @256x256 batch=64'), 'value': value, 'unit': 'Mpixel/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'data_note': 'synthetic cameras, textures and upstream gradients; the mesh is the reference\'s teapot.obj (embedded in '
                          'tests/golden/reference_fixtures.npz), as BASELINE.json names it',
             'config': {
-                'workload': 'teapot.obj (2464 faces, fill_back -> %d), %d azimuth views split over %d GPU(s) (%d per GPU), raster '
+                'workload': ('BASELINE.json configs[3] (SURVEY 8d C4): %d seeded random meshes (icosphere of 5 120 faces, radial noise, '
+                             'random rotation; fill_back -> %d faces) split over %d GPU(s) (%d per GPU), raster %dx%d, texture_size %d '
+                             'random textures, RGB forward + backward through the Rasterize autograd operator%s'
+                             % (G, F, world, B, S, S, ts, ', one all_gather of the rendered shards per step' if gather else '')) if c4 else
+                            'teapot.obj (2464 faces, fill_back -> %d), %d azimuth views split over %d GPU(s) (%d per GPU), raster '
                             '%dx%d (anti_aliasing off), texture_size %d, rgb+alpha+depth forward + backward through the '
                             'Rasterize autograd operator' % (F, G, world, B, S, S, ts),
                 'views_total': G, 'views_per_gpu': B, 'image_size': S, 'num_faces': F, 'texture_size': ts, 'eps': eps,
@@ -894,6 +1012,9 @@ def main():
                 'parallelism': 'the batch of views split over %d GPU(s): rank r renders views [r*%d/%d, (r+1)*%d/%d), no collective%s'
                                % (world, G, world, G, world, ' + all_gather(rgb)' if gather else ''),
             },
+            'cold': {'ms_per_step': cold_ms, 'value': total_pixels / (cold_ms * 1e-3) / 1e6, 'unit': 'Mpixel/s',
+                     'what': 'the same K steps behind W warm-up steps WITHOUT the untimed pre-warm, measured first in the process'},
+            'exact': exact_row,
             'weak_scaling': weak, 'shard_rows': shards,
             'roofline': roofline, 'cpu_baseline': cpu, 'stages_us': stages, 'grad_check': check,
             'extra_rows': extra_rows, 'launch_mode': mode, 'eager_ms_per_step': eager_ms, 'renderer_end_to_end': e2e,

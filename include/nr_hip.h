@@ -56,7 +56,9 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 401 /* 0.4.1: NR_FLAG_SERIAL_BACKWARD (the fused backward's gather shares a launch with K6's line setup);
+#define NR_VERSION 500 /* 0.5.0: K6's default mode on the lane-parallel band kernel (k_bpm_px; NR_FLAG_K6_LEGACY keeps k_bpm_fast); the
+                          *        measurement hook nr_profile_band_kernel left the product ABI (include/nr_hip_profile.h, libnr_hip_prof.so);
+                          * 0.4.1: NR_FLAG_SERIAL_BACKWARD (the fused backward's gather shares a launch with K6's line setup);
                           * 0.4.0: NR_FLAG_EXACT_GRADIENT and NR_FLAG_K6_SCAN combine (one band kernel, two arithmetic modes);
                           *        NR_FLAG_SPARSE_WEIGHT_MAP;
                           * 0.3.0: any `near` (NR_E_NEAR removed); 0.2.0: faces_z_ref, visible_faces, flags on the K6 entry points */
@@ -106,11 +108,14 @@ extern "C" {
                                          grad_faces last.  Same values: one float addition per element of grad_faces either
                                          way; a testing / measuring aid. */
 
-#define NR_FLAG_K6_LEGACY 128          /* K6: keep the default arithmetic mode on the piece-per-lane band kernel of rounds 3-4
-                                         (k_bpm_fast) instead of the lane-parallel one (k_bpm_px, round 5: the pixels of a sweep
-                                         across the lanes, the line records through the scalar unit).  Same per-pixel terms,
-                                         summed in a different order; a testing / measuring aid.  The exact mode, the scan
-                                         path and rasters whose line does not fit k_bpm_px's LDS band run on k_bpm_fast anyway. */
+#define NR_FLAG_K6_LEGACY 128          /* K6, default arithmetic mode: always the piece-per-lane band kernel of rounds 3-4 (k_bpm_fast) */
+#define NR_FLAG_K6_PX 256              /* K6, default arithmetic mode: always the lane-parallel band kernel (k_bpm_px, round 5: the pixels
+                                         of a sweep across the lanes of a wave, the line's records one after the other) where its
+                                         band fits the LDS (raster <= 1024 with colours) and eps > 0.  Without either flag the
+                                         library picks per launch by what was measured (large launches at rasters >= 512, single-
+                                         output modes and dense meshes: k_bpm_px; the rest: k_bpm_fast).  Same per-pixel terms,
+                                         summed in a different order; testing / measuring aids.  The exact mode and the scan path
+                                         run on k_bpm_fast. */
 
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):
@@ -127,15 +132,6 @@ extern "C" {
 
 int nr_version(void);
 const char *nr_error_string(int code);
-
-/* Measurement hook (bench.py's `roofline`): with enable != 0 every K6 band-kernel launch of nr_backward_pixel_map /
- * nr_backward_rasterize[_lit] is bracketed by a pair of HIP events recorded on the call's stream (events of the library's own,
- * created on the first enable); nr_profile_band_kernel_ms() waits for the last pair and returns the time between them in
- * milliseconds (< 0: no launch was bracketed, or an event call failed).  That is the duration of the path's dominant kernel
- * alone, without the helper launches of its stage call, as `rocprofv3 --kernel-trace --stats` reports it.  Process-wide, not
- * thread-safe, and the two event packets cost the stream a few microseconds per call: off outside measurements. */
-int nr_profile_band_kernel(int32_t enable);
-float nr_profile_band_kernel_ms(void);
 
 /* Scratch needed by the forward: the packed 64-bit z-buffer (depth bits << 32 | face index, one word per pixel) and the
  * queue of faces with large screen boxes.  The reference's `faces_inv` scratch (rasterize.py:240) is not materialised. */

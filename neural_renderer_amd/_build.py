@@ -9,9 +9,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(HERE, 'csrc', n) for n in ('nr_forward.hip', 'nr_backward_pixel_map.hip', 'nr_backward_gather.hip', 'nr_geometry.hip',
                                                       'nr_image.hip', 'nr_frontend.hip', 'nr_texture_io.hip', 'nr_optim.hip')]
-HEADERS = [os.path.join(os.path.dirname(HERE), 'include', 'nr_hip.h'), os.path.join(HERE, 'csrc', 'nr_device.h'),
+HEADERS = [os.path.join(os.path.dirname(HERE), 'include', 'nr_hip.h'), os.path.join(os.path.dirname(HERE), 'include', 'nr_hip_profile.h'),
+           os.path.join(HERE, 'csrc', 'nr_device.h'),
            os.path.join(HERE, 'csrc', 'nr_k6_tune.h'), os.path.join(HERE, 'csrc', 'nr_band_lines.h')]
 LIB_PATH = os.path.join(HERE, 'libnr_hip.so')
+# the measurement build: the same sources with -DNR_PROFILE_HOOK (include/nr_hip_profile.h); bench.py times the dominant kernel with it
+PROFILE_LIB_PATH = os.path.join(HERE, 'libnr_hip_prof.so')
 
 # -ffp-contract=off + correctly rounded division: the parity contract (DESIGN.md "Numerics").
 # -munsafe-fp-atomics: hardware global_atomic_add_f32 instead of a CAS loop (torch memory is coarse-grained).
@@ -47,6 +50,18 @@ def build(force=False, verbose=False):
             print(' '.join(cmd))
         subprocess.check_call(cmd)
     return LIB_PATH
+
+
+def build_profile(force=False, verbose=False):
+    """libnr_hip_prof.so: the product's sources plus the band-kernel timing hook (include/nr_hip_profile.h).  Loaded only by
+    bench.py's roofline measurement and by the hook's test (neural_renderer_amd._lib.load_profile)."""
+    if force or not os.path.exists(PROFILE_LIB_PATH) or \
+            any(os.path.getmtime(p) > os.path.getmtime(PROFILE_LIB_PATH) for p in SOURCES + HEADERS + [os.path.abspath(__file__)]):
+        cmd = [hipcc()] + HIPCC_FLAGS + ['-DNR_PROFILE_HOOK=1'] + SOURCES + ['-o', PROFILE_LIB_PATH]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return PROFILE_LIB_PATH
 
 
 def build_variant(tag, defines, verbose=False, sources=None, flags=None):

@@ -33,8 +33,6 @@ _cam_p, _light_p, _fl_p = _c.POINTER(Camera), _c.POINTER(Light), _c.POINTER(Face
 SIGNATURES = {
     'nr_version': (_c.c_int, []),
     'nr_error_string': (_c.c_char_p, [_c.c_int]),
-    'nr_profile_band_kernel': (_c.c_int, [_i32]),
-    'nr_profile_band_kernel_ms': (_c.c_float, []),
     'nr_forward_workspace_bytes': (_sz, [_i32, _i32, _i32]),
     'nr_backward_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32]),
     'nr_forward_face_index_map': (_c.c_int, [_vp] * 6 + [_i32, _i32, _i32, _f64, _f64, _vp, _sz, _vp]),
@@ -60,7 +58,7 @@ SIGNATURES = {
     'nr_frontend_backward_light': (_c.c_int, [_vp] * 7 + [_i32] * 6 + [_cam_p, _light_p, _vp, _sz, _vp]),
 }
 
-NR_VERSION = 401  # include/nr_hip.h; load() refuses a library of another version (a stale build)
+NR_VERSION = 500  # include/nr_hip.h; load() refuses a library of another version (a stale build)
 NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
 NR_FLAG_EXACT_GRADIENT = 2
 NR_FLAG_K6_GLOBAL = 4
@@ -69,6 +67,7 @@ NR_FLAG_ZBUF_EPOCH = 16  # + epoch number << 8 (include/nr_hip.h)
 NR_FLAG_SPARSE_WEIGHT_MAP = 32
 NR_FLAG_SERIAL_BACKWARD = 64
 NR_FLAG_K6_LEGACY = 128
+NR_FLAG_K6_PX = 256
 NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1
 NR_CAMERA_LOOK = 2
@@ -99,6 +98,33 @@ def load():
                       % (path, lib.nr_version(), NR_VERSION))
     _lib = lib
     return lib
+
+
+# the measurement build's two extra exports (include/nr_hip_profile.h)
+PROFILE_SIGNATURES = {
+    'nr_profile_band_kernel': (_c.c_int, [_i32]),
+    'nr_profile_band_kernel_ms': (_c.c_float, []),
+}
+_profile_lib = None
+
+
+def load_profile():
+    """libnr_hip_prof.so -- the product's sources with the band-kernel timing hook compiled in -- for measurements only
+    (bench.py's roofline, the hook's test).  The product path never loads it."""
+    global _profile_lib
+    if _profile_lib is None:
+        path = _build.PROFILE_LIB_PATH
+        if not os.path.exists(path):
+            raise NRError('%s not found: build it with neural_renderer_amd._build.build_profile()' % path)
+        lib = _c.CDLL(path)
+        for name, (res, args) in list(SIGNATURES.items()) + list(PROFILE_SIGNATURES.items()):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.nr_version() != NR_VERSION:
+            raise NRError('%s is version %d, this package binds version %d: rebuild it' % (path, lib.nr_version(), NR_VERSION))
+        _profile_lib = lib
+    return _profile_lib
 
 
 def check(code, what):

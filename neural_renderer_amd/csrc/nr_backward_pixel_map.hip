@@ -1826,7 +1826,11 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
     return bpm_layout(B, F, S).total;
 }
 
-// Measurement hook (include/nr_hip.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.
+// Measurement hook (include/nr_hip_profile.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.  Only in the
+// measurement build of the library (libnr_hip_prof.so, -DNR_PROFILE_HOOK: neural_renderer_amd._build.build_profile); the product
+// library keeps no such state and does not export the two functions.
+#ifdef NR_PROFILE_HOOK
+#include "../../include/nr_hip_profile.h"
 namespace {
 struct BandKernelTimer {
     bool on = false, recorded = false;
@@ -1858,6 +1862,12 @@ NR_API float nr_profile_band_kernel_ms(void)
     }
     return ms;
 }
+#define NR_BAND_TIMER_START(st) if (g_band_timer.on) g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess
+#define NR_BAND_TIMER_STOP(st) if (g_band_timer.on && g_band_timer.recorded) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess
+#else
+#define NR_BAND_TIMER_START(st) ((void)0)
+#define NR_BAND_TIMER_STOP(st) ((void)0)
+#endif
 
 int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map, const float *rgb_map,
                                const float *alpha_map, const float *grad_rgb_map, const float *grad_alpha_map,
@@ -1890,15 +1900,23 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     int w_max = shape.w_max;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
     const int W_fast = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
-    // The lane-parallel band kernel (k_bpm_px) takes the default arithmetic mode on line records; k_bpm_fast keeps the exact
-    // mode, the scan path, rasters beyond k_bpm_px's LDS band and NR_FLAG_K6_LEGACY (a testing / measuring aid).  With
-    // k_bpm_px the band tables and the line records are binned per LINE (band width 1).
-    size_t px_lds = 0;
+    // Two band kernels serve the default arithmetic mode on line records (same per-pixel terms): k_bpm_fast (a piece of a sweep
+    // per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
+    // was measured (profiles/r05_k6_kernels.md: whole steps, same process): k_bpm_px wins on large launches of small faces --
+    // >= 2^18 faces in the call -- when the raster is 512 or more (teapot, 64 views, rgb: 0.97 vs 1.25 ms), when only one of
+    // rgb / alpha is asked for (256^2: 0.335 vs 0.367 / 0.242 vs 0.253), or when the meshes are dense (config 4: 0.74 vs 0.79);
+    // k_bpm_fast keeps the headline shape (rgb + alpha at 256^2: 0.354 vs 0.365), small launches (8-32 views: 7 % faster) and
+    // large faces (4 views at 1024^2: k_bpm_px walks an in sweep with one lane).  NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one
+    // of them (tests, measurements).  The exact mode, the scan path and rasters beyond k_bpm_px's LDS band are k_bpm_fast's.
+    // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
     // (eps must be positive as a float: a lane outside a sweep multiplies 0 by 1 / (|c t| + eps), and t = 0 -- the crossing
     // point on a pixel centre -- would make that 0 * Inf)
-    const int W_px = (exact || (flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY)) || B > 65535 || S > 3072 || W_fast == 0 ||
-                      !((float)eps >= 1e-30f))
-                         ? 0 : px_band_config(S, rgb, B, &px_lds);
+    size_t px_lds = 0;
+    const bool px_possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY)) && B <= 65535 && S <= 3072 && W_fast != 0 &&
+                             (float)eps >= 1e-30f;
+    const bool px_wanted = (flags & NR_FLAG_K6_PX) ||
+                           ((size_t)B * F >= k6::PX_MIN_FACES && (S >= 512 || !(rgb && alpha) || F >= k6::PX_DENSE_FACES));
+    const int W_px = px_possible && px_wanted ? px_band_config(S, rgb, B, &px_lds) : 0;
     const bool use_px = W_px > 0;
     const int W = use_px ? 1 : W_fast;  // the band width of the tables
     if (W_fast == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
@@ -2021,7 +2039,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
             if (mode == K6_EXACT_POW2) return by_threads(r, a, std::integral_constant<int, K6_EXACT_POW2>());
             return by_threads(r, a, std::integral_constant<int, K6_EXACT>());
         };
-        if (g_band_timer.on) g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess;
+        NR_BAND_TIMER_START(st);
         rc = 0;
         if (use_px) {
             auto lp = [&](auto r, auto a) {
@@ -2030,10 +2048,10 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                     line_buf, L.cap, B, F, S, W_px, px_lds, eps, st, zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
             };
             rc = (rgb && alpha) ? lp(T(), T()) : (rgb ? lp(T(), N()) : lp(N(), T()));
+            NR_BAND_TIMER_STOP(st);
         }
-        if (g_band_timer.on && g_band_timer.recorded && use_px) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess;
         if (rc == 0) rc = (rgb && alpha) ? by_mode(T(), T()) : (rgb ? by_mode(T(), N()) : by_mode(N(), T()));
-        if (g_band_timer.on && g_band_timer.recorded && !use_px) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess;
+        if (!use_px) NR_BAND_TIMER_STOP(st);
         if (rc == 0 && zero_ok && zeroed) *zeroed = 1;
     }
     if (rc) return rc;

@@ -43,6 +43,13 @@
 #define NR_PX_MIN_WGS 8192
 #endif
 
+#ifndef NR_PX_MIN_FACES     // k_bpm_px is considered from this many faces in the call (batch x faces) on
+#define NR_PX_MIN_FACES 262144
+#endif
+#ifndef NR_PX_DENSE_FACES   // ... and taken for rgb + alpha at rasters below 512 only from this many faces per image on
+#define NR_PX_DENSE_FACES 8192
+#endif
+
 #ifndef NR_SHARED_LAUNCH_MAX_FACES  // fused backward: calls of up to this many faces (batch x faces) put the line setup and the
 #define NR_SHARED_LAUNCH_MAX_FACES 98304  // K7 / K8 gather into one launch (nr_backward_rasterize_lit; measured: LAB-NOTEBOOK, late round 4)
 #endif
@@ -61,6 +68,8 @@ constexpr int WMAX = NR_K6_WMAX;
 constexpr int FOLD_KB = NR_K6_FOLD_KB;
 constexpr unsigned long LDS_BUDGET = NR_K6_LDS_BUDGET;
 constexpr unsigned long PX_MIN_WGS = NR_PX_MIN_WGS;
+constexpr unsigned long PX_MIN_FACES = NR_PX_MIN_FACES;
+constexpr int PX_DENSE_FACES = NR_PX_DENSE_FACES;
 constexpr unsigned long SHARED_LAUNCH_MAX_FACES = NR_SHARED_LAUNCH_MAX_FACES;
 }  // namespace k6
 }  // namespace nr

@@ -71,7 +71,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_host_only_entry_points(lib_path):
     lib = _lib.load()
-    assert lib.nr_version() == 401 == _lib.NR_VERSION
+    assert lib.nr_version() == 500 == _lib.NR_VERSION
     import neural_renderer_amd
     v = _lib.NR_VERSION
     assert neural_renderer_amd.__version__ == '%d.%d.%d' % (v // 1000, v // 100 % 10, v % 100)
@@ -80,8 +80,8 @@ def test_host_only_entry_points(lib_path):
     assert lib.nr_forward_workspace_bytes(64, 4928, 256) >= 64 * 256 * 256 * 8 + 64 * 4928 * 4
     assert lib.nr_forward_workspace_bytes(0, 1, 1) == 0
     assert lib.nr_forward_workspace_bytes(1, 1, 20000) == 0
-    # the measurement hook: switched off it touches no device, and there is nothing to read
-    assert lib.nr_profile_band_kernel(0) == 0 and lib.nr_profile_band_kernel_ms() < 0
+    # the measurement hook is not part of the product library (include/nr_hip_profile.h: libnr_hip_prof.so only)
+    assert not hasattr(lib, 'nr_profile_band_kernel') and not hasattr(lib, 'nr_profile_band_kernel_ms')
 
 
 def test_argument_errors_do_not_need_a_gpu(lib_path):

@@ -28,7 +28,8 @@ EXACT = 2  # _lib.NR_FLAG_EXACT_GRADIENT
 K6_GLOBAL = 4  # _lib.NR_FLAG_K6_GLOBAL
 K6_SCAN = 8    # _lib.NR_FLAG_K6_SCAN
 SERIAL = 64    # _lib.NR_FLAG_SERIAL_BACKWARD
-K6_LEGACY = 128  # _lib.NR_FLAG_K6_LEGACY: the default mode on the piece-per-lane band kernel (k_bpm_fast) instead of k_bpm_px
+K6_LEGACY = 128  # _lib.NR_FLAG_K6_LEGACY: the default mode always on the piece-per-lane band kernel (k_bpm_fast)
+K6_PX = 256      # _lib.NR_FLAG_K6_PX: ... always on the lane-parallel one (k_bpm_px); without either the library picks per launch
 
 
 def report(test, **values):
@@ -285,17 +286,19 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
             gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                   use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
             assert H.rel_err(abi.host(gf3), gf) <= SAME_TERMS
-            # ... and the two band kernels of the default mode against each other (flags 0: the lane-parallel k_bpm_px where its
-            # band fits; NR_FLAG_K6_LEGACY: k_bpm_fast on line records) -- and the legacy kernel against the oracle as well
-            if not (flags & (EXACT | K6_GLOBAL | K6_SCAN | K6_LEGACY)):
-                gf4, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
-                                      use_face_inv_map=residual_maps, k6_flags=flags | K6_LEGACY)
-                gf4 = abi.host(gf4)
-                err_l = H.rel_err(gf4, ref_d)
-                report('check_backward_legacy_kernel', S=S, modes=list(modes), flags=flags | K6_LEGACY, err_vs_double_sum=err_l,
-                       px_vs_legacy=H.rel_err(gf4, gf))
-                assert err_l <= bound, 'grad_faces (k_bpm_fast) vs double-summed oracle: %g' % err_l
-                assert H.rel_err(gf4, gf) <= SAME_TERMS
+            # ... and each of the two band kernels of the default mode by name (without a flag the library picks per launch by
+            # size and mode: small test scenes would never reach k_bpm_px): both against the oracle and against each other
+            if not (flags & (EXACT | K6_GLOBAL | K6_SCAN | K6_LEGACY | K6_PX)):
+                for kflag, kname in ((K6_LEGACY, 'k_bpm_fast'), (K6_PX, 'k_bpm_px')):
+                    gf4, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
+                                          use_face_inv_map=residual_maps, k6_flags=flags | kflag)
+                    gf4 = abi.host(gf4)
+                    assert not np.isnan(gf4).any()
+                    err_k = H.rel_err(gf4, ref_d)
+                    report('check_backward_' + kname, S=S, modes=list(modes), flags=flags | kflag, err_vs_double_sum=err_k,
+                           vs_default=H.rel_err(gf4, gf))
+                    assert err_k <= bound, 'grad_faces (%s) vs double-summed oracle: %g' % (kname, err_k)
+                    assert H.rel_err(gf4, gf) <= SAME_TERMS
     if rgb:
         gt = abi.host(gt)
         assert not np.isnan(gt).any(), 'grad_textures has unwritten elements'
@@ -1170,27 +1173,34 @@ def test_operator_does_not_leak_device_memory():
 
 
 def test_band_kernel_timing_hook():
-    """nr_profile_band_kernel (include/nr_hip.h): off -> no reading; on -> the band kernel's launch of the last K6 call is bracketed
-    by the library's own events, staged and fused entry points alike, and the results do not change."""
+    """nr_profile_band_kernel (include/nr_hip_profile.h) lives in the MEASUREMENT build of the library only (libnr_hip_prof.so,
+    what bench.py's roofline loads): off -> no reading; on -> the band kernel's launch of the last K6 call is bracketed by the
+    library's own events, staged and fused entry points alike, and the results are those of the product library."""
     from neural_renderer_amd import _lib
-    lib = _lib.load()
+    assert not hasattr(_lib.load(), 'nr_profile_band_kernel')  # (not in the product ABI)
+    lib = _lib.load_profile()
     faces, _ = H.teapot_views(2, 64)
     rng = np.random.default_rng(77)
     textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
     fw = abi.forward(faces, textures, 64, 0.1, 100.0, 1e-3, (0.1, 0.2, 0.3), 0, True, True, False)
     g_rgb = rng.normal(size=(2, 64, 64, 3)).astype(np.float32)
     g_alpha = rng.normal(size=(2, 64, 64)).astype(np.float32)
-    assert lib.nr_profile_band_kernel(0) == 0 and lib.nr_profile_band_kernel_ms() < 0
     ref, _ = abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
-    assert lib.nr_profile_band_kernel(1) == 0
+    assert lib.nr_profile_band_kernel(0) == 0 and lib.nr_profile_band_kernel_ms() < 0
+    prev = _lib._lib
+    _lib._lib = lib  # (tests/abi.py calls through _lib.load(): the measurement build for the calls below)
     try:
+        assert lib.nr_profile_band_kernel(1) == 0
         assert lib.nr_profile_band_kernel_ms() < 0  # nothing bracketed yet
         got, _ = abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
         t_fused = lib.nr_profile_band_kernel_ms()
         abi.backward(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
         t_staged = lib.nr_profile_band_kernel_ms()
+        abi.backward(fw, g_rgb, g_alpha, None)  # (the default mode's band kernel, k_bpm_px, is bracketed as well)
+        t_px = lib.nr_profile_band_kernel_ms()
     finally:
         lib.nr_profile_band_kernel(0)
-    assert 0 < t_fused < 50 and 0 < t_staged < 50  # milliseconds; a 2-view 64 x 64 launch takes tens of microseconds
-    np.testing.assert_array_equal(abi.host(got), abi.host(ref))  # (exact mode: the same bits run to run)
+        _lib._lib = prev
+    assert 0 < t_fused < 50 and 0 < t_staged < 50 and 0 < t_px < 50  # milliseconds; a 2-view 64 x 64 launch takes tens of microseconds
+    np.testing.assert_array_equal(abi.host(got), abi.host(ref))  # (exact mode: the same bits run to run, and in both builds)
     assert lib.nr_profile_band_kernel_ms() < 0

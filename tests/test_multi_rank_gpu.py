@@ -56,3 +56,53 @@ def test_bench_two_ranks_on_one_gpu(gather):
     assert w['scaling'] == 'weak' and w['views_per_gpu'] == 64 and w['views_total'] == 128 and w['value'] > 0
     assert ('all_gather' in d['config']['parallelism']) == gather
     assert d['cpu_baseline'] is None  # (--cpu-sample-views 0 in this test; an N > 1 run otherwise carries rank 0's CPU rows)
+
+
+def _launch(n_ranks, extra, log_name, timeout=420):
+    env = dict(os.environ, NR_DIST_DEVICE='0', NR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks), '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(n_ranks), '--steps', '2',
+           '--warmup', '1', '--cpu-sample-views', '0', '--stage-iters', '2', '--light', '--prewarm-ms', '0'] + extra
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, log_name), 'w') as f:
+            f.write('$ NR_DIST_DEVICE=0 NR_DIST_BACKEND=gloo ' + ' '.join(cmd) + '\n' + res.stdout + '\n--- stderr ---\n' +
+                    res.stderr[-4000:])
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('views', [64, 60], ids=['even_8_views_each', 'uneven_60_views'])
+def test_bench_eight_ranks_on_one_gpu(views):
+    """The control path of the 8-GPU run (VERDICT r04 missing #3): 8 ranks, gloo rendezvous, all on the one GPU of the test box --
+    rank -> shard bounds (an uneven split of 60 views: four ranks of 8, four of 7), pin_to_l3_group(local_rank) for eight local
+    ranks, the reference-face broadcast, barrier / max-over-ranks timing, the weak-scaling leg, the padded all-gather of uneven
+    shards.  Not a measurement."""
+    d = _launch(8, ['--batch', str(views), '--gather'], 'eight_ranks_one_gpu_%d.log' % views)
+    assert d['n_gpus'] == 8 and d['scaling'] == 'strong' and d['value'] > 0
+    assert d['config']['views_total'] == views and d['config']['views_per_gpu'] == -(-views // 8)  # rank 0 holds a larger shard
+    assert abs(d['value'] - views * 256 * 256 / (d['ms_per_step'] * 1e-3) / 1e6) <= 1e-6 * d['value']
+    assert d['weak_scaling']['views_total'] == 8 * views and 'all_gather' in d['config']['parallelism']
+    assert d['grad_check']['face_index_mismatch'] == 0
+
+
+@pytest.mark.parametrize('gather', [False, True], ids=['no_collective', 'all_gather'])
+def test_bench_config4_two_ranks_on_one_gpu(gather):
+    """BASELINE.json configs[3] in its stated form (VERDICT r04 missing #2): `bench.py --workload c4` shards the 512 seeded meshes
+    over the ranks (here 8 meshes over 2 ranks: the job's size is an argument), RGB forward + backward, `--gather` all-gathers
+    the rendered [meshes / R, 256, 256, 3] shards; the line names the workload and keeps roofline + grad_check."""
+    d = _launch(2, ['--workload', 'c4', '--batch', '8'] + (['--gather'] if gather else []),
+                'c4_two_ranks_one_gpu%s.log' % ('_gather' if gather else ''))
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and 'configs[3]' in d['metric'] and 'configs[3]' in d['config']['workload']
+    assert d['config']['views_total'] == 8 and d['config']['views_per_gpu'] == 4 and d['config']['num_faces'] == 10240
+    assert d['config']['texture_size'] == 4
+    assert abs(d['value'] - 8 * 256 * 256 / (d['ms_per_step'] * 1e-3) / 1e6) <= 1e-6 * d['value']
+    assert ('all_gather' in d['config']['workload']) == gather
+    g = d['grad_check']
+    assert g['face_index_mismatch'] == 0 and g['grad_faces']['max_rel_err_floor_1e-3_of_max'] <= 1e-4
+    assert g['grad_textures']['max_abs_err'] <= 1e-4 * g['grad_textures']['max_abs']
+    w = d['roofline']['whole_step']  # rgb only: SURVEY 8d's 76 B per pixel
+    assert w['algorithmic_bytes'] == 76 * 8 * 256 * 256 + (108 + 24 * 64) * 8 * 10240
