@@ -208,8 +208,9 @@ def whole_step_bytes_rgb(B, F, S, ts):
     return 76 * B * S * S + (108 + 24 * ts ** 3) * B * F
 
 
-def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flags=0):
-    """Average duration of each C-ABI stage, measured with events on the stream the kernels are launched on."""
+def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flags=0, only=None):
+    """Average duration of each C-ABI stage, measured with events on the stream the kernels are launched on.  `only`: a subset of
+    the stage names (the stages are run in the order below: later ones read what earlier ones wrote)."""
     from neural_renderer_amd import _lib
     lib = _lib.load()
     dev = faces.device
@@ -268,6 +269,8 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flag
         vis.data_ptr(), bws.data_ptr(), bwsb, st)
     out = {}
     for name, call in calls.items():
+        if only is not None and name not in only:
+            continue
         for _ in range(2):
             _lib.check(call(), name)
         torch.cuda.synchronize(dev)
@@ -286,7 +289,7 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flag
         plib = _lib.load_profile()
     except Exception:  # (no measurement build in the tree: the stage call's own duration stands in)
         plib = None
-    if plib is not None:
+    if plib is not None and (only is None or 'backward_pixel_map' in only):
         pcalls = {
             'backward_pixel_map': lambda: plib.nr_backward_pixel_map(
                 faces.data_ptr(), fi.data_ptr(), rgb.data_ptr(), am.data_ptr(), g_rgb.data_ptr(), g_alpha.data_ptr(),
@@ -296,6 +299,8 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flag
                 g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(), gt.data_ptr(), B, F, S, ts, eps, k6_flags,
                 vis.data_ptr(), bws.data_ptr(), bwsb, st)}
         for key, name in (('k6_band_kernel_alone', 'backward_pixel_map'), ('k6_band_kernel_alone_in_fused_backward', 'fused_backward_rasterize')):
+            if only is not None and name not in only:
+                continue
             samples = []
             _lib.check(plib.nr_profile_band_kernel(1), 'profile hook')
             try:
@@ -928,9 +933,25 @@ def main():
             tex2 = textures.detach().clone().requires_grad_(True)
             g2 = upstream_gradients(faces2, tex2, 2 * S, eps, 4321)
             ms2 = time_step(make_step(faces2, tex2, 2 * S, g2), dev, max(3, args.steps // 4), 2)
+            # the roofline of THIS row (the reference's default configuration: Renderer() renders with anti-aliasing, raster 2 S):
+            # its dominant stage's algorithmic bytes over that stage's dominant kernel alone, as for the headline
+            st2 = time_stages(faces2.detach(), tex2.detach(), 2 * S, eps, g2[0], g2[1], g2[2], max(3, args.stage_iters // 2), k6_flags,
+                              only=('forward_face_index_map', 'forward_texture_sampling', 'backward_pixel_map'))
+            sb2 = algorithmic_bytes(B, F, 2 * S, ts)['backward_pixel_map']
+            k2_us = st2.get('k6_band_kernel_alone') or st2['backward_pixel_map']
+            wb2 = whole_step_bytes(B, F, 2 * S, ts)
             extra_rows.append({'row': 'anti_aliasing on: raster %dx%d for image_size %d' % (2 * S, 2 * S, S), 'ms_per_step': ms2,
                                'mpixel_per_s_raster': B * 4 * S * S / (ms2 * 1e-3) / 1e6,
-                               'mpixel_per_s_image': B * S * S / (ms2 * 1e-3) / 1e6})
+                               'mpixel_per_s_image': B * S * S / (ms2 * 1e-3) / 1e6,
+                               'roofline': {'bound': 'hbm', 'stage': 'backward_pixel_map',
+                                            'kernel': k6_band_kernel(B, F, 2 * S, True, True, args.exact), 'avg_launch_us': k2_us,
+                                            'algorithmic_bytes_per_launch': sb2, 'achieved': sb2 / (k2_us * 1e-6) / 1e9,
+                                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': sb2 / (k2_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                            'stage_call_us': st2['backward_pixel_map'],
+                                            'whole_step': {'algorithmic_bytes': wb2, 'achieved': wb2 / (ms2 * 1e-3) / 1e9,
+                                                           'frac': wb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                            'traffic': None,
+                                            'traffic_note': 'counter passes of this shape: profiles/r05_pmc_hbm_traffic_S512.json'}})
             del faces2, tex2, g2
             ones = upstream_gradients(faces, textures, S, eps, 0, all_ones=True)
             ms3 = time_step(make_step(faces, textures, S, ones), dev, args.steps, 2)

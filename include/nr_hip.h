@@ -79,7 +79,12 @@ extern "C" {
                                          against the exactly summed reference terms.  Default (flag clear): float terms through
                                          fused multiply-adds and v_rcp_f32, ~1 ulp per term, bound 1e-4 (the north star's
                                          tolerance).  Same sweep structure either way; what the modes cost and measure:
-                                         profiles/<round>_parity_summary.md, DESIGN.md 3. */
+                                         profiles/<round>_parity_summary.md, DESIGN.md 3.
+                                         REPRODUCIBILITY: only this flag gives run-to-run identical grad_faces.  The default mode
+                                         adds float partial sums in the order its atomics arrive: two calls on the same data
+                                         differ by up to ~1.2e-5 of the largest gradient (sharded vs unsharded batches and fused vs
+                                         staged calls included); the exact mode sums in double throughout (<= 1e-6, bit-identical
+                                         in every pair measured). */
 #define NR_FLAG_K6_GLOBAL 4           /* K6: force the global-memory kernel that otherwise only serves rasters whose band
                                          does not fit in LDS (a testing aid) */
 #define NR_FLAG_K6_SCAN 8             /* K6: let every band workgroup derive its lines from the image's visible-face list
@@ -109,7 +114,7 @@ extern "C" {
                                          way; a testing / measuring aid. */
 
 #define NR_FLAG_K6_LEGACY 128          /* K6, default arithmetic mode: always the piece-per-lane band kernel of rounds 3-4 (k_bpm_fast) */
-#define NR_FLAG_K6_PX 256              /* K6, default arithmetic mode: always the lane-parallel band kernel (k_bpm_px, round 5: the pixels
+#define NR_FLAG_K6_PX 65536              /* K6, default arithmetic mode: always the lane-parallel band kernel (k_bpm_px, round 5: the pixels
                                          of a sweep across the lanes of a wave, the line's records one after the other) where its
                                          band fits the LDS (raster <= 1024 with colours) and eps > 0.  Without either flag the
                                          library picks per launch by what was measured (large launches at rasters >= 512, single-

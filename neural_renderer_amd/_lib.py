@@ -67,7 +67,7 @@ NR_FLAG_ZBUF_EPOCH = 16  # + epoch number << 8 (include/nr_hip.h)
 NR_FLAG_SPARSE_WEIGHT_MAP = 32
 NR_FLAG_SERIAL_BACKWARD = 64
 NR_FLAG_K6_LEGACY = 128
-NR_FLAG_K6_PX = 256
+NR_FLAG_K6_PX = 65536  # (bits 8..15 of a forward's flags carry the epoch number)
 NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1
 NR_CAMERA_LOOK = 2

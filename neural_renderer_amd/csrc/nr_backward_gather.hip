@@ -929,7 +929,10 @@ int nr::run_backward_textures(const int32_t *face_index_map, const float *sampli
     // table), else they are filled in front.
     const bool face_kernel = ts <= 13;  // (above: the per-pixel scatter)
     const size_t gather_lds = (ts2_static && !sampling_weight_map) ? 0 : (size_t)(256 / (ts <= 5 ? 16 : (ts <= 8 ? 64 : 256))) * n_tex * sizeof(double);
-    const bool fuse = ls && vis_list && face_kernel && phase != 2 && ls->lds_bytes <= 32768 && gather_lds <= 49152;
+    // (the shared launch's dynamic LDS is the larger of the two bodies' and its static arrays -- both bodies', ~6 KB -- come on top;
+    // without a hipFuncSetAttribute call a launch may use 64 KB in all, so the dynamic part is kept to 40 KB: texture_size 12
+    // (41.5 KB of gather accumulators) and rasters whose line setup needs more than 32 KB take the two launches)
+    const bool fuse = ls && vis_list && face_kernel && phase != 2 && ls->lds_bytes <= 32768 && gather_lds <= 40960;
     const bool zero_in_launch = fuse && !lit.light && zero_slot_of && !prefilled && ((size_t)grad_textures & 15) == 0;
     if (phase != 2) {
     if (lit.light) {

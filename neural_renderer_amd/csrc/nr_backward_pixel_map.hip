@@ -1406,6 +1406,24 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
     px.c = (float *)carve((size_t)W * SP * NC * 4);
     px.bg = nullptr; px.cov = nullptr; px.CW = 0; px.span = nullptr;
     double *s_acc = (double *)carve((size_t)NW * WIN * 16);
+    const int n_groups = (S + GROUP - 1) / GROUP;
+    // A band narrower than the workgroup has waves (small launches: the host narrows the bands to have enough workgroups) deals
+    // the records of a line to n_parts waves, in runs of WIN / n_parts: the critical path of a workgroup is its longest line.
+    const int n_parts = max(1, NW / (W * n_groups)), sub_win = WIN / n_parts;
+    const BandLine *recs_b = line_buf + (size_t)b * cap;
+    // (the first window of the wave's first line is requested in front of the staging loads: one global round trip less on the
+    // workgroup's critical path)
+    int4 hh_first = make_int4(1, 1, 0, 0);
+    float4 qq_first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (wave < nld * n_groups * n_parts) {
+        const int task = wave / n_parts, part = wave - task * n_parts, ld = task / n_groups;
+        const int n_rec = band_lines[lt + ld], r = part * sub_win + lane;
+        if (lane < sub_win && r < n_rec) {
+            const BandLine *R = recs_b + band_start[lt + ld] + r;
+            hh_first = *reinterpret_cast<const int4 *>(R);
+            qq_first = *reinterpret_cast<const float4 *>(&R->cross);
+        }
+    }
     fast_stage<RGB, ALPHA, NT>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, (size_t)b * S * S, axis, band_lo, nld, S, SP);
     __syncthreads();
 
@@ -1413,12 +1431,7 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
     asm volatile("" : "+v"(lane_zero));
     float eps_v = eps_f;
     asm volatile("" : "+v"(eps_v));  // (a VGPR: the visit's fma takes |c| from an SGPR, and one SGPR is all a VALU operation reads)
-    const int n_groups = (S + GROUP - 1) / GROUP;
-    // A band narrower than the workgroup has waves (small launches: the host narrows the bands to have enough workgroups) deals
-    // the records of a line to n_parts waves, in runs of WIN / n_parts: the critical path of a workgroup is its longest line.
-    const int n_parts = max(1, NW / (W * n_groups)), sub_win = WIN / n_parts;
     double *acc = s_acc + wave * (WIN * 2);
-    const BandLine *recs_b = line_buf + (size_t)b * cap;
     for (int vt = wave; vt < nld * n_groups * n_parts; vt += NW) {
         const int task = vt / n_parts, part = vt - task * n_parts;
         const int ld = task / n_groups, grp = task - ld * n_groups;
@@ -1447,12 +1460,16 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
             // ---- phase A: lane = record.  The lane keeps its record for the flush, walks the record's in sweep, and prepares what
             // phase B broadcasts from it: the reference colour of the OUT sweep (the in pixel, :594-601), |c0|, |c1|, the crossing
             // point, and the sweep's pixel range with the chunks it touches.
-            int4 hh = make_int4(1, 1, 0, 0);
-            float4 qq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (lane < nw) {
-                const BandLine *R = recs + w0 + lane;
-                hh = *reinterpret_cast<const int4 *>(R);
-                qq = *reinterpret_cast<const float4 *>(&R->cross);
+            int4 hh = hh_first;
+            float4 qq = qq_first;
+            if (!(vt == wave && w0 == part * sub_win)) {  // (not the window requested in front of the staging)
+                hh = make_int4(1, 1, 0, 0);
+                qq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (lane < nw) {
+                    const BandLine *R = recs + w0 + lane;
+                    hh = *reinterpret_cast<const int4 *>(R);
+                    qq = *reinterpret_cast<const float4 *>(&R->cross);
+                }
             }
             const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
             const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
@@ -1464,7 +1481,7 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
             }
             // the sweep inside this group: first pixel, last pixel (relative to the group), chunks touched
             const int rel_from = max(o_from - gb, 0), rel_to = min(o_to - gb, GROUP - 1);
-            const int pk = has_out ? (rel_from | (rel_to - rel_from) << 8 | (rel_from >> 6) << 18 | (rel_to >> 6) << 16) : 0;
+            const int pk = has_out ? (rel_from | (rel_to - rel_from) << 8 | ((2 << (rel_to >> 6)) - (1 << (rel_from >> 6))) << 16) : 0;
             double in0 = 0.0, in1 = 0.0;
             if (grp == 0) {
                 const int in_from = hh.x & 0xffff, in_to = hh.x >> 16;
@@ -1545,13 +1562,12 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
                 if constexpr (RGB) { rr = bcast_f(oref.y, r); rg = bcast_f(oref.z, r); rb = bcast_f(oref.w, r); }
                 const unsigned rel0 = (unsigned)(spk & 0xff), len = (unsigned)((spk >> 8) & 0xff);
                 float a0 = 0.0f, a1 = 0.0f;
-                // The chunks a sweep touches are a run jlo .. jhi.  (A straight-line block per possible run, so that the visits of a
-                // record's chunks could be interleaved, was built and measured: the compiler keeps the visits one after the other
-                // in either scheduling strategy, and the ten blocks cost 23 % more instructions -- 217 vs 172 us.)
-                const int jlo = (spk >> 18) & 3, jhi = (spk >> 16) & 3;
+                // (A straight-line block per possible run of chunks, so that the visits of a record's chunks could be interleaved, was
+                // built and measured: the compiler keeps the visits one after the other in either scheduling strategy, and the
+                // ten blocks cost 23 % more instructions -- 217 vs 172 us.)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    if (j < jlo || j > jhi) continue;
+                    if (!(spk & (0x10000 << j))) continue;  // (bits 16..19: the chunks the sweep touches)
                     float d;                                                                   // :631-638
                     if constexpr (RGB) {
                         d = ALPHA ? __builtin_fmaf(cq[j][NC - 3] - rr, gq[j][NC - 3], (cq[j][0] - ra) * gq[j][0])

@@ -40,6 +40,8 @@ FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 # term; the tests bound the deviation from the reference's terms summed exactly by the north star's 1e-4.  NR_EXACT_GRADIENT=1
 # (read once, here) or the `exact_gradient` attribute of a Rasterize instance: every term with the reference's own arithmetic,
 # sums in double (bound 2e-6).  Measured levels and costs of both: profiles/*_parity_summary.md.
+# Reproducibility: only the exact mode returns the same grad_faces bit for bit from call to call; the default mode's float
+# partial sums are grouped by the order its atomics arrive in (two calls on the same data: up to ~1.2e-5 of the largest gradient).
 EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
 # (measuring aid, read once: NR_SERIAL_BACKWARD=1 makes the fused backward launch K6's line setup, its band kernel and the gather one
 # after the other instead of the first and the last in one grid -- include/nr_hip.h NR_FLAG_SERIAL_BACKWARD; same values)
@@ -81,8 +83,11 @@ _BG_CACHE = {}
 
 def _background_tensor(bg, device):
     """Device copy of a host background colour, cached (a pageable H2D copy per call would serialise the stream)."""
-    if type(bg) is tuple:
-        key = (device.index, bg)
+    # (the fast key only for tuples of plain Python numbers: a 0-d tensor or array element hashes by identity and may change in
+    # place; floats are keyed by their repr so that -0.0 and 0.0 stay apart)
+    fast = type(bg) is tuple and all(type(x) in (int, float) for x in bg)
+    if fast:
+        key = (device.index, tuple(repr(x) for x in bg))
         t = _BG_CACHE.get(key)
         if t is not None:
             return t
@@ -93,11 +98,8 @@ def _background_tensor(bg, device):
         if len(_BG_CACHE) > 64:
             _BG_CACHE.clear()
         t = _BG_CACHE[key2] = torch.as_tensor(arr, device=device)
-    if type(bg) is tuple:
-        try:
-            _BG_CACHE[(device.index, bg)] = t
-        except TypeError:  # (an unhashable element)
-            pass
+    if fast:
+        _BG_CACHE[key] = t
     return t
 
 
@@ -143,7 +145,11 @@ def _forward_workspace(lib, dev, stream, B, F, S):
         raise ValueError('unsupported sizes B=%d F=%d S=%d' % (B, F, S))
     if F >= (1 << 24) or 2 * ws_bytes > _ZBUF_CACHE_BYTES or torch.cuda.is_current_stream_capturing():
         return torch.empty((ws_bytes,), dtype=torch.uint8, device=dev), ws_bytes, 0
-    key = (dev.index, int(stream), B, F, S)
+    # (the calling THREAD is part of the key: the epochs of a workspace must reach the stream in the order they were handed out
+    # -- a call launched later with the larger epoch of an earlier hand-out would lose every atomic minimum against the words of
+    # the call in front of it -- and within one host thread hand-out order is launch order; two threads rendering the same shapes
+    # on one stream each keep their own workspace)
+    key = (dev.index, int(stream), B, F, S, threading.get_ident())
     with _ZBUF_LOCK:
         ent = _ZBUF_CACHE.get(key)
         if ent is None:

@@ -55,8 +55,8 @@ def _compare(faces, textures, S, eps, modes, seed, bg=(0.0, 0.0, 0.0), double_te
         ref_gf = fn.backward(g_rgb, g_alpha, g_depth, accumulate_double=True, skip_textures=True)[0]
     t_bwd = time.time() - t0
     out = {}
-    # (default mode: the kernel the library picks for the launch, then each band kernel by name -- NR_FLAG_K6_LEGACY 128, NR_FLAG_K6_PX 256)
-    for flags, bound in ((0, K6_BOUND_DEFAULT), (128, K6_BOUND_DEFAULT), (256, K6_BOUND_DEFAULT), (EXACT, K6_BOUND_EXACT)):
+    # (default mode: the kernel the library picks for the launch, then each band kernel by name -- NR_FLAG_K6_LEGACY 128, NR_FLAG_K6_PX 65536)
+    for flags, bound in ((0, K6_BOUND_DEFAULT), (128, K6_BOUND_DEFAULT), (65536, K6_BOUND_DEFAULT), (EXACT, K6_BOUND_EXACT)):
         gf, gt = abi.backward_fused(fw, g_rgb, g_alpha, g_depth, k6_flags=flags)
         gf = abi.host(gf)
         assert np.isfinite(gf).all()
@@ -73,7 +73,7 @@ def _compare(faces, textures, S, eps, modes, seed, bg=(0.0, 0.0, 0.0), double_te
             del gt
     report('full_size', S=S, B=int(faces.shape[0]), F=int(faces.shape[1]), modes=list(modes), oracle_fwd_s=t_fwd,
            oracle_bwd_s=t_bwd, threads=O.get_threads(), covered=int((fi >= 0).sum()), visits=fn.visits,
-           default=out[0], k_bpm_fast=out[128], k_bpm_px=out[256], exact=out[EXACT])
+           default=out[0], k_bpm_fast=out[128], k_bpm_px=out[65536], exact=out[EXACT])
     return out
 
 

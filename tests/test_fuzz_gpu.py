@@ -50,10 +50,10 @@ def test_fuzz_unusual_parameters(seed):
             g[0][rng.uniform(size=g[0].shape) < 0.5] = 0
         ref_gf, ref_gt = fn.backward(*g, accumulate_double=True)
         # default K6 numerics (staged and fused entry points) within the north star's 1e-4, NR_FLAG_EXACT_GRADIENT within 2e-5
-        # (256: NR_FLAG_K6_PX -- the lane-parallel band kernel by name; without a flag small scenes take k_bpm_fast)
+        # (65536: NR_FLAG_K6_PX -- the lane-parallel band kernel by name; without a flag small scenes take k_bpm_fast)
         for name, run, bound in (('backward', abi.backward, 1e-4), ('backward_fused', abi.backward_fused, 1e-4),
-                                 ('backward_px', lambda *a: abi.backward(*a, k6_flags=256), 1e-4),
-                                 ('backward_fused_px', lambda *a: abi.backward_fused(*a, k6_flags=256), 1e-4),
+                                 ('backward_px', lambda *a: abi.backward(*a, k6_flags=65536), 1e-4),
+                                 ('backward_fused_px', lambda *a: abi.backward_fused(*a, k6_flags=65536), 1e-4),
                                  ('backward_exact', lambda *a: abi.backward(*a, k6_flags=2), 2e-5),
                                  ('backward_fused_exact', lambda *a: abi.backward_fused(*a, k6_flags=2), 2e-5)):
             gf, gt = run(fw, *g)
@@ -206,7 +206,7 @@ def test_fuzz_default_k6_error_levels(seed):
         g_alpha = (scale * rng.normal(size=(B, S, S))).astype(np.float32) if alpha else None
         ref = fn.backward(g_rgb, g_alpha, None, accumulate_double=True)[0]
         gf = abi.host(abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=128)[0])   # k_bpm_fast by name (NR_FLAG_K6_LEGACY)
-        gp = abi.host(abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=256)[0])   # k_bpm_px by name (NR_FLAG_K6_PX)
+        gp = abi.host(abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=65536)[0])   # k_bpm_px by name (NR_FLAG_K6_PX)
         ge = abi.host(abi.backward_fused(fw, g_rgb, g_alpha, None, k6_flags=2)[0])
         e_def, e_px, e_exact = H.rel_err(gf, ref), H.rel_err(gp, ref), H.rel_err(ge, ref)
         worst[family] = max(worst.get(family, 0.0), e_def)

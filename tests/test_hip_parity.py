@@ -29,7 +29,7 @@ K6_GLOBAL = 4  # _lib.NR_FLAG_K6_GLOBAL
 K6_SCAN = 8    # _lib.NR_FLAG_K6_SCAN
 SERIAL = 64    # _lib.NR_FLAG_SERIAL_BACKWARD
 K6_LEGACY = 128  # _lib.NR_FLAG_K6_LEGACY: the default mode always on the piece-per-lane band kernel (k_bpm_fast)
-K6_PX = 256      # _lib.NR_FLAG_K6_PX: ... always on the lane-parallel one (k_bpm_px); without either the library picks per launch
+K6_PX = 65536      # _lib.NR_FLAG_K6_PX: ... always on the lane-parallel one (k_bpm_px); without either the library picks per launch
 
 
 def report(test, **values):
