@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${TAG:-fwd1}; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 SH="1x256 8x256 16x256 32x256 64x256 64x512 16x512"
-for fl in 48 131120 48 131120; do
+for fl in 48 131120 48 131120; do  # (131072: NR_FLAG_FILL_IN_RESOLVE)
   echo "fwd_flags=$fl (48: epochs + sparse weights; +131072: NR_FLAG_NO_RASTER_FILL)"
   FWD_FLAGS=$fl SHAPES="$SH" ITERS=50 timeout 300 python scripts/fwd_variants.py 2>> $OUT/err.log | tee -a $OUT/fwd_$fl.jsonl
 done
