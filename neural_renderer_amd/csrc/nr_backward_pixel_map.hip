@@ -1350,14 +1350,14 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
 // Images whose records exceed the line buffer (lines_ok == 0) are left to k_bpm_fast's scan path (launched behind this kernel
 // with overflow_only set).  The exact mode (NR_FLAG_EXACT_GRADIENT) stays with k_bpm_fast.
 namespace pxk {
-constexpr int NT = 256;           // threads per workgroup: four waves, a band line each
+constexpr int NT = NR_PX_NT;      // threads per workgroup (nr_k6_tune.h: 256 = four waves), a band line per wave
 constexpr int NW = NT / 64;
 constexpr int CH = 4;             // chunks of 64 pixels a wave holds in registers
 constexpr int GROUP = 64 * CH;    // pixels of a line per task
 constexpr int WIN = 64;           // records per window (phase A gives each a lane)
 constexpr int IN_SEG = 16;        // float terms per double addition of an in sweep (a piece of k_bpm_fast holds 15)
 constexpr int IN_BATCH = 4;       // pixels of an in sweep whose LDS reads are requested together
-constexpr size_t LDS_BUDGET = 40 * 1024;  // four workgroups per 160 KB CU
+constexpr size_t LDS_BUDGET = (size_t)10 * 1024 * (NT / 64);  // sixteen waves per 160 KB CU
 }  // namespace pxk
 
 // LDS hand-over between the lanes of ONE wave (its LDS operations execute in order; the fences keep the compiler from moving

@@ -39,6 +39,9 @@
 #define NR_K6_LDS_BUDGET (53 * 1024)
 #endif
 
+#ifndef NR_PX_NT            // k_bpm_px: threads per workgroup (one band line per wave; 10 KB of LDS per wave)
+#define NR_PX_NT 256
+#endif
 #ifndef NR_PX_MIN_WGS       // k_bpm_px: bands are narrowed (4 -> 2 -> 1 lines) while the launch has fewer band workgroups than this
 #define NR_PX_MIN_WGS 8192
 #endif

@@ -14,7 +14,7 @@ for f in tests/test_hip_parity.py tests/test_fuzz_gpu.py tests/test_full_size_gp
 done
 echo "=== tests/test_abi.py (no GPU marker: the ABI / symbol checks)" >> $OUT/pytest.log
 timeout 300 python -m pytest tests/test_abi.py -q --tb=short -p no:cacheprovider 2>&1 | tail -5 >> $OUT/pytest.log
-cp gpurun_out/parity_errors.jsonl gpurun_out/two_ranks_one_gpu*.log $OUT/ 2>/dev/null
+cp gpurun_out/parity_errors.jsonl gpurun_out/*ranks_one_gpu*.log $OUT/ 2>/dev/null
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 grep -E "===|passed|failed|error" $OUT/pytest.log | head -40
 tail -2 $OUT/smoke.log
