@@ -876,7 +876,16 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             }
         }
     }
-    const int nU = nF - nM, nL = nG - nS;
+    // class U pieces travel in SUPER-PIECES of up to k6::U_GROUP consecutive pieces of one line (round 5): one descriptor, one
+    // record decode and one flush for up to 45 pixels -- the pieces behind the silhouette come in long runs, and decode + flush
+    // cost a piece about half of what its fifteen visits do.  The two runs of a line's U pieces (in front of its M pieces and
+    // behind them) are grouped separately; a super-piece's count sits above its first piece number in the descriptor.
+    // (tolerance mode only: with the exact mode's 62-slot visits the lanes of a wave that hold one piece wait three times as long
+    // for those that hold three -- 342 -> 370 us)
+    constexpr int UG = EXACT ? 1 : k6::U_GROUP;
+    const int nUa = nF > 0 ? pmin : 0, nUb = nF - nM - nUa;  // U pieces in front of / behind the line's M pieces
+    const int gUa = (nUa + UG - 1) / UG, gUb = (nUb + UG - 1) / UG;
+    const int nU = gUa + gUb, nL = nG - nS;
     // one scan for the four numberings (16 bits each: a window holds < 2^16 pieces of every kind by the choice of win_lines)
     unsigned long long totals = 0;
     const unsigned long long offs = block_excl_scan64<NT>((unsigned long long)nU | ((unsigned long long)nM << 16) |
@@ -911,7 +920,11 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                 if (wide) q32[id - lo] = (unsigned)my_line | ((unsigned)seg << 8);
                 else q16[id - lo] = (unsigned short)(my_line | (seg << 8));
             };
-            for (int j = min(max(lo - idU, 0), nU), j1 = min(max(hi - idU, 0), nU); j < j1; ++j) put(idU + j, j < pmin ? j : j + nM);
+            for (int j = min(max(lo - idU, 0), nU), j1 = min(max(hi - idU, 0), nU); j < j1; ++j) {
+                const int first = j < gUa ? j * UG : pmin + nM + (j - gUa) * UG;
+                const int cnt = j < gUa ? min(UG, nUa - j * UG) : min(UG, nUb - (j - gUa) * UG);
+                put(idU + j, first | ((cnt - 1) << (wide ? 22 : 6)));
+            }
             for (int j = min(max(lo - idM, 0), nM), j1 = min(max(hi - idM, 0), nM); j < j1; ++j) put(idM + j, pmin + j);
             for (int j = 0, cs = 0, cl = 0; j < nG; ++j) {  // G piece j: in piece j (j < nIn) or the out remainder
                 const int len = j < nIn - 1 ? FSEG : (j == nIn - 1 ? rin : rem);
@@ -928,7 +941,12 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
             // a lane on a padding id behind its class walks piece 0 of line 0 (valid LDS addresses) and throws the result away
             const bool valid = id < cls_end;
             const unsigned desc = valid ? (wide ? q32[id - lo] : (unsigned)q16[id - lo]) : 0u;
-            const int line = (int)(desc & 0xffu), seg = (int)(desc >> 8);
+            const int line = (int)(desc & 0xffu);
+            int seg = (int)(desc >> 8), u_cnt = 1;
+            if (cls == 0) {  // a super-piece of class U: count - 1 above the first piece number
+                u_cnt = (wide ? (seg >> 22) : (seg >> 6)) + 1;
+                seg &= wide ? 0x3fffff : 63;
+            }
             const BandLine *L = &s_line[line];
             const int4 h = *reinterpret_cast<const int4 *>(L);
             const float4 c = *reinterpret_cast<const float4 *>(&L->cross);
@@ -1054,7 +1072,12 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                     if constexpr (!EXACT && k6::BATCH_DOUBLE) { f0 += (double)b0; f1 += (double)b1; b0 = b1 = 0.0f; }
                 };
                 if (cls == 0) {
-                    // U: gradients only; the next batch's LDS reads are in flight while this one is evaluated
+                    // U: gradients only; the next batch's LDS reads are in flight while this one is evaluated.  The pieces of a
+                    // super-piece one after the other: each piece's sums in a float of their own, added up like the run sums do
+                    for (int u = 0; u < u_cnt; ++u) {
+                    const auto p0 = f0, p1 = f1;
+                    f0 = 0;
+                    f1 = 0;
                     float4 gc[FB], gn[FB];
                     float ac[FB], an[FB];
 #pragma unroll
@@ -1080,6 +1103,11 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
 #pragma unroll
                         for (int j = 0; j < FB; ++j) { gc[j] = gn[j]; ac[j] = an[j]; }
                         __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting every batch's reads to the top)
+                    }
+                    f0 += p0;
+                    f1 += p1;
+                    gp += (RGB ? 4 : 1) * FSEG;
+                    d1fb += (float)FSEG;
                     }
                 } else {
                     // M: every pixel's colour as well -- an uncovered one holds the background colour (K5), so the same
@@ -1203,7 +1231,7 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     px.CW = (((SP + 31) >> 5) + 3) & ~3;  // words per line, a multiple of four (16-byte reads of the classification)
     px.cov = (unsigned *)carve((size_t)W * px.CW * 4);
     px.span = (int *)carve(4 * 2 * 4);  // (W <= 4 lines)
-    const bool wide = S > 255 * FSEG;  // piece numbers beyond 8 bits: 32-bit descriptors
+    const bool wide = S > 63 * FSEG;  // piece numbers beyond 6 bits (two more carry a class-U super-piece's count): 32-bit descriptors
     // The rest of the workgroup's LDS is split between the line window (32 B record + two double sums per line) and the piece
     // queue by the host (fast_band_config).  (A per-band split inside the kernel -- equal windows, as few as let a window's
     // pieces through the queue in one round -- was measured and lost to the fixed split, 258 vs 242 us: it trades windows of
@@ -1727,7 +1755,7 @@ BandShape band_shape(int S)
 // per thread) and the piece queue (2 or 4 B per descriptor).  Returns W (0: the raster does not fit, global fallback).
 int fast_band_config(int S, bool rgb, const BandShape &shape, int w_max, size_t *lds_bytes, int *win, int *qcap)
 {
-    const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 255 * FSEG ? 4 : 2;
+    const size_t per_px = rgb ? 36 : 12, SP = (size_t)S + 4, dsz = S > 63 * FSEG ? 4 : 2;
     // pieces per line the split is made for: measured, stage times in us, raster 256: S/22 (192 lines, 3072 descriptors)
     // 240, S/32 (224, 2560) 230, S/48 (256, 2048: two rounds per window) 267; raster 512: S/22 (160, 4096) 906, S/32 (192,
     // 3584) 891, S/48 (224, 2560) 766 -- a band of a 512 x 512 teapot view has ~185 lines: one window instead of two

@@ -23,6 +23,9 @@
 #ifndef NR_K6_FB           // pixels of an unrolled piece whose LDS reads are requested together (FSEG is a multiple;
 #define NR_K6_FB 3         // 1 / 3 / 5 -> stage 229 / 230 / 252 us, 3 needs the fewest registers)
 #endif
+#ifndef NR_K6_U_GROUP      // class U pieces per super-piece (one descriptor / decode / flush for up to this many pieces of 15 pixels;
+#define NR_K6_U_GROUP 3      // 1: every piece on its own, rounds 3-4; at most 4: the count travels in two bits)
+#endif
 #ifndef NR_K6_SMALL_RASTER_MAX  // up to this raster size: 256-thread workgroups on two-line bands (band_shape; 0: never)
 #define NR_K6_SMALL_RASTER_MAX 400
 #endif
@@ -65,6 +68,8 @@ constexpr bool FUSED_DIST = NR_K6_FUSED_DIST != 0;
 constexpr bool BATCH_DOUBLE = NR_K6_BATCH_DOUBLE != 0;
 constexpr bool RUNSUM_DOUBLE = NR_K6_RUNSUM_DOUBLE != 0;
 constexpr int FB = NR_K6_FB;
+constexpr int U_GROUP = NR_K6_U_GROUP;
+static_assert(U_GROUP >= 1 && U_GROUP <= 4, "a super-piece's count travels in two bits");
 constexpr int SMALL_RASTER_MAX = NR_K6_SMALL_RASTER_MAX;
 constexpr int MINWAVES_256 = NR_K6_MINWAVES_256;
 constexpr int WMAX = NR_K6_WMAX;
