@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: k_bpm_px iteration -- K6 tests, error levels + stage times (px vs legacy), kernel trace, SQ counters
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/${TAG:-px3}; mkdir -p $OUT
+OUT=gpurun_out/${TAG:-k6it}; mkdir -p $OUT
 rm -f gpurun_out/parity_errors.jsonl
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 if [ -z "$NOTESTS" ]; then
