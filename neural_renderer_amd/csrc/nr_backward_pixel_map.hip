@@ -1468,7 +1468,10 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
         const BandLine *recs = recs_b + band_start[lt + ld];
         const int base = ld * SP, gb = grp * GROUP;
         // ---- the group's pixels: gradients, colours, coordinate (a lane beyond the line repeats the last pixel; no mask reaches it)
-        float gq[CH][NC], cq[CH][NC], d1f[CH];
+        // PDOT: sum_c (I_c - ref_c) g_c = sum_c I_c g_c - sum_c ref_c g_c -- the first sum is a property of the pixel (pq, formed
+        // once per group in double and rounded once), the second one fused multiply-add per channel on top of it: four
+        // operations of a visit instead of eight, and the colours leave the registers
+        float gq[CH][NC], cq[CH][NC], pq[CH], d1f[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int d1 = gb + 64 * j + lane, l = base + min(d1, S - 1);
@@ -1478,9 +1481,12 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
                 const float4 c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l);
                 gq[j][0] = g4.x; gq[j][NC - 3] = g4.y; gq[j][NC - 2] = g4.z; gq[j][NC - 1] = g4.w;
                 cq[j][0] = c4.x; cq[j][NC - 3] = c4.y; cq[j][NC - 2] = c4.z; cq[j][NC - 1] = c4.w;
+                pq[j] = (float)((ALPHA ? (double)c4.x * (double)g4.x : 0.0) + (double)c4.y * (double)g4.y + (double)c4.z * (double)g4.z +
+                                (double)c4.w * (double)g4.w);
             } else {
                 gq[j][0] = px.g[l];
                 cq[j][0] = px.c[l];
+                pq[j] = cq[j][0] * gq[j][0];
             }
         }
         for (int w0 = part * sub_win; w0 < n_rec; w0 += sub_win * n_parts) {
@@ -1597,7 +1603,15 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
                 for (int j = 0; j < CH; ++j) {
                     if (!(spk & (0x10000 << j))) continue;  // (bits 16..19: the chunks the sweep touches)
                     float d;                                                                   // :631-638
-                    if constexpr (RGB) {
+                    if constexpr (k6::PX_PDOT) {
+                        d = pq[j];
+                        if constexpr (!RGB || ALPHA) d = __builtin_fmaf(-ra, gq[j][0], d);
+                        if constexpr (RGB) {
+                            d = __builtin_fmaf(-rr, gq[j][NC - 3], d);
+                            d = __builtin_fmaf(-rg, gq[j][NC - 2], d);
+                            d = __builtin_fmaf(-rb, gq[j][NC - 1], d);
+                        }
+                    } else if constexpr (RGB) {
                         d = ALPHA ? __builtin_fmaf(cq[j][NC - 3] - rr, gq[j][NC - 3], (cq[j][0] - ra) * gq[j][0])
                                   : (cq[j][NC - 3] - rr) * gq[j][NC - 3];
                         d = __builtin_fmaf(cq[j][NC - 2] - rg, gq[j][NC - 2], d);

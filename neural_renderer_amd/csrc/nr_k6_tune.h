@@ -45,6 +45,9 @@
 #ifndef NR_PX_NT            // k_bpm_px: threads per workgroup (one band line per wave; 10 KB of LDS per wave)
 #define NR_PX_NT 256
 #endif
+#ifndef NR_PX_PDOT          // k_bpm_px: a visit's diff as (sum I g) - sum ref g, the first sum held per pixel (0: sum (I - ref) g)
+#define NR_PX_PDOT 1
+#endif
 #ifndef NR_PX_MIN_WGS       // k_bpm_px: bands are narrowed (4 -> 2 -> 1 lines) while the launch has fewer band workgroups than this
 #define NR_PX_MIN_WGS 8192
 #endif
@@ -78,6 +81,7 @@ constexpr unsigned long LDS_BUDGET = NR_K6_LDS_BUDGET;
 constexpr unsigned long PX_MIN_WGS = NR_PX_MIN_WGS;
 constexpr unsigned long PX_MIN_FACES = NR_PX_MIN_FACES;
 constexpr int PX_DENSE_FACES = NR_PX_DENSE_FACES;
+constexpr bool PX_PDOT = NR_PX_PDOT != 0;
 constexpr unsigned long SHARED_LAUNCH_MAX_FACES = NR_SHARED_LAUNCH_MAX_FACES;
 }  // namespace k6
 }  // namespace nr

@@ -12,7 +12,7 @@ done
 cp gpurun_out/parity_errors.jsonl $OUT/ 2>/dev/null
 grep -E "===|passed|failed|error|Error" $OUT/pytest.log | head
 fi
-VARIANTS="$VARIANTS" SCENES="${SCENES:-H C4}" K6_FLAGS="0 128" ITERS=30 timeout 600 python scripts/k6_numerics.py > $OUT/numerics.jsonl 2> $OUT/numerics.err
+VARIANTS="$VARIANTS" SCENES="${SCENES:-H C4}" K6_FLAGS="${K6_FLAGS:-0 128}" ITERS=30 timeout 600 python scripts/k6_numerics.py > $OUT/numerics.jsonl 2> $OUT/numerics.err
 python - <<PY
 import json
 for l in open('$OUT/numerics.jsonl'):
