@@ -1361,15 +1361,17 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
 // every piece a descriptor, a record decode and a flush, every window a chain of barriers (profiles/r04_pmc_k6.txt: half of the
 // wave-cycles parked, the LDS array 45 % busy with 47 % of it bank conflicts, 48 lane-slots per 13-instruction visit).  Here a
 // WAVE owns a band line: its lanes hold the line's pixels in REGISTERS -- 64 consecutive pixels per chunk, pxk::CH chunks = one
-// group of 256 pixels -- and the line's records come through the SCALAR unit one after the other (s_load: the records of a line
-// are contiguous because the line setup bins per line, band width 1).  A visit is the 17 instructions of k_bpm_fast's class M,
-// but its record constants are SGPR operands, its pixel data never leaves the registers, the sweep's range is a 64-bit lane
-// mask made by the scalar unit, and nothing is queued, classified or decoded.  Per record and wave:
-//   out sweep (rasterize.py:604-657)   every chunk the sweep overlaps is one masked visit of all 64 lanes; the two sums of the
-//       record are reduced across the lanes (v_permlane32_swap folds the pair into one register, four DPP row steps) and the
-//       four row sums added in double to the record's slot of the wave's window (ds_add_f64, four lanes);
-//   in sweep (:665-728)   nine in ten are <= 4 pixels: a lane takes a whole record (phase A, k_bpm_fast's class G loop: LDS
-//       reads, ownership test :707, per-pixel sign of +- eps), float sums of <= 15 terms, double above;
+// group of 256 pixels: the four gradients and sum_c I_c g_c of each pixel -- and the line's records (contiguous: the line setup
+// bins per line, band width 1) are taken 64 at a time, a lane each.  A visit is 15 vector operations whose record constants are
+// SGPR operands and whose pixel data never leaves the registers; nothing is queued, classified or decoded.  Per window of records:
+//   phase A (lane = record)   the record's in sweep (:665-728; nine in ten are <= 4 pixels): k_bpm_fast's class G loop -- LDS
+//       reads, ownership test :707, per-pixel sign of +- eps --, float sums of <= 16 terms, double above; and what phase B
+//       broadcasts from the lane: the out sweep's reference colour (the in pixel, :594-601), |c0|, |c1|, the crossing point, the
+//       sweep's pixel range inside the group and the chunks it touches;
+//   phase B (one record after the other, v_readlane -> SGPRs)   out sweep (:604-657): every chunk the sweep overlaps is one
+//       visit of all 64 lanes (range test: one unsigned comparison); diff = (sum I g) - sum ref g, one fused multiply-add per
+//       channel; the record's two sums through 2^PX_RED_LEVELS-lane DPP trees in float and LDS atomics in double (ds_add_f64)
+//       onto the record's slot of the wave's window;
 //   flush   one lane per record adds the window's two sums to the double scratch (global_atomic_add_f64), as k_bpm_fast does.
 // Arithmetic of a visit: the tolerance mode of k_bpm_fast (fused multiply-adds, v_rcp_f32), with
 //   dist = sigma * (|c| * |t| + eps),  sigma = sign(c) * sign(t)  -- t = d1 - d1_cross keeps its sign along an out sweep, so
@@ -1627,12 +1629,12 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
                     a0 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y0), a0);                     // :651 (sign: the flush)
                     a1 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y1), a1);                     // :656
                 }
-                // the rows of 16 lanes in float (a tree of depth 4), the four row sums of each in double onto the record's slot
+                // runs of 2^PX_RED_LEVELS lanes in float (a DPP tree), their sums in double onto the record's slot
                 a0 += dpp_row_shr_v<1>(a0); a1 += dpp_row_shr_v<1>(a1);
                 a0 += dpp_row_shr_v<2>(a0); a1 += dpp_row_shr_v<2>(a1);
-                a0 += dpp_row_shr_v<4>(a0); a1 += dpp_row_shr_v<4>(a1);
-                a0 += dpp_row_shr_v<8>(a0); a1 += dpp_row_shr_v<8>(a1);
-                if ((lane & 15) == 15) {
+                if constexpr (k6::PX_RED_LEVELS >= 3) { a0 += dpp_row_shr_v<4>(a0); a1 += dpp_row_shr_v<4>(a1); }
+                if constexpr (k6::PX_RED_LEVELS >= 4) { a0 += dpp_row_shr_v<8>(a0); a1 += dpp_row_shr_v<8>(a1); }
+                if ((lane & ((1 << k6::PX_RED_LEVELS) - 1)) == (1 << k6::PX_RED_LEVELS) - 1) {
                     // (lane_zero: an address the compiler cannot prove uniform -- for a uniform one its atomic optimizer replaces
                     // the four-lane ds_add_f64 by a readlane loop of double additions, ~50 instructions per record)
                     atomicAdd(&acc[2 * r + lane_zero], (double)a0);
