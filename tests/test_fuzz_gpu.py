@@ -12,8 +12,12 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
+# (a soak run: NR_FUZZ_EXTRA_SEEDS="4 5 6 ..." adds seeds to the first and the last test below; the suite itself runs the fixed ones)
+import os
+EXTRA_SEEDS = [int(x) for x in os.environ.get('NR_FUZZ_EXTRA_SEEDS', '').split()]
 
-@pytest.mark.parametrize('seed', [1, 2, 3])
+
+@pytest.mark.parametrize('seed', [1, 2, 3] + EXTRA_SEEDS)
 def test_fuzz_unusual_parameters(seed):
     rng = np.random.default_rng(seed)
     failures = []
@@ -161,7 +165,7 @@ def test_fuzz_micro_triangles_and_needles(seed):
     assert not bad, bad
 
 
-@pytest.mark.parametrize('seed', [31, 32])
+@pytest.mark.parametrize('seed', [31, 32] + [100 + x for x in EXTRA_SEEDS])
 def test_fuzz_default_k6_error_levels(seed):
     """How far the default (tolerance-mode) K6 kernel gets from the exactly summed reference terms on scenes built to cancel:
     many overlapping faces of similar, bright colours (small `diff`, both signs), large and small `eps` (with a large eps every
