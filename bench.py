@@ -158,10 +158,10 @@ STAGE_KERNEL = {
 
 
 def k6_band_kernel(B, F, S, rgb, alpha, exact):
-    """Which of K6's two band kernels the library launches for a call of this shape in this mode (the rule of
-    run_backward_pixel_map, csrc/nr_backward_pixel_map.hip; thresholds: csrc/nr_k6_tune.h NR_PX_MIN_FACES / NR_PX_DENSE_FACES)."""
-    px = (not exact) and B * F >= 262144 and (S >= 512 or not (rgb and alpha) or F >= 8192) and S <= (1024 if rgb else 3072)
-    return 'k_bpm_px' if px else 'k_bpm_fast'
+    """Which of K6's two band kernels the library launched for the rgb + alpha stage call of this shape that time_stages()
+    timed through the measurement build (nr_profile_band_kernel_which: the library picks per launch, csrc/nr_backward_pixel_map.hip
+    run_backward_pixel_map).  Without a measurement of that shape: the kernel of small launches."""
+    return time_stages.band_kernel.get((B, F, S, bool(exact)), 'k_bpm_fast')
 
 
 def algorithmic_bytes(B, F, S, ts):
@@ -310,11 +310,16 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flag
                     ms = plib.nr_profile_band_kernel_ms()
                     if ms >= 0:
                         samples.append(ms * 1e3)
+                        # (which of the two band kernels the library picked for this call: asked, not re-derived)
+                        time_stages.band_kernel[(B, F, S, bool(k6_flags & 2))] = ('k_bpm_fast', 'k_bpm_px')[plib.nr_profile_band_kernel_which() == 1]
             finally:
                 plib.nr_profile_band_kernel(0)
             if samples:
                 out[key] = sum(samples) / len(samples)
     return out
+
+
+time_stages.band_kernel = {}
 
 
 def time_step(step, dev, steps, warmup):

@@ -23,6 +23,8 @@ extern "C" {
  * thread-safe, and the two event packets cost the stream a few microseconds per call: off outside measurements. */
 int nr_profile_band_kernel(int32_t enable);
 float nr_profile_band_kernel_ms(void);
+/* which band kernel the last bracketed launch was: 0 k_bpm_fast, 1 k_bpm_px (-1: none) -- the library picks per launch */
+int nr_profile_band_kernel_which(void);
 
 #ifdef __cplusplus
 }

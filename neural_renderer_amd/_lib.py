@@ -104,6 +104,7 @@ def load():
 PROFILE_SIGNATURES = {
     'nr_profile_band_kernel': (_c.c_int, [_i32]),
     'nr_profile_band_kernel_ms': (_c.c_float, []),
+    'nr_profile_band_kernel_which': (_c.c_int, []),
 }
 _profile_lib = None
 

@@ -1894,6 +1894,7 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
 namespace {
 struct BandKernelTimer {
     bool on = false, recorded = false;
+    int which = -1;  // the bracketed launch: 0 k_bpm_fast, 1 k_bpm_px
     hipEvent_t start = nullptr, stop = nullptr;
 } g_band_timer;
 }  // namespace
@@ -1922,7 +1923,8 @@ NR_API float nr_profile_band_kernel_ms(void)
     }
     return ms;
 }
-#define NR_BAND_TIMER_START(st) if (g_band_timer.on) g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess
+NR_API int nr_profile_band_kernel_which(void) { return g_band_timer.recorded ? g_band_timer.which : -1; }
+#define NR_BAND_TIMER_START(st) if (g_band_timer.on) { g_band_timer.which = use_px ? 1 : 0; g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess; }
 #define NR_BAND_TIMER_STOP(st) if (g_band_timer.on && g_band_timer.recorded) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess
 #else
 #define NR_BAND_TIMER_START(st) ((void)0)
@@ -1962,20 +1964,30 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const int W_fast = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
     // Two band kernels serve the default arithmetic mode on line records (same per-pixel terms): k_bpm_fast (a piece of a sweep
     // per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
-    // was measured (profiles/r05_k6_kernels.md: whole steps, same process): k_bpm_px wins on large launches of small faces --
-    // >= 2^18 faces in the call -- when the raster is 512 or more (teapot, 64 views, rgb: 0.97 vs 1.25 ms), when only one of
-    // rgb / alpha is asked for (256^2: 0.335 vs 0.367 / 0.242 vs 0.253), or when the meshes are dense (config 4: 0.74 vs 0.79);
-    // k_bpm_fast keeps the headline shape (rgb + alpha at 256^2: 0.354 vs 0.365), small launches (8-32 views: 7 % faster) and
-    // large faces (4 views at 1024^2: k_bpm_px walks an in sweep with one lane).  NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one
-    // of them (tests, measurements).  The exact mode, the scan path and rasters beyond k_bpm_px's LDS band are k_bpm_fast's.
+    // was measured (profiles/r05_k6_kernels.md: whole steps and K6 stage calls, same process).  k_bpm_px is a kernel for large
+    // launches (>= 2^18 faces in the call) of small faces (on average <= 64 pixels of the raster per face: it walks an in sweep
+    // with one lane -- 32 teapot views at 1024^2: 7.2 vs 2.0 ms) whose lines fill its groups of 256 pixels (a raster of 384 or
+    // 576 leaves a third of the last group's lanes idle: +11 ... +17 %).  There it wins when only the colour gradient is asked
+    // for (teapot, 64 views: 320^2 ... 576^2 -6 ... -31 %, 256^2 0.326 vs 0.371 ms a step: k_bpm_fast's colour-only instance is
+    // its slowest), at the reference's default raster 512 (rgb 0.94 vs 1.21 ms, silhouettes 0.69 vs 0.73, all outputs 1.02 vs
+    // 1.07), and up to raster 256 for silhouettes (0.243 vs 0.257), dense meshes (config 4: 0.73 vs 0.79) and very large
+    // batches (128 views: 366 vs 384 us); k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at
+    // 0.359 ms) and small launches (8-32 views: 4 % faster).  NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests,
+    // measurements).  The exact mode, the scan path and rasters beyond k_bpm_px's LDS band are k_bpm_fast's.
     // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
     // (eps must be positive as a float: a lane outside a sweep multiplies 0 by 1 / (|c t| + eps), and t = 0 -- the crossing
     // point on a pixel centre -- would make that 0 * Inf)
     size_t px_lds = 0;
     const bool px_possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY)) && B <= 65535 && S <= 3072 && W_fast != 0 &&
                              (float)eps >= 1e-30f;
-    const bool px_wanted = (flags & NR_FLAG_K6_PX) ||
-                           ((size_t)B * F >= k6::PX_MIN_FACES && (S >= 512 || !(rgb && alpha) || F >= k6::PX_DENSE_FACES));
+    const size_t call_faces = (size_t)B * F;
+    const int px_groups = (S + pxk::GROUP - 1) / pxk::GROUP;
+    const bool px_small_faces = (size_t)F * 64 >= (size_t)S * S;
+    const bool px_full_groups = S <= pxk::GROUP || (size_t)(px_groups * pxk::GROUP - S) * 7 <= (size_t)S;
+    const bool px_wanted =
+        (flags & NR_FLAG_K6_PX) ||
+        (call_faces >= k6::PX_MIN_FACES && px_small_faces &&
+         (!alpha || (px_full_groups && (S > pxk::GROUP || !rgb || F >= k6::PX_DENSE_FACES || call_faces >= 2 * k6::PX_MIN_FACES))));
     const int W_px = px_possible && px_wanted ? px_band_config(S, rgb, B, &px_lds) : 0;
     const bool use_px = W_px > 0;
     const int W = use_px ? 1 : W_fast;  // the band width of the tables

@@ -55,10 +55,10 @@
 #define NR_PX_MIN_WGS 8192
 #endif
 
-#ifndef NR_PX_MIN_FACES     // k_bpm_px is considered from this many faces in the call (batch x faces) on
-#define NR_PX_MIN_FACES 262144
+#ifndef NR_PX_MIN_FACES     // k_bpm_px is considered from this many faces in the call (batch x faces) on; with both gradients up to
+#define NR_PX_MIN_FACES 262144  // raster 256 from twice as many (run_backward_pixel_map: the rule and what it was measured on)
 #endif
-#ifndef NR_PX_DENSE_FACES   // ... and taken for rgb + alpha at rasters below 512 only from this many faces per image on
+#ifndef NR_PX_DENSE_FACES   // ... or from this many faces per image on
 #define NR_PX_DENSE_FACES 8192
 #endif
 

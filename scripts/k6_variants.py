@@ -34,25 +34,26 @@ for shape in os.environ.get('SHAPES', '8x256 16x256 32x256 64x256').split():
         gt = torch.empty_like(textures)
         wsb = lib.nr_backward_workspace_bytes(B, F, S, 1, 1)
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
-        kfl = int(os.environ.get('K6V_FLAGS', 0))  # e.g. 128: NR_FLAG_K6_LEGACY
-        calls = {
-            'k6': lambda: lib.nr_backward_pixel_map(faces.data_ptr(), r.face_index_map.data_ptr(), r.rgb_map.data_ptr(),
-                                                    r.alpha_map.data_ptr(), g_rgb.data_ptr(), g_alpha.data_ptr(), gf.data_ptr(), B, F,
-                                                    S, 1e-3, 1, 1, kfl, r.visible.data_ptr(), ws.data_ptr(), wsb, st),
-            'bwd': lambda: lib.nr_backward_rasterize(faces.data_ptr(), None, r.face_index_map.data_ptr(), r.weight_map.data_ptr(),
-                                                     r.depth_map.data_ptr(), r.rgb_map.data_ptr(), r.alpha_map.data_ptr(),
-                                                     g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(),
-                                                     gt.data_ptr(), B, F, S, ts, 1e-3, kfl, r.visible.data_ptr(), ws.data_ptr(), wsb, st)}
-        for name, call in calls.items():
-            for _ in range(3):
-                _lib.check(call(), name)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                call()
-            e1.record()
-            torch.cuda.synchronize()
-            row['%s_%s' % (tag or 'product', name)] = round(e0.elapsed_time(e1) * 1e3 / iters, 1)
+        m_rgb, m_alpha = (int(c) for c in os.environ.get('K6V_MODE', '11'))  # which gradients the K6 stage call gets: rgb, alpha
+        for kfl in [int(x) for x in os.environ.get('K6V_FLAGS', '0').split()]:  # e.g. "128 65536": NR_FLAG_K6_LEGACY, NR_FLAG_K6_PX
+            calls = {
+                'k6': lambda: lib.nr_backward_pixel_map(faces.data_ptr(), r.face_index_map.data_ptr(), r.rgb_map.data_ptr(),
+                                                        r.alpha_map.data_ptr(), g_rgb.data_ptr(), g_alpha.data_ptr(), gf.data_ptr(), B, F,
+                                                        S, 1e-3, m_rgb, m_alpha, kfl, r.visible.data_ptr(), ws.data_ptr(), wsb, st),
+                'bwd': lambda: lib.nr_backward_rasterize(faces.data_ptr(), None, r.face_index_map.data_ptr(), r.weight_map.data_ptr(),
+                                                         r.depth_map.data_ptr(), r.rgb_map.data_ptr(), r.alpha_map.data_ptr(),
+                                                         g_rgb.data_ptr(), g_alpha.data_ptr(), g_depth.data_ptr(), gf.data_ptr(),
+                                                         gt.data_ptr(), B, F, S, ts, 1e-3, kfl, r.visible.data_ptr(), ws.data_ptr(), wsb, st)}
+            for name, call in calls.items():
+                for _ in range(3):
+                    _lib.check(call(), name)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    call()
+                e1.record()
+                torch.cuda.synchronize()
+                row['%s_%s%s' % (tag or 'product', name, '_f%d' % kfl if kfl else '')] = round(e0.elapsed_time(e1) * 1e3 / iters, 1)
     print(json.dumps(row), flush=True)
 use_library('')

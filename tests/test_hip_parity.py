@@ -1212,8 +1212,12 @@ def test_band_kernel_timing_hook():
         t_fused = lib.nr_profile_band_kernel_ms()
         abi.backward(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
         t_staged = lib.nr_profile_band_kernel_ms()
-        abi.backward(fw, g_rgb, g_alpha, None)  # (the default mode's band kernel, k_bpm_px, is bracketed as well)
+        assert lib.nr_profile_band_kernel_which() == 0  # (the exact mode: k_bpm_fast)
+        abi.backward(fw, g_rgb, g_alpha, None, k6_flags=K6_PX)  # (k_bpm_px is bracketed as well, and named)
         t_px = lib.nr_profile_band_kernel_ms()
+        assert lib.nr_profile_band_kernel_which() == 1
+        abi.backward(fw, g_rgb, g_alpha, None)  # (a launch this small: the library picks k_bpm_fast)
+        assert lib.nr_profile_band_kernel_ms() > 0 and lib.nr_profile_band_kernel_which() == 0
     finally:
         lib.nr_profile_band_kernel(0)
         _lib._lib = prev
