@@ -1436,7 +1436,10 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
     px.c = (float *)carve((size_t)W * SP * NC * 4);
     px.bg = nullptr; px.cov = nullptr; px.CW = 0; px.span = nullptr;
     double *s_acc = (double *)carve((size_t)NW * WIN * 16);
-    const int n_groups = (S + GROUP - 1) / GROUP;
+    // a line longer than one group of GROUP pixels is cut into n_groups EQUAL runs of whole chunks (raster 384: 2 x 192, not
+    // 256 + 128 -- the waves of a workgroup finish together)
+    // (four runs instead of three for a one-line band of 576 ... 768 pixels, so that no wave idles, was measured: 0 ... +9 %)
+    const int n_groups = (S + GROUP - 1) / GROUP, gpx = (((S + n_groups - 1) / n_groups) + 63) & ~63;
     // A band narrower than the workgroup has waves (small launches: the host narrows the bands to have enough workgroups) deals
     // the records of a line to n_parts waves, in runs of WIN / n_parts: the critical path of a workgroup is its longest line.
     const int n_parts = max(1, NW / (W * n_groups)), sub_win = WIN / n_parts;
@@ -1468,7 +1471,7 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
         const int n_rec = band_lines[lt + ld];
         if (n_rec == 0) continue;
         const BandLine *recs = recs_b + band_start[lt + ld];
-        const int base = ld * SP, gb = grp * GROUP;
+        const int base = ld * SP, gb = grp * gpx;
         // ---- the group's pixels: gradients, colours, coordinate (a lane beyond the line repeats the last pixel; no mask reaches it)
         // PDOT: sum_c (I_c - ref_c) g_c = sum_c I_c g_c - sum_c ref_c g_c -- the first sum is a property of the pixel (pq, formed
         // once per group in double and rounded once), the second one fused multiply-add per channel on top of it: four
@@ -1509,14 +1512,14 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
             }
             const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
             const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
-            const bool has_out = o_from <= o_to && o_to >= gb && o_from < gb + GROUP;  // (:604: the in pixel is the face's)
+            const bool has_out = o_from <= o_to && o_to >= gb && o_from < gb + gpx;  // (:604: the in pixel is the face's)
             float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (has_out) {
                 if constexpr (RGB) oref = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)(base + d1_in));
                 else oref.x = px.c[base + d1_in];
             }
             // the sweep inside this group: first pixel, last pixel (relative to the group), chunks touched
-            const int rel_from = max(o_from - gb, 0), rel_to = min(o_to - gb, GROUP - 1);
+            const int rel_from = max(o_from - gb, 0), rel_to = min(o_to - gb, gpx - 1);
             const int pk = has_out ? (rel_from | (rel_to - rel_from) << 8 | ((2 << (rel_to >> 6)) - (1 << (rel_from >> 6))) << 16) : 0;
             double in0 = 0.0, in1 = 0.0;
             if (grp == 0) {
@@ -1839,7 +1842,9 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     // 1-D grid: the kernel maps ids to (image, axis, band) per XCD
-    const unsigned grid = overflow_only ? (total_wg < 256u ? total_wg : 256u) : xcd_grid(total_wg);
+    // (overflow-only launch behind k_bpm_px: a resident grid that strides over the bands.  1024 workgroups: with nothing to do
+    // it costs ~4 us (256: ~3), with every image over the line buffer -- 32 teapot views at 1024^2 -- 5.0 instead of 7.3 ms)
+    const unsigned grid = overflow_only ? (total_wg < k6::OVF_GRID ? total_wg : k6::OVF_GRID) : xcd_grid(total_wg);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
                        eps, k2s, B, win_lines, qcap, (uint4 *)zero_ptr, zero_bytes / 16);
@@ -1966,14 +1971,15 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     // per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
     // was measured (profiles/r05_k6_kernels.md: whole steps and K6 stage calls, same process).  k_bpm_px is a kernel for large
     // launches (>= 2^18 faces in the call) of small faces (on average <= 64 pixels of the raster per face: it walks an in sweep
-    // with one lane -- 32 teapot views at 1024^2: 7.2 vs 2.0 ms) whose lines fill its groups of 256 pixels (a raster of 384 or
-    // 576 leaves a third of the last group's lanes idle: +11 ... +17 %).  There it wins when only the colour gradient is asked
-    // for (teapot, 64 views: 320^2 ... 576^2 -6 ... -31 %, 256^2 0.326 vs 0.371 ms a step: k_bpm_fast's colour-only instance is
-    // its slowest), at the reference's default raster 512 (rgb 0.94 vs 1.21 ms, silhouettes 0.69 vs 0.73, all outputs 1.02 vs
-    // 1.07), and up to raster 256 for silhouettes (0.243 vs 0.257), dense meshes (config 4: 0.73 vs 0.79) and very large
-    // batches (128 views: 366 vs 384 us); k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at
-    // 0.359 ms) and small launches (8-32 views: 4 % faster).  NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests,
-    // measurements).  The exact mode, the scan path and rasters beyond k_bpm_px's LDS band are k_bpm_fast's.
+    // with one lane -- 32 teapot views at 1024^2: 7.2 vs 2.0 ms) on rasters up to 512 (beyond, its bands are one line wide and
+    // the staging of single columns costs more than its visits save: 576^2 +16 %, 768^2 +10 %; at 320^2 ... 384^2 +6 ... +10 %).
+    // There it wins when only the colour gradient is asked for (teapot, 64 views: 320^2 ... 640^2 -10 ... -32 %, 256^2 0.326
+    // vs 0.371 ms a step: k_bpm_fast's colour-only instance is its slowest), at the reference's default raster 512 and just
+    // below (rgb 0.94 vs 1.21 ms, silhouettes 0.69 vs 0.73, all outputs 1.02 vs 1.07), and up to raster 256 for silhouettes (0.243
+    // vs 0.257), dense meshes (config 4: 0.73 vs 0.79) and very large batches (128 views: 366 vs 384 us); k_bpm_fast keeps
+    // the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms) and small launches (8-32 views: 4 % faster).
+    // NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
+    // beyond k_bpm_px's LDS band are k_bpm_fast's.
     // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
     // (eps must be positive as a float: a lane outside a sweep multiplies 0 by 1 / (|c t| + eps), and t = 0 -- the crossing
     // point on a pixel centre -- would make that 0 * Inf)
@@ -1981,13 +1987,12 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const bool px_possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY)) && B <= 65535 && S <= 3072 && W_fast != 0 &&
                              (float)eps >= 1e-30f;
     const size_t call_faces = (size_t)B * F;
-    const int px_groups = (S + pxk::GROUP - 1) / pxk::GROUP;
     const bool px_small_faces = (size_t)F * 64 >= (size_t)S * S;
-    const bool px_full_groups = S <= pxk::GROUP || (size_t)(px_groups * pxk::GROUP - S) * 7 <= (size_t)S;
+    const bool px_good_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP);  // (one group, or two nearly full ones)
     const bool px_wanted =
         (flags & NR_FLAG_K6_PX) ||
         (call_faces >= k6::PX_MIN_FACES && px_small_faces &&
-         (!alpha || (px_full_groups && (S > pxk::GROUP || !rgb || F >= k6::PX_DENSE_FACES || call_faces >= 2 * k6::PX_MIN_FACES))));
+         (!alpha || (px_good_raster && (S > pxk::GROUP || !rgb || F >= k6::PX_DENSE_FACES || call_faces >= 2 * k6::PX_MIN_FACES))));
     const int W_px = px_possible && px_wanted ? px_band_config(S, rgb, B, &px_lds) : 0;
     const bool use_px = W_px > 0;
     const int W = use_px ? 1 : W_fast;  // the band width of the tables

@@ -51,6 +51,9 @@
 #ifndef NR_PX_RED_LEVELS    // k_bpm_px: DPP levels (float) of a record's two sums before the LDS atomics in double take over (4: rows of 16 lanes, 3: of 8 -- same time, errors 5 % lower; 2: +12 %)
 #define NR_PX_RED_LEVELS 3
 #endif
+#ifndef NR_K6_OVF_GRID      // workgroups of k_bpm_fast's overflow-only launch behind k_bpm_px (images whose records exceed the line buffer)
+#define NR_K6_OVF_GRID 1024
+#endif
 #ifndef NR_PX_MIN_WGS       // k_bpm_px: bands are narrowed (4 -> 2 -> 1 lines) while the launch has fewer band workgroups than this
 #define NR_PX_MIN_WGS 8192
 #endif
@@ -86,6 +89,7 @@ constexpr unsigned long PX_MIN_FACES = NR_PX_MIN_FACES;
 constexpr int PX_DENSE_FACES = NR_PX_DENSE_FACES;
 constexpr bool PX_PDOT = NR_PX_PDOT != 0;
 constexpr int PX_RED_LEVELS = NR_PX_RED_LEVELS;
+constexpr unsigned OVF_GRID = NR_K6_OVF_GRID;
 constexpr unsigned long SHARED_LAUNCH_MAX_FACES = NR_SHARED_LAUNCH_MAX_FACES;
 }  // namespace k6
 }  // namespace nr

@@ -20,7 +20,18 @@ variants = [''] + os.environ.get('VARIANTS', '').split()
 for shape in os.environ.get('SHAPES', '8x256 16x256 32x256 64x256').split():
     B, S = (int(x) for x in shape.split('x'))
     use_library('')
-    faces, textures = bench.build_scene(dev, B, 0, 64 if B <= 64 else B, S, 2)
+    if os.environ.get('K6V_MESH', '').startswith('ico'):  # K6V_MESH=ico3: spheres of 20 * 4^3 faces (fill_back: twice that), random rotations
+        import numpy as np
+        v0, f0 = bench.icosphere(int(os.environ['K6V_MESH'][3:]))
+        rng = np.random.default_rng(5)
+        verts = np.stack([(0.75 * v0) @ np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32) for _ in range(B)]).astype(np.float32)
+        fi_ = torch.from_numpy(f0).to(dev)[None].repeat(B, 1, 1)
+        fi_ = torch.cat((fi_, torch.flip(fi_, dims=[2])), dim=1)
+        eye = torch.tensor([[0.3, 0.4, -2.6]], dtype=torch.float32, device=dev).repeat(B, 1)
+        faces = nr.vertices_to_faces(nr.perspective(nr.look_at(torch.from_numpy(verts).to(dev), eye), 30.), fi_).contiguous()
+        textures = torch.from_numpy(rng.uniform(0, 1, (B, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)).to(dev)
+    else:
+        faces, textures = bench.build_scene(dev, B, 0, 64 if B <= 64 else B, S, 2)
     F, ts = faces.shape[1], 2
     g_rgb, g_alpha, g_depth = bench.upstream_gradients(faces, textures, S, 1e-3, 1234)
     fn = nr.Rasterize(S, 0.1, 100, 1e-3, (0, 0, 0), True, True, True)
