@@ -1709,7 +1709,17 @@ struct BpmLayout {
 
 // capacity (line records per image) of the band line buffer: a mesh has a few lines per face (teapot 3.8, dense meshes ~2);
 // scenes of few large faces are covered by the S term.  Images beyond it take the scan path of k_bpm_fast.
-size_t line_capacity(int F, int S) { return (size_t)8 * F + (size_t)32 * S; }
+size_t line_capacity(int F, int S)
+{
+    // + S sqrt(F): a mesh whose V visible faces tile a fixed share of the image has ~ sqrt(V) S records (teapot views: ~100 k at
+    // 1024^2, over 8 F + 32 S from raster ~600 on: the scan path cost k_bpm_fast 30 % there and k_bpm_px -- whose overflow launch
+    // strides over one-line bands -- a factor)
+    const size_t want = (size_t)8 * F + (size_t)32 * S + (size_t)((double)S * sqrt((double)F));
+    // (the images' buffers follow one another: a stride near a multiple of 2 MiB -- 65 579 records x 32 B at the headline shape --
+    // puts the same band of every image on the same memory channels and cost k_line_setup 3 us of 25; the stride is kept at
+    // 34 KiB past a multiple of 64 KiB)
+    return (want + 2047 - 1088) / 2048 * 2048 + 1088;
+}
 
 BpmLayout bpm_layout(int B, int F, int S)
 {
@@ -1969,15 +1979,19 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const int W_fast = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
     // Two band kernels serve the default arithmetic mode on line records (same per-pixel terms): k_bpm_fast (a piece of a sweep
     // per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
-    // was measured (profiles/r05_k6_kernels.md: whole steps and K6 stage calls, same process).  k_bpm_px is a kernel for large
-    // launches (>= 2^18 faces in the call) of small faces (on average <= 64 pixels of the raster per face: it walks an in sweep
-    // with one lane -- 32 teapot views at 1024^2: 7.2 vs 2.0 ms) on rasters up to 512 (beyond, its bands are one line wide and
-    // the staging of single columns costs more than its visits save: 576^2 +16 %, 768^2 +10 %; at 320^2 ... 384^2 +6 ... +10 %).
-    // There it wins when only the colour gradient is asked for (teapot, 64 views: 320^2 ... 640^2 -10 ... -32 %, 256^2 0.326
-    // vs 0.371 ms a step: k_bpm_fast's colour-only instance is its slowest), at the reference's default raster 512 and just
-    // below (rgb 0.94 vs 1.21 ms, silhouettes 0.69 vs 0.73, all outputs 1.02 vs 1.07), and up to raster 256 for silhouettes (0.243
-    // vs 0.257), dense meshes (config 4: 0.73 vs 0.79) and very large batches (128 views: 366 vs 384 us); k_bpm_fast keeps
-    // the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms) and small launches (8-32 views: 4 % faster).
+    // was measured (profiles/r05_k6_kernels.md: whole steps and K6 stage calls of 64 teapot views at rasters 256 ... 1024 in the
+    // three gradient modes, config 4 / 5, low-poly spheres; same process).  k_bpm_px is a kernel for large launches (>= 2^18
+    // faces in the call) whose images stay inside the line buffer (an image beyond it goes to the overflow-only launch of
+    // k_bpm_fast on one-line bands: 2.5 x slower than k_bpm_fast's own handling -- so a pessimistic estimate of the records,
+    // a mesh that fills the image, has to fit).  There it wins
+    //   * whenever only the colour gradient is asked for (-10 ... -32 % at every raster: k_bpm_fast's colour-only instance is its
+    //     slowest; 256^2: 0.326 vs 0.371 ms a step);
+    //   * with alpha involved: at the reference's default raster 512 and just below (448 ... 512: rgb + alpha -5 %, silhouettes
+    //     -6 ... -9 %; all outputs 1.00 vs 1.07 ms a step) and with colours from 640 on (-4 ... -19 %), but not at 320 ... 384 and
+    //     576 (+4 ... +17 %);
+    //   * up to raster 256: silhouettes (0.243 vs 0.257 ms a step), dense meshes (config 4: 0.73 vs 0.79), very large batches
+    //     (128 views: 366 vs 384 us); k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a
+    //     step) and small launches (8-32 views: 4 % faster).
     // NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
     // beyond k_bpm_px's LDS band are k_bpm_fast's.
     // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
@@ -1987,12 +2001,12 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const bool px_possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY)) && B <= 65535 && S <= 3072 && W_fast != 0 &&
                              (float)eps >= 1e-30f;
     const size_t call_faces = (size_t)B * F;
-    const bool px_small_faces = (size_t)F * 64 >= (size_t)S * S;
-    const bool px_good_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP);  // (one group, or two nearly full ones)
+    const bool px_fits = 2.1 * sqrt((double)F) * (double)S <= (double)line_capacity(F, S);  // (~6 sqrt(coverage x visible faces) S records)
+    const bool px_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP) || (rgb && S >= 640);
     const bool px_wanted =
         (flags & NR_FLAG_K6_PX) ||
-        (call_faces >= k6::PX_MIN_FACES && px_small_faces &&
-         (!alpha || (px_good_raster && (S > pxk::GROUP || !rgb || F >= k6::PX_DENSE_FACES || call_faces >= 2 * k6::PX_MIN_FACES))));
+        (call_faces >= k6::PX_MIN_FACES && px_fits &&
+         (!alpha || (px_raster && (S > pxk::GROUP || !rgb || F >= k6::PX_DENSE_FACES || call_faces >= 2 * k6::PX_MIN_FACES))));
     const int W_px = px_possible && px_wanted ? px_band_config(S, rgb, B, &px_lds) : 0;
     const bool use_px = W_px > 0;
     const int W = use_px ? 1 : W_fast;  // the band width of the tables

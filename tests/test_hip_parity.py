@@ -376,6 +376,36 @@ def test_big_triangles_long_sweeps():
     check_backward(faces, textures, 256, 1e-3, (True, True, False), seed=12)
 
 
+def test_line_buffer_overflow_in_some_images_of_a_batch():
+    """Images whose line records exceed the buffer (8 F + 32 S + S sqrt(F) per image) beside images that fit: 120 faces that
+    span most of a 128 x 128 image have tens of thousands of records against a capacity of ~6 400, the image between them a
+    handful.  k_bpm_fast walks such an image by its in-kernel face scan inside the normal grid; behind k_bpm_px the overflow-only
+    launch of k_bpm_fast takes it (check_backward runs both kernels by name, and the exact mode)."""
+    rng = np.random.default_rng(321)
+    big = H.random_scene(rng, 3, 120, spread=0.4, size=1.2)
+    small = H.random_scene(rng, 3, 120, spread=0.5, size=0.05)
+    faces = np.stack((big[0], small[1], big[2]))
+    textures = rng.uniform(0, 1, (3, 120, 2, 2, 2, 3)).astype(np.float32)
+    S, F = 128, 120
+    # the records of an image: one per visible face, edge, axis and integer line inside the edge's extent (rasterize.py:567-569)
+    fn = oracle_forward(faces, textures, S, 0.1, 100, 1e-3, (0.2, 0.4, 0.6), True, True, False)
+    capacity = 8 * F + 32 * S + int(S * np.sqrt(F))
+    records = []
+    for b in range(3):
+        vis = np.unique(fn.face_index_map[b][fn.face_index_map[b] >= 0])
+        p = (faces[b, vis, :, :2].astype(np.float64) * S + S - 1) / 2  # [V, 3, 2] pixel coordinates
+        n = 0
+        for e in range(3):
+            for ax in range(2):
+                lo = np.maximum(np.ceil(np.minimum(p[:, e, ax], p[:, (e + 1) % 3, ax])), 0)
+                hi = np.minimum(np.floor(np.maximum(p[:, e, ax], p[:, (e + 1) % 3, ax])), S - 1)
+                n += int(np.maximum(hi - lo + 1, 0).sum())
+        records.append(n)
+    assert min(records[0], records[2]) > 1.5 * capacity and records[1] < capacity // 2, (records, capacity)
+    check_backward(faces, textures, S, 1e-3, (True, True, False), seed=322)
+    check_backward(faces, textures, S, 1e-3, (True, False, False), seed=323)
+
+
 @pytest.mark.parametrize('ts,eps', [(2, 1e-3), (2, 1e-10), (3, 1e-3), (6, 1e-3), (9, 1e-3)])
 def test_big_faces_every_gather_path(ts, eps):
     """Screen-filling faces mixed with small ones: their texture / depth gradients come from k_backward_big (a workgroup per
