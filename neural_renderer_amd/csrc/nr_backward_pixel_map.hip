@@ -1776,6 +1776,11 @@ struct BandShape {
 BandShape band_shape(int S)
 {
     if (S <= k6::SMALL_RASTER_MAX) return {256, 2, (size_t)40 * 1024};  // four workgroups per 160 KB CU
+    // rasters of ~600 ... 830: a two-line band no longer fits 53 KB beside a useful line window, and a one-line band stages single
+    // columns (64 teapot views, K6 stage: 576^2 857 us -> 608^2 1242, 640^2 1461); with 80 KB -- two workgroups per CU, still four
+    // waves per SIMD -- the band stays two lines wide: 640^2 1061, 768^2 1574 -> 1400 (at 512^2 / 576^2 / 1024^2 the same budget
+    // costs 5 ... 15 %: there the band width does not change)
+    if (S > k6::WIDE_BUDGET_FROM && S <= k6::WIDE_BUDGET_TO) return {512, k6::WMAX, (size_t)80 * 1024};
     return {512, k6::WMAX, k6::LDS_BUDGET};
 }
 
@@ -1987,8 +1992,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     //   * whenever only the colour gradient is asked for (-10 ... -32 % at every raster: k_bpm_fast's colour-only instance is its
     //     slowest; 256^2: 0.326 vs 0.371 ms a step);
     //   * with alpha involved: at the reference's default raster 512 and just below (448 ... 512: rgb + alpha -5 %, silhouettes
-    //     -6 ... -9 %; all outputs 1.00 vs 1.07 ms a step) and with colours from 640 on (-4 ... -19 %), but not at 320 ... 384 and
-    //     576 (+4 ... +17 %);
+    //     -6 ... -9 %; all outputs 1.00 vs 1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with
+    //     its two-line bands of band_shape: +5 ... +15 %; 896^2 ... 1024^2 +5 ... -8 %);
     //   * up to raster 256: silhouettes (0.243 vs 0.257 ms a step), dense meshes (config 4: 0.73 vs 0.79), very large batches
     //     (128 views: 366 vs 384 us); k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a
     //     step) and small launches (8-32 views: 4 % faster).
@@ -2002,7 +2007,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
                              (float)eps >= 1e-30f;
     const size_t call_faces = (size_t)B * F;
     const bool px_fits = 2.1 * sqrt((double)F) * (double)S <= (double)line_capacity(F, S);  // (~6 sqrt(coverage x visible faces) S records)
-    const bool px_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP) || (rgb && S >= 640);
+    const bool px_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP);
     const bool px_wanted =
         (flags & NR_FLAG_K6_PX) ||
         (call_faces >= k6::PX_MIN_FACES && px_fits &&

@@ -51,6 +51,12 @@
 #ifndef NR_PX_RED_LEVELS    // k_bpm_px: DPP levels (float) of a record's two sums before the LDS atomics in double take over (4: rows of 16 lanes, 3: of 8 -- same time, errors 5 % lower; 2: +12 %)
 #define NR_PX_RED_LEVELS 3
 #endif
+#ifndef NR_K6_WIDE_BUDGET_FROM  // rasters in (FROM, TO]: the 512-thread shape with 80 KB of LDS per workgroup (band_shape)
+#define NR_K6_WIDE_BUDGET_FROM 576
+#endif
+#ifndef NR_K6_WIDE_BUDGET_TO
+#define NR_K6_WIDE_BUDGET_TO 832
+#endif
 #ifndef NR_K6_OVF_GRID      // workgroups of k_bpm_fast's overflow-only launch behind k_bpm_px (images whose records exceed the line buffer)
 #define NR_K6_OVF_GRID 1024
 #endif
@@ -90,6 +96,7 @@ constexpr int PX_DENSE_FACES = NR_PX_DENSE_FACES;
 constexpr bool PX_PDOT = NR_PX_PDOT != 0;
 constexpr int PX_RED_LEVELS = NR_PX_RED_LEVELS;
 constexpr unsigned OVF_GRID = NR_K6_OVF_GRID;
+constexpr int WIDE_BUDGET_FROM = NR_K6_WIDE_BUDGET_FROM, WIDE_BUDGET_TO = NR_K6_WIDE_BUDGET_TO;
 constexpr unsigned long SHARED_LAUNCH_MAX_FACES = NR_SHARED_LAUNCH_MAX_FACES;
 }  // namespace k6
 }  // namespace nr
