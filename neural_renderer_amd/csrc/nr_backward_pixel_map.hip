@@ -1994,9 +1994,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     //   * with alpha involved: at the reference's default raster 512 and just below (448 ... 512: rgb + alpha -5 %, silhouettes
     //     -6 ... -9 %; all outputs 1.00 vs 1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with
     //     its two-line bands of band_shape: +5 ... +15 %; 896^2 ... 1024^2 +5 ... -8 %);
-    //   * up to raster 256: silhouettes (0.243 vs 0.257 ms a step), dense meshes (config 4: 0.73 vs 0.79), very large batches
-    //     (128 views: 366 vs 384 us); k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a
-    //     step) and small launches (8-32 views: 4 % faster).
+    //   * on dense meshes (>= 8192 faces per image) at every raster (config 4: 0.73 vs 0.79 ms a step; config 5, 655 360 faces at
+    //     1024^2: 397 vs 533 us);
+    //   * up to raster 256: silhouettes (0.243 vs 0.257 ms a step) and very large batches (128 views: 366 vs 384 us);
+    //     k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a step) and small launches
+    //     (8-32 views: 4 % faster).
     // NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
     // beyond k_bpm_px's LDS band are k_bpm_fast's.
     // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
@@ -2011,7 +2013,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     const bool px_wanted =
         (flags & NR_FLAG_K6_PX) ||
         (call_faces >= k6::PX_MIN_FACES && px_fits &&
-         (!alpha || (px_raster && (S > pxk::GROUP || !rgb || F >= k6::PX_DENSE_FACES || call_faces >= 2 * k6::PX_MIN_FACES))));
+         (!alpha || F >= k6::PX_DENSE_FACES || (px_raster && (S > pxk::GROUP || !rgb || call_faces >= 2 * k6::PX_MIN_FACES))));
     const int W_px = px_possible && px_wanted ? px_band_config(S, rgb, B, &px_lds) : 0;
     const bool use_px = W_px > 0;
     const int W = use_px ? 1 : W_fast;  // the band width of the tables
