@@ -25,6 +25,9 @@ int nr_profile_band_kernel(int32_t enable);
 float nr_profile_band_kernel_ms(void);
 /* which band kernel the last bracketed launch was: 0 k_bpm_fast, 1 k_bpm_px (-1: none) -- the library picks per launch */
 int nr_profile_band_kernel_which(void);
+/* the per-launch rule itself, as a function of the call (host logic only, callable without a device): 1 when a default-mode call
+ * of this shape takes k_bpm_px, 0 for k_bpm_fast */
+int nr_profile_k6_choice(int32_t B, int32_t F, int32_t S, int32_t return_rgb, int32_t return_alpha, double eps, int32_t flags);
 
 #ifdef __cplusplus
 }

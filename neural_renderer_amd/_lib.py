@@ -105,6 +105,7 @@ PROFILE_SIGNATURES = {
     'nr_profile_band_kernel': (_c.c_int, [_i32]),
     'nr_profile_band_kernel_ms': (_c.c_float, []),
     'nr_profile_band_kernel_which': (_c.c_int, []),
+    'nr_profile_k6_choice': (_c.c_int, [_i32, _i32, _i32, _i32, _i32, _c.c_double, _i32]),
 }
 _profile_lib = None
 

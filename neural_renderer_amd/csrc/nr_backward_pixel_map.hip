@@ -1906,6 +1906,46 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
     return bpm_layout(B, F, S).total;
 }
 
+// Which band kernel a default-mode call takes: the band width (lines per workgroup) of k_bpm_px and its LDS bytes, or 0 for
+// k_bpm_fast.
+// Two band kernels serve the default arithmetic mode on line records (same per-pixel terms): k_bpm_fast (a piece of a sweep
+// per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
+// was measured (profiles/r05_k6_kernels.md: whole steps and K6 stage calls of 64 teapot views at rasters 256 ... 1024 in the
+// three gradient modes, config 4 / 5, low-poly spheres; same process).  k_bpm_px is a kernel for large launches (>= 2^18
+// faces in the call) whose images stay inside the line buffer (an image beyond it goes to the overflow-only launch of
+// k_bpm_fast on one-line bands: 2.5 x slower than k_bpm_fast's own handling -- so a pessimistic estimate of the records,
+// a mesh that fills the image, has to fit).  There it wins
+//   * whenever only the colour gradient is asked for (-10 ... -32 % at every raster: k_bpm_fast's colour-only instance is its
+//     slowest; 256^2: 0.326 vs 0.371 ms a step) -- there already from 2^16 faces in the call (16 views: -6 %, 32: -12 %);
+//   * with alpha involved: at the reference's default raster 512 and just below (448 ... 512: rgb + alpha -5 %, silhouettes
+//     -6 ... -9 %; all outputs 1.00 vs 1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with
+//     its two-line bands of band_shape: +5 ... +15 %; 896^2 ... 1024^2 +5 ... -8 %);
+//   * on dense meshes (>= 8192 faces per image) at every raster (config 4: 0.73 vs 0.79 ms a step; config 5, 655 360 faces at
+//     1024^2: 397 vs 533 us);
+//   * up to raster 256: silhouettes (0.243 vs 0.257 ms a step) and very large batches (128 views: 366 vs 384 us);
+//     k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a step) and small launches
+//     (8-32 views: 4 % faster).
+// NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
+// beyond k_bpm_px's LDS band are k_bpm_fast's.
+// With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
+// (eps must be positive as a float: a lane outside a sweep multiplies 0 by 1 / (|c t| + eps), and t = 0 -- the crossing
+// point on a pixel centre -- would make that 0 * Inf)
+int k6_px_band(int B, int F, int S, bool rgb, bool alpha, double eps, int flags, bool fast_fits, size_t *px_lds)
+{
+    const bool exact = (flags & NR_FLAG_EXACT_GRADIENT) != 0;
+    const bool px_possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY | NR_FLAG_K6_GLOBAL)) && B <= 65535 && S <= 3072 &&
+                             fast_fits && (float)eps >= 1e-30f;
+    const size_t call_faces = (size_t)B * F;
+    const bool px_fits = 2.1 * sqrt((double)F) * (double)S <= (double)line_capacity(F, S);  // (~6 sqrt(coverage x visible faces) S records)
+    const bool px_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP);
+    const bool px_wanted =
+        (flags & NR_FLAG_K6_PX) ||
+        (px_fits && (alpha ? call_faces >= k6::PX_MIN_FACES &&
+                                 (F >= k6::PX_DENSE_FACES || (px_raster && (S > pxk::GROUP || !rgb || call_faces >= 2 * k6::PX_MIN_FACES)))
+                           : call_faces >= k6::PX_MIN_FACES / 4));
+    return px_possible && px_wanted ? px_band_config(S, rgb, B, px_lds) : 0;
+}
+
 // Measurement hook (include/nr_hip_profile.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.  Only in the
 // measurement build of the library (libnr_hip_prof.so, -DNR_PROFILE_HOOK: neural_renderer_amd._build.build_profile); the product
 // library keeps no such state and does not export the two functions.
@@ -1944,6 +1984,15 @@ NR_API float nr_profile_band_kernel_ms(void)
     return ms;
 }
 NR_API int nr_profile_band_kernel_which(void) { return g_band_timer.recorded ? g_band_timer.which : -1; }
+// (pure host logic, no device needed: the per-launch rule as a function of the call's shape, for tests/test_abi.py)
+NR_API int nr_profile_k6_choice(int32_t B, int32_t F, int32_t S, int32_t return_rgb, int32_t return_alpha, double eps, int32_t flags)
+{
+    size_t lds = 0, fl = 0;
+    int win = 0, qcap = 0;
+    const BandShape shape = band_shape(S);
+    const bool fast_fits = fast_band_config(S, return_rgb != 0, shape, shape.w_max, &fl, &win, &qcap) != 0;
+    return k6_px_band(B, F, S, return_rgb != 0, return_alpha != 0, eps, flags, fast_fits, &lds) > 0 ? 1 : 0;
+}
 #define NR_BAND_TIMER_START(st) if (g_band_timer.on) { g_band_timer.which = use_px ? 1 : 0; g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess; }
 #define NR_BAND_TIMER_STOP(st) if (g_band_timer.on && g_band_timer.recorded) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess
 #else
@@ -1982,39 +2031,8 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     int w_max = shape.w_max;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
     const int W_fast = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
-    // Two band kernels serve the default arithmetic mode on line records (same per-pixel terms): k_bpm_fast (a piece of a sweep
-    // per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
-    // was measured (profiles/r05_k6_kernels.md: whole steps and K6 stage calls of 64 teapot views at rasters 256 ... 1024 in the
-    // three gradient modes, config 4 / 5, low-poly spheres; same process).  k_bpm_px is a kernel for large launches (>= 2^18
-    // faces in the call) whose images stay inside the line buffer (an image beyond it goes to the overflow-only launch of
-    // k_bpm_fast on one-line bands: 2.5 x slower than k_bpm_fast's own handling -- so a pessimistic estimate of the records,
-    // a mesh that fills the image, has to fit).  There it wins
-    //   * whenever only the colour gradient is asked for (-10 ... -32 % at every raster: k_bpm_fast's colour-only instance is its
-    //     slowest; 256^2: 0.326 vs 0.371 ms a step);
-    //   * with alpha involved: at the reference's default raster 512 and just below (448 ... 512: rgb + alpha -5 %, silhouettes
-    //     -6 ... -9 %; all outputs 1.00 vs 1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with
-    //     its two-line bands of band_shape: +5 ... +15 %; 896^2 ... 1024^2 +5 ... -8 %);
-    //   * on dense meshes (>= 8192 faces per image) at every raster (config 4: 0.73 vs 0.79 ms a step; config 5, 655 360 faces at
-    //     1024^2: 397 vs 533 us);
-    //   * up to raster 256: silhouettes (0.243 vs 0.257 ms a step) and very large batches (128 views: 366 vs 384 us);
-    //     k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a step) and small launches
-    //     (8-32 views: 4 % faster).
-    // NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
-    // beyond k_bpm_px's LDS band are k_bpm_fast's.
-    // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
-    // (eps must be positive as a float: a lane outside a sweep multiplies 0 by 1 / (|c t| + eps), and t = 0 -- the crossing
-    // point on a pixel centre -- would make that 0 * Inf)
     size_t px_lds = 0;
-    const bool px_possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY)) && B <= 65535 && S <= 3072 && W_fast != 0 &&
-                             (float)eps >= 1e-30f;
-    const size_t call_faces = (size_t)B * F;
-    const bool px_fits = 2.1 * sqrt((double)F) * (double)S <= (double)line_capacity(F, S);  // (~6 sqrt(coverage x visible faces) S records)
-    const bool px_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP);
-    const bool px_wanted =
-        (flags & NR_FLAG_K6_PX) ||
-        (call_faces >= k6::PX_MIN_FACES && px_fits &&
-         (!alpha || F >= k6::PX_DENSE_FACES || (px_raster && (S > pxk::GROUP || !rgb || call_faces >= 2 * k6::PX_MIN_FACES))));
-    const int W_px = px_possible && px_wanted ? px_band_config(S, rgb, B, &px_lds) : 0;
+    const int W_px = k6_px_band(B, F, S, rgb, alpha, eps, flags, W_fast != 0, &px_lds);  // (the rule and its measurements: there)
     const bool use_px = W_px > 0;
     const int W = use_px ? 1 : W_fast;  // the band width of the tables
     if (W_fast == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)

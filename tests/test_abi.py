@@ -81,7 +81,39 @@ def test_host_only_entry_points(lib_path):
     assert lib.nr_forward_workspace_bytes(0, 1, 1) == 0
     assert lib.nr_forward_workspace_bytes(1, 1, 20000) == 0
     # the measurement hook is not part of the product library (include/nr_hip_profile.h: libnr_hip_prof.so only)
-    assert not any(hasattr(lib, n) for n in ('nr_profile_band_kernel', 'nr_profile_band_kernel_ms', 'nr_profile_band_kernel_which'))
+    assert not any(hasattr(lib, n) for n in ('nr_profile_band_kernel', 'nr_profile_band_kernel_ms', 'nr_profile_band_kernel_which',
+                                             'nr_profile_k6_choice'))
+
+
+def test_k6_band_kernel_choice_table(lib_path):
+    """Which of K6's two band kernels a default-mode call takes (run_backward_pixel_map's rule, read through the measurement build:
+    host logic, no device).  The rows are the shapes the rule was measured on (profiles/r05_k6_kernels.md, r05_raster_sweep.md): a
+    change of the rule that moves one of them has to come with a measurement."""
+    choice = _lib.load_profile().nr_profile_k6_choice
+    PX, FAST, T = 1, 0, 4928  # (teapot with fill_back)
+    table = [
+        # B, F, S, rgb, alpha, eps, flags -> kernel
+        ((64, T, 256, 1, 1, 1e-3, 0), FAST),        # the headline shape: a tie, k_bpm_fast stays
+        ((64, T, 256, 0, 1, 1e-3, 0), PX),          # silhouettes
+        ((64, T, 256, 1, 0, 1e-3, 0), PX),          # colour only
+        ((128, T, 256, 1, 1, 1e-3, 0), PX),         # very large batches
+        ((32, T, 256, 1, 1, 1e-3, 0), FAST), ((8, T, 256, 1, 0, 1e-3, 0), FAST), ((8, T, 256, 0, 1, 1e-3, 0), FAST),  # shards
+        ((16, T, 256, 1, 0, 1e-3, 0), PX), ((32, T, 512, 1, 0, 1e-3, 0), PX),      # colour only: from 2^16 faces on
+        ((64, T, 512, 1, 1, 1e-3, 0), PX), ((64, T, 512, 0, 1, 1e-3, 0), PX), ((64, T, 448, 0, 1, 1e-3, 0), PX),    # the reference's default raster
+        ((64, T, 384, 1, 1, 1e-3, 0), FAST), ((64, T, 320, 0, 1, 1e-3, 0), FAST), ((64, T, 384, 1, 0, 1e-3, 0), PX),
+        ((64, T, 576, 1, 1, 1e-3, 0), FAST), ((64, T, 640, 1, 1, 1e-3, 0), FAST), ((64, T, 768, 0, 1, 1e-3, 0), FAST),
+        ((64, T, 640, 1, 0, 1e-3, 0), PX), ((64, T, 768, 1, 0, 1e-3, 0), PX),
+        ((64, T, 1024, 1, 0, 1e-3, 0), FAST),       # the pessimistic record estimate no longer fits the line buffer
+        ((64, 10240, 256, 1, 0, 1e-3, 0), PX),      # config 4
+        ((1, 655360, 1024, 1, 1, 1e-3, 0), PX),     # config 5 (dense: 397 vs 533 us)
+        ((4, T, 1024, 1, 1, 1e-3, 0), FAST), ((1, T, 2048, 1, 1, 1e-3, 0), FAST),
+        ((64, T, 256, 0, 1, 0.0, 0), FAST),         # eps = 0: k_bpm_px needs a positive eps
+        ((64, T, 512, 1, 1, 1e-3, 2), FAST),        # NR_FLAG_EXACT_GRADIENT
+        ((64, T, 512, 1, 1, 1e-3, 128), FAST), ((2, 40, 64, 1, 1, 1e-3, 65536), PX),  # forced by name
+        ((64, T, 512, 1, 1, 1e-3, 65536 | 2), FAST),
+    ]
+    wrong = [(args, want, choice(*args)) for args, want in table if choice(*args) != want]
+    assert not wrong, wrong
 
 
 def test_argument_errors_do_not_need_a_gpu(lib_path):
