@@ -734,6 +734,16 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
 // When a contribution is not taken (:648 / :653: d0 equals the vertex) its coefficient is +-Inf / NaN; the lane then
 // accumulates garbage that is discarded after the loop (no per-visit test of the has0 / has1 flags).
 static_assert(FSEG % k6::FB == 0, "batches must tile a piece");
+
+// One pixel's four floats out of LDS as ONE 16-byte read.  In the colour-only instantiation the alpha slot is never used and the
+// compiler narrows the load to ds_read2_b32 + ds_read_b32 (two LDS instructions at 4-byte granularity per pixel: that instance
+// ran 15 % slower than the one that also handles alpha); keeping the first component formally alive keeps the b128 form.
+__device__ __forceinline__ float4 lds_px4(const float *p)
+{
+    float4 v = *reinterpret_cast<const float4 *>(p);
+    asm volatile("" : "+v"(v.x));
+    return v;
+}
 constexpr int G_SHORT = 4;  // class G pieces up to this many pixels are numbered apart from the longer ones
 
 // DPP moves inside a row of 16 lanes: value of the lane D places below / one place above; a lane without such a neighbour
@@ -1084,7 +1094,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                     for (int j = 0; j < FB; ++j) {
                         gc[j] = gn[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         ac[j] = an[j] = 0.0f;
-                        if (RGB) gc[j] = *reinterpret_cast<const float4 *>(gp + 4 * j);
+                        if (RGB) gc[j] = lds_px4(gp + 4 * j);
                         else ac[j] = gp[j];
                     }
 #pragma unroll
@@ -1093,7 +1103,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                         if (kb + FB < FSEG) {
 #pragma unroll
                             for (int j = 0; j < FB; ++j) {
-                                if (RGB) gn[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + FB + j));
+                                if (RGB) gn[j] = lds_px4(gp + 4 * (kb + FB + j));
                                 else an[j] = gp[kb + FB + j];
                             }
                         }
@@ -1122,8 +1132,8 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                             g4[j] = c4[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                             ga[j] = ca[j] = 0.0f;
                             if (RGB) {
-                                g4[j] = *reinterpret_cast<const float4 *>(gp + 4 * (kb + j));
-                                c4[j] = *reinterpret_cast<const float4 *>(cp + 4 * (kb + j));
+                                g4[j] = lds_px4(gp + 4 * (kb + j));
+                                c4[j] = lds_px4(cp + 4 * (kb + j));
                             } else {
                                 ga[j] = gp[kb + j];
                                 ca[j] = cp[kb + j];
@@ -1145,7 +1155,7 @@ __device__ __forceinline__ void fast_sweeps(const FastPx &px, const BandLine *s_
                     const int fi = px.fi[l];
                     float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c4 = g4;
                     float ga = 0.0f, ca = 0.0f;
-                    if (RGB) { g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l); c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l); }
+                    if (RGB) { g4 = lds_px4(px.g + 4 * (size_t)l); c4 = lds_px4(px.c + 4 * (size_t)l); }
                     else { ga = px.g[l]; ca = px.c[l]; }
                     const float diff = own_diff(c4, ca, g4, ga);  // (an uncovered pixel holds the background colour)
                     // :707 (only the in sweep tests ownership) and :647 / :717 (a NaN diff is not `<= 0`), without divergent
@@ -1482,8 +1492,7 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
             const int d1 = gb + 64 * j + lane, l = base + min(d1, S - 1);
             d1f[j] = (float)d1;
             if constexpr (RGB) {
-                const float4 g4 = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
-                const float4 c4 = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l);
+                const float4 g4 = lds_px4(px.g + 4 * (size_t)l), c4 = lds_px4(px.c + 4 * (size_t)l);
                 gq[j][0] = g4.x; gq[j][NC - 3] = g4.y; gq[j][NC - 2] = g4.z; gq[j][NC - 1] = g4.w;
                 cq[j][0] = c4.x; cq[j][NC - 3] = c4.y; cq[j][NC - 2] = c4.z; cq[j][NC - 1] = c4.w;
                 pq[j] = (float)((ALPHA ? (double)c4.x * (double)g4.x : 0.0) + (double)c4.y * (double)g4.y + (double)c4.z * (double)g4.z +
@@ -1515,7 +1524,7 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
             const bool has_out = o_from <= o_to && o_to >= gb && o_from < gb + gpx;  // (:604: the in pixel is the face's)
             float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (has_out) {
-                if constexpr (RGB) oref = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)(base + d1_in));
+                if constexpr (RGB) oref = lds_px4(px.c + 4 * (size_t)(base + d1_in));
                 else oref.x = px.c[base + d1_in];
             }
             // the sweep inside this group: first pixel, last pixel (relative to the group), chunks touched
@@ -1529,7 +1538,7 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
                     const int lref = base + d1_in + ((flags & 8) ? 1 : -1);
                     float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
                     if constexpr (RGB) {
-                        const float4 q = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)lref);
+                        const float4 q = lds_px4(px.c + 4 * (size_t)lref);
                         ra = q.x; rr = q.y; rg = q.z; rb = q.w;
                     } else {
                         ra = px.c[lref];
@@ -1549,8 +1558,8 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
                                 const int l = base + min(q0 + k, s1);
                                 fi[k] = px.fi[l];
                                 if constexpr (RGB) {
-                                    g4[k] = *reinterpret_cast<const float4 *>(px.g + 4 * (size_t)l);
-                                    c4[k] = *reinterpret_cast<const float4 *>(px.c + 4 * (size_t)l);
+                                    g4[k] = lds_px4(px.g + 4 * (size_t)l);
+                                    c4[k] = lds_px4(px.c + 4 * (size_t)l);
                                 } else {
                                     g4[k] = make_float4(px.g[l], 0.0f, 0.0f, 0.0f);
                                     c4[k] = make_float4(px.c[l], 0.0f, 0.0f, 0.0f);
@@ -1910,21 +1919,19 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
 // k_bpm_fast.
 // Two band kernels serve the default arithmetic mode on line records (same per-pixel terms): k_bpm_fast (a piece of a sweep
 // per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
-// was measured (profiles/r05_k6_kernels.md: whole steps and K6 stage calls of 64 teapot views at rasters 256 ... 1024 in the
-// three gradient modes, config 4 / 5, low-poly spheres; same process).  k_bpm_px is a kernel for large launches (>= 2^18
-// faces in the call) whose images stay inside the line buffer (an image beyond it goes to the overflow-only launch of
-// k_bpm_fast on one-line bands: 2.5 x slower than k_bpm_fast's own handling -- so a pessimistic estimate of the records,
-// a mesh that fills the image, has to fit).  There it wins
-//   * whenever only the colour gradient is asked for (-10 ... -32 % at every raster: k_bpm_fast's colour-only instance is its
-//     slowest; 256^2: 0.326 vs 0.371 ms a step) -- there already from 2^16 faces in the call (16 views: -6 %, 32: -12 %);
-//   * with alpha involved: at the reference's default raster 512 and just below (448 ... 512: rgb + alpha -5 %, silhouettes
-//     -6 ... -9 %; all outputs 1.00 vs 1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with
-//     its two-line bands of band_shape: +5 ... +15 %; 896^2 ... 1024^2 +5 ... -8 %);
+// was measured (profiles/r05_raster_sweep.md, r05_k6_kernels.md: K6 stage calls and whole steps of 64 teapot views at rasters
+// 256 ... 1024 in the three gradient modes, config 4 / 5, low-poly spheres; same process).  k_bpm_px is a kernel for large
+// launches (>= 2^18 faces in the call) whose images stay inside the line buffer (an image beyond it goes to the overflow-only
+// launch of k_bpm_fast on one-line bands: 2.5 x slower than k_bpm_fast's own handling -- so a pessimistic estimate of the
+// records, a mesh that fills the image, has to fit).  There it wins
 //   * on dense meshes (>= 8192 faces per image) at every raster (config 4: 0.73 vs 0.79 ms a step; config 5, 655 360 faces at
 //     1024^2: 397 vs 533 us);
-//   * up to raster 256: silhouettes (0.243 vs 0.257 ms a step) and very large batches (128 views: 366 vs 384 us);
-//     k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a step) and small launches
-//     (8-32 views: 4 % faster).
+//   * at the reference's default raster 512 and just below (448 ... 512: -5 ... -9 % in every gradient mode; all outputs 1.00 vs
+//     1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with its two-line bands of band_shape:
+//     +2 ... +16 %; 32 views at 1024^2 it is 8 % ahead again);
+//   * up to raster 256 with one gradient (silhouettes 0.243 vs 0.257 ms a step, colour only -6 %) and on very large batches
+//     (128 views: -10 %); k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a step) and
+//     small launches (8-32 views: 0 ... 4 % faster).
 // NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
 // beyond k_bpm_px's LDS band are k_bpm_fast's.
 // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
@@ -1940,9 +1947,8 @@ int k6_px_band(int B, int F, int S, bool rgb, bool alpha, double eps, int flags,
     const bool px_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP);
     const bool px_wanted =
         (flags & NR_FLAG_K6_PX) ||
-        (px_fits && (alpha ? call_faces >= k6::PX_MIN_FACES &&
-                                 (F >= k6::PX_DENSE_FACES || (px_raster && (S > pxk::GROUP || !rgb || call_faces >= 2 * k6::PX_MIN_FACES)))
-                           : call_faces >= k6::PX_MIN_FACES / 4));
+        (px_fits && call_faces >= k6::PX_MIN_FACES &&
+         (F >= k6::PX_DENSE_FACES || (px_raster && (S > pxk::GROUP || !(rgb && alpha) || call_faces >= 2 * k6::PX_MIN_FACES))));
     return px_possible && px_wanted ? px_band_config(S, rgb, B, px_lds) : 0;
 }
 

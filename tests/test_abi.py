@@ -97,13 +97,12 @@ def test_k6_band_kernel_choice_table(lib_path):
         ((64, T, 256, 0, 1, 1e-3, 0), PX),          # silhouettes
         ((64, T, 256, 1, 0, 1e-3, 0), PX),          # colour only
         ((128, T, 256, 1, 1, 1e-3, 0), PX),         # very large batches
-        ((32, T, 256, 1, 1, 1e-3, 0), FAST), ((8, T, 256, 1, 0, 1e-3, 0), FAST), ((8, T, 256, 0, 1, 1e-3, 0), FAST),  # shards
-        ((16, T, 256, 1, 0, 1e-3, 0), PX), ((32, T, 512, 1, 0, 1e-3, 0), PX),      # colour only: from 2^16 faces on
+        ((32, T, 256, 1, 1, 1e-3, 0), FAST), ((16, T, 256, 1, 0, 1e-3, 0), FAST), ((8, T, 256, 0, 1, 1e-3, 0), FAST),  # shards
         ((64, T, 512, 1, 1, 1e-3, 0), PX), ((64, T, 512, 0, 1, 1e-3, 0), PX), ((64, T, 448, 0, 1, 1e-3, 0), PX),    # the reference's default raster
-        ((64, T, 384, 1, 1, 1e-3, 0), FAST), ((64, T, 320, 0, 1, 1e-3, 0), FAST), ((64, T, 384, 1, 0, 1e-3, 0), PX),
-        ((64, T, 576, 1, 1, 1e-3, 0), FAST), ((64, T, 640, 1, 1, 1e-3, 0), FAST), ((64, T, 768, 0, 1, 1e-3, 0), FAST),
-        ((64, T, 640, 1, 0, 1e-3, 0), PX), ((64, T, 768, 1, 0, 1e-3, 0), PX),
-        ((64, T, 1024, 1, 0, 1e-3, 0), FAST),       # the pessimistic record estimate no longer fits the line buffer
+        ((64, T, 512, 1, 0, 1e-3, 0), PX),
+        ((64, T, 384, 1, 1, 1e-3, 0), FAST), ((64, T, 320, 0, 1, 1e-3, 0), FAST), ((64, T, 384, 1, 0, 1e-3, 0), FAST),
+        ((64, T, 576, 1, 1, 1e-3, 0), FAST), ((64, T, 640, 1, 0, 1e-3, 0), FAST), ((64, T, 768, 0, 1, 1e-3, 0), FAST),
+        ((64, T, 1024, 1, 0, 1e-3, 0), FAST),
         ((64, 10240, 256, 1, 0, 1e-3, 0), PX),      # config 4
         ((1, 655360, 1024, 1, 1, 1e-3, 0), PX),     # config 5 (dense: 397 vs 533 us)
         ((4, T, 1024, 1, 1, 1e-3, 0), FAST), ((1, T, 2048, 1, 1, 1e-3, 0), FAST),
