@@ -1929,9 +1929,10 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
 //   * at the reference's default raster 512 and just below (448 ... 512: -5 ... -9 % in every gradient mode; all outputs 1.00 vs
 //     1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with its two-line bands of band_shape:
 //     +2 ... +16 %; 32 views at 1024^2 it is 8 % ahead again);
-//   * up to raster 256 with one gradient (silhouettes 0.243 vs 0.257 ms a step, colour only -6 %) and on very large batches
-//     (128 views: -10 %); k_bpm_fast keeps the headline shape (rgb + alpha, 64 views at 256^2: a tie at 0.359 ms a step) and
-//     small launches (8-32 views: 0 ... 4 % faster).
+//   * up to raster 256 (silhouettes 0.243 vs 0.257 ms a step, colour only -6 %, 128 views -10 %; the headline shape -- rgb +
+//     alpha, 64 views at 256^2 -- K6 stage 204 ... 210 vs 207 ... 219 us in six same-process pairs, fused backward 253 ... 255 vs
+//     255 ... 265, bench.py 0.335 ... 0.336 vs 0.347 ... 0.348 ms a step on the one box both were run on; k_bpm_fast's time varies
+//     more from box to box); k_bpm_fast keeps small launches (8-32 views: 0 ... 4 % faster).
 // NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
 // beyond k_bpm_px's LDS band are k_bpm_fast's.
 // With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
@@ -1948,7 +1949,9 @@ int k6_px_band(int B, int F, int S, bool rgb, bool alpha, double eps, int flags,
     const bool px_wanted =
         (flags & NR_FLAG_K6_PX) ||
         (px_fits && call_faces >= k6::PX_MIN_FACES &&
-         (F >= k6::PX_DENSE_FACES || (px_raster && (S > pxk::GROUP || !(rgb && alpha) || call_faces >= 2 * k6::PX_MIN_FACES))));
+         (F >= k6::PX_DENSE_FACES || px_raster));
+    (void)rgb;
+    (void)alpha;
     return px_possible && px_wanted ? px_band_config(S, rgb, B, px_lds) : 0;
 }
 

@@ -11,7 +11,7 @@ import sys
 
 def main():
     db, out = sys.argv[1], sys.argv[2]
-    want = sys.argv[3] if len(sys.argv) > 3 else 'k_bpm_fast<true, true'
+    want = sys.argv[3] if len(sys.argv) > 3 else 'k_bpm_'  # (the band kernel the library picked: the one with the most instructions)
     c = sqlite3.connect(db)
     t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     pick = lambda p: [x for x in t if x.startswith(p)][0]

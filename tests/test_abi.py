@@ -93,7 +93,7 @@ def test_k6_band_kernel_choice_table(lib_path):
     PX, FAST, T = 1, 0, 4928  # (teapot with fill_back)
     table = [
         # B, F, S, rgb, alpha, eps, flags -> kernel
-        ((64, T, 256, 1, 1, 1e-3, 0), FAST),        # the headline shape: a tie, k_bpm_fast stays
+        ((64, T, 256, 1, 1, 1e-3, 0), PX),          # the headline shape
         ((64, T, 256, 0, 1, 1e-3, 0), PX),          # silhouettes
         ((64, T, 256, 1, 0, 1e-3, 0), PX),          # colour only
         ((128, T, 256, 1, 1, 1e-3, 0), PX),         # very large batches
