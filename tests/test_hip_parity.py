@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # north_star tolerance for floating-point outputs
 # K6 against the reference's per-pixel terms summed exactly (oracle, accumulate_double): the default kernel evaluates the
 # terms in float through the hardware reciprocal, NR_FLAG_EXACT_GRADIENT with the reference's own arithmetic
-K6_BOUND_DEFAULT = 1e-4  # the north star's tolerance; measured levels per test: profiles/r05_parity_summary.md (worst 4.7e-5)
+K6_BOUND_DEFAULT = 1e-4  # the north star's tolerance; measured levels per test: profiles/r05_parity_summary.md (worst 4.9e-5)
 K6_BOUND_EXACT = 2e-6
 SAME_TERMS = 3e-5  # two evaluations of the same per-pixel terms in different summation orders (float run sums of the default K6
                    # kernel, regrouped by the order of its atomics: up to 1.2e-5 between two calls on config 2 where the line
