@@ -33,12 +33,15 @@ for it in range(60):
         print(dict(B=B, F=F, S=S, ts=ts, eps=eps, near=near, far=far, flags=flags))
         ref_gf, _ = fn.backward(*g, accumulate_double=True)
         print('visits', fn.visits, 'max|ref|', np.nanmax(np.abs(ref_gf)), 'rgb range', np.nanmin(fn.rgb_map), np.nanmax(fn.rgb_map))
-        for k6 in (0, 2):
+        ref_f, _ = fn.backward(*g)  # the reference's own float sums
+        okf = np.isfinite(ref_gf) & np.isfinite(ref_f)
+        print('reference float sums vs the same terms summed in double:', H.rel_err(ref_f[okf], ref_gf[okf]))
+        for k6 in (0, 128, 65536, 2):
             gf, _ = abi.backward(fw, *g, k6_flags=k6)
             gf = abi.host(gf)
             ok = np.isfinite(ref_gf) & np.isfinite(gf)
             err = np.abs(gf - ref_gf); err[~ok] = 0
             idx = np.unravel_index(np.argmax(err), err.shape)
-            print('flags', k6, 'rel_err', H.rel_err(gf[ok], ref_gf[ok]), 'worst at', idx, 'got', gf[idx], 'ref', ref_gf[idx],
-                  'face', faces[idx[0], idx[1]].tolist())
+            print('flags', k6, 'rel_err', H.rel_err(gf[ok], ref_gf[ok]), 'worst at', idx, 'got', gf[idx], 'ref', ref_gf[idx], 'float ref',
+                  ref_f[idx], 'face', faces[idx[0], idx[1]].tolist())
         break

