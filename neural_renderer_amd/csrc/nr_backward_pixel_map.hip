@@ -1483,24 +1483,62 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
         const BandLine *recs = recs_b + band_start[lt + ld];
         const int base = ld * SP, gb = grp * gpx;
         // ---- the group's pixels: gradients, colours, coordinate (a lane beyond the line repeats the last pixel; no mask reaches it)
-        // PDOT: sum_c (I_c - ref_c) g_c = sum_c I_c g_c - sum_c ref_c g_c -- the first sum is a property of the pixel (pq, formed
-        // once per group in double and rounded once), the second one fused multiply-add per channel on top of it: four
-        // operations of a visit instead of eight, and the colours leave the registers
+        // The colour difference of a visit in two sums: sum_c (I_c - ref_c) g_c = sum_c (I_c - K_c) g_c - sum_c (ref_c - K_c) g_c.
+        // The first sum is a property of the pixel (pq: formed once per group in double, rounded once), the second one fused
+        // multiply-add per channel on top of it -- four operations of a visit instead of eight, and the colours leave the registers.
+        // K is any colour NEAR the group's colours: with K = 0 the two sums are large where the colours are large, and a scene whose
+        // background is as bright as its faces (every term the small difference of large products) came out 3 ... 6e-4 off (a soak
+        // run of tests/test_fuzz_gpu.py found it).  K = the colour of an uncovered pixel of the group -- the background: the sum
+        // of a background pixel is then exactly 0 and a visit computes (bg - ref) g like k_bpm_fast's class U -- or, in a group
+        // without one, of its first pixel; not finite: 0.
         float gq[CH][NC], cq[CH][NC], pq[CH], d1f[CH];
+        int fq[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int d1 = gb + 64 * j + lane, l = base + min(d1, S - 1);
             d1f[j] = (float)d1;
+            fq[j] = d1 < S ? px.fi[l] : 0;
             if constexpr (RGB) {
                 const float4 g4 = lds_px4(px.g + 4 * (size_t)l), c4 = lds_px4(px.c + 4 * (size_t)l);
                 gq[j][0] = g4.x; gq[j][NC - 3] = g4.y; gq[j][NC - 2] = g4.z; gq[j][NC - 1] = g4.w;
                 cq[j][0] = c4.x; cq[j][NC - 3] = c4.y; cq[j][NC - 2] = c4.z; cq[j][NC - 1] = c4.w;
-                pq[j] = (float)((ALPHA ? (double)c4.x * (double)g4.x : 0.0) + (double)c4.y * (double)g4.y + (double)c4.z * (double)g4.z +
-                                (double)c4.w * (double)g4.w);
             } else {
                 gq[j][0] = px.g[l];
                 cq[j][0] = px.c[l];
-                pq[j] = cq[j][0] * gq[j][0];
+            }
+        }
+        float kc[NC];
+        {
+            bool found = false;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kc[c] = bcast_f(cq[0][c], 0);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const unsigned long long m = __ballot(fq[j] < 0);
+                if (!found && m) {
+                    const int r = (int)__builtin_ctzll(m);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) kc[c] = bcast_f(cq[j][c], r);
+                    found = true;
+                }
+            }
+            bool fin = true;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) fin = fin && (fabsf(kc[c]) <= 3.0e38f);
+            if (!fin) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) kc[c] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if constexpr (RGB) {
+                pq[j] = (float)((ALPHA ? (double)(cq[j][0] - kc[0]) * (double)gq[j][0] : 0.0) +
+                                (double)(cq[j][NC - 3] - kc[NC - 3]) * (double)gq[j][NC - 3] +
+                                (double)(cq[j][NC - 2] - kc[NC - 2]) * (double)gq[j][NC - 2] +
+                                (double)(cq[j][NC - 1] - kc[NC - 1]) * (double)gq[j][NC - 1]);
+            } else {
+                pq[j] = (cq[j][0] - kc[0]) * gq[j][0];
             }
         }
         for (int w0 = part * sub_win; w0 < n_rec; w0 += sub_win * n_parts) {
@@ -1522,10 +1560,14 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
             const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
             const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
             const bool has_out = o_from <= o_to && o_to >= gb && o_from < gb + gpx;  // (:604: the in pixel is the face's)
-            float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // (minus K: see the group's pixels above)
             if (has_out) {
-                if constexpr (RGB) oref = lds_px4(px.c + 4 * (size_t)(base + d1_in));
-                else oref.x = px.c[base + d1_in];
+                if constexpr (RGB) {
+                    oref = lds_px4(px.c + 4 * (size_t)(base + d1_in));
+                    oref.x -= kc[0]; oref.y -= kc[NC - 3]; oref.z -= kc[NC - 2]; oref.w -= kc[NC - 1];
+                } else {
+                    oref.x = px.c[base + d1_in] - kc[0];
+                }
             }
             // the sweep inside this group: first pixel, last pixel (relative to the group), chunks touched
             const int rel_from = max(o_from - gb, 0), rel_to = min(o_to - gb, gpx - 1);
