@@ -1379,8 +1379,8 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
 //       broadcasts from the lane: the out sweep's reference colour (the in pixel, :594-601), |c0|, |c1|, the crossing point, the
 //       sweep's pixel range inside the group and the chunks it touches;
 //   phase B (one record after the other, v_readlane -> SGPRs)   out sweep (:604-657): every chunk the sweep overlaps is one
-//       visit of all 64 lanes (range test: one unsigned comparison); diff = (sum I g) - sum ref g, one fused multiply-add per
-//       channel; the record's two sums through 2^PX_RED_LEVELS-lane DPP trees in float and LDS atomics in double (ds_add_f64)
+//       visit of all 64 lanes (range test: one unsigned comparison); diff = (sum (I - K) g) - sum (ref - K) g, K a colour
+//       near the group's colours (the background), one fused multiply-add per channel; the record's two sums through 2^PX_RED_LEVELS-lane DPP trees in float and LDS atomics in double (ds_add_f64)
 //       onto the record's slot of the wave's window;
 //   flush   one lane per record adds the window's two sums to the double scratch (global_atomic_add_f64), as k_bpm_fast does.
 // Arithmetic of a visit: the tolerance mode of k_bpm_fast (fused multiply-adds, v_rcp_f32), with

@@ -17,7 +17,7 @@ import os
 EXTRA_SEEDS = [int(x) for x in os.environ.get('NR_FUZZ_EXTRA_SEEDS', '').split()]
 
 
-@pytest.mark.parametrize('seed', [1, 2, 3] + EXTRA_SEEDS)
+@pytest.mark.parametrize('seed', [1, 2, 3, 6] + EXTRA_SEEDS)  # (6: the scene at the metric's worst case, see the bound below)
 def test_fuzz_unusual_parameters(seed):
     rng = np.random.default_rng(seed)
     failures = []
@@ -174,7 +174,7 @@ def test_fuzz_micro_triangles_and_needles(seed):
     assert not bad, bad
 
 
-@pytest.mark.parametrize('seed', [31, 32] + [100 + x for x in EXTRA_SEEDS])
+@pytest.mark.parametrize('seed', [31, 32, 112, 121] + [100 + x for x in EXTRA_SEEDS])  # (112, 121: the bright scenes that caught k_bpm_px's sums around 0)
 def test_fuzz_default_k6_error_levels(seed):
     """How far the default (tolerance-mode) K6 kernel gets from the exactly summed reference terms on scenes built to cancel:
     many overlapping faces of similar, bright colours (small `diff`, both signs), large and small `eps` (with a large eps every
