@@ -1716,6 +1716,335 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
     }
 }
 
+// ==================================================================================================
+// k_bpm_row (round 6): the out sweeps on ROWS of 16 lanes -- four records per wave instruction.
+//
+// k_bpm_px visits one record at a time with all 64 lanes: a sweep of ~66 pixels (the average of a 256 x 256 teapot view) fills
+// two 64-lane chunks half, and every record pays a frame of its own (8 v_readlane, four chunk branches, two DPP trees, two
+// LDS atomics): 45 instructions of frame around 32 of visits, one third of the issued lanes useful (profiles/r05_pmc_k6.txt).
+// Here a DPP row of 16 lanes takes a record, the four rows of a wave four different ones:
+//   * the band's pixels stay in LDS (as in k_bpm_fast); a row reads 16 consecutive pixels of its line per step, in segments
+//     ALIGNED to 16 pixels -- 256 contiguous bytes per row and array: every ds_read_b128 is conflict-free whatever segments the
+//     four rows are at;
+//   * an out sweep runs from the crossing point to the image border (:607-609), so "inside the sweep" is the sign of
+//     td = direction * (d1 - d1_cross), a value the visit needs anyway: no range arithmetic, and a row may start segments
+//     before its sweep or run on behind it -- those lanes are masked by the same comparison;
+//   * the records of a window are SORTED by their number of segments (a counting sort in LDS) and dealt to the rows four at a
+//     time: the rows of a group walk (nearly) the same number of steps, so the group is one loop with a uniform trip count, one
+//     DPP tree over the rows (8 operations for four records) and one store per record -- no atomics: every record is reduced
+//     exactly once;
+//   * a record's constants reach its row by ds_bpermute_b32 from the lane that prepared them in phase A.
+// A visit is the arithmetic of k_bpm_fast's class M (diff = sum (I - ref) g with fused multiply-adds, dist = |c| |t| + eps,
+// v_rcp_f32; the sign of the record goes on at the flush as in k_bpm_px): 19 vector operations and two LDS reads for up to 64
+// useful lanes.  Phase A (in sweeps, a lane per record) and the flush are k_bpm_px's.
+namespace rowk {
+constexpr int NT = 256, NW = NT / 64;
+constexpr int WIN = 64;            // records per window (a lane each in phase A)
+constexpr int SEG = 16;            // pixels per step of a row
+constexpr int MAX_SEGS = 64;       // segments of a line, at most (raster <= 1024): the sort's keys
+constexpr int IN_SEG = 16, IN_BATCH = 4;  // (in sweeps: as k_bpm_px)
+constexpr int CHUNK_STEPS = 16;    // float terms per lane before the DPP tree (a piece of k_bpm_fast holds 15)
+template <bool RGB> constexpr int c_off() { return RGB ? 16384 : 4096; }  // bytes from the gradient array to the colour array
+}  // namespace rowk
+
+template <bool RGB, bool ALPHA>
+__global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
+    const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
+    const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, double *__restrict__ scratch,
+    const int *__restrict__ band_lines, const int *__restrict__ band_start, const int *__restrict__ lines_ok,
+    const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, float eps_f, int B,
+    uint4 *__restrict__ zero16, size_t n_zero16)
+{
+    using namespace rowk;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
+    const unsigned total_wg = n_bands * 2u * (unsigned)B;
+    const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_fast)
+    if (logical >= total_wg) return;
+    if (n_zero16) {  // the fused backward's zero fill of grad_textures rides along (see k_bpm_fast)
+        const size_t per = (n_zero16 + total_wg - 1) / total_wg, z_lo = (size_t)logical * per, z_hi = min(n_zero16, z_lo + per);
+        for (size_t k = z_lo + tid; k < z_hi; k += NT) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
+    if (lines_ok[b] == 0) return;  // records beyond the buffer: k_bpm_fast's scan path serves this image
+    const int band_lo = band * W, nld = min(W, S - band_lo);
+    const size_t lt = ((size_t)b * 2 + axis) * S + band_lo;  // the band's lines in the per-line tables (band width 1)
+    int n_tot = 0;
+    for (int l = 0; l < nld; ++l) n_tot += band_lines[lt + l];
+    if (n_tot == 0) return;  // no visible face has a line here
+
+    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient / colour arrays: (alpha, r, g, b) or alpha alone
+    constexpr int C_OFF = c_off<RGB>();
+    // a line in LDS: SP pixels, a multiple of 32 (an even number of segments); the pixels behind the raster hold zero gradients
+    const int SP = (S + 31) & ~31, nsl = SP / SEG;
+    FastPx px;
+    px.g = (float *)smem;
+    px.c = (float *)(smem + C_OFF);
+    px.fi = (int *)(smem + 2 * C_OFF);
+    px.bg = nullptr; px.cov = nullptr; px.CW = 0; px.span = nullptr;
+    unsigned char *wave_mem = smem + 2 * C_OFF + (((size_t)W * SP * 4 + 15) & ~(size_t)15) + (size_t)wave * (WIN * 8 + WIN);
+    float2 *acc = (float2 *)wave_mem;            // [WIN] a record's two out-sweep sums (magnitudes) ...
+    int *hist = (int *)wave_mem;                 // ... after the sort's counters are done with the same bytes
+    unsigned char *sorted = wave_mem + WIN * 8;  // [WIN] lane of the k-th record in the order of the sort
+    const int n_parts = max(1, NW / W);  // (a band narrower than the workgroup has waves: they share the windows of a line)
+    const BandLine *recs_b = line_buf + (size_t)b * cap;
+    // (the first window of the wave's first line is requested in front of the staging loads: one global round trip less on the
+    // workgroup's critical path)
+    int4 hh_first = make_int4(1, 1, 0, 0);
+    float4 qq_first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (wave < nld * n_parts) {
+        const int ld = wave / n_parts, part = wave - ld * n_parts;
+        const int n_rec = band_lines[lt + ld], r = part * WIN + lane;
+        if (r < n_rec) {
+            const BandLine *R = recs_b + band_start[lt + ld] + r;
+            hh_first = *reinterpret_cast<const int4 *>(R);
+            qq_first = *reinterpret_cast<const float4 *>(&R->cross);
+        }
+    }
+    if (SP != S) {  // the pixels behind the raster: no gradient, nobody's
+        const int pad = SP - S;
+        for (int i = tid; i < nld * pad; i += NT) {
+            const int ld = i / pad, l = ld * SP + S + (i - ld * pad);
+            px.fi[l] = -1;
+            if constexpr (RGB) {
+                *reinterpret_cast<float4 *>(px.g + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                *reinterpret_cast<float4 *>(px.c + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                px.g[l] = 0.0f;
+                px.c[l] = 0.0f;
+            }
+        }
+    }
+    fast_stage<RGB, ALPHA, NT>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, (size_t)b * S * S, axis, band_lo, nld, S, SP);
+    __syncthreads();
+
+    float eps_v = eps_f;
+    asm volatile("" : "+v"(eps_v));
+    const int row = lane >> 4, l16 = lane & 15;
+    for (int vt = wave; vt < nld * n_parts; vt += NW) {
+        const int ld = vt / n_parts, part = vt - ld * n_parts;
+        const int n_rec = band_lines[lt + ld];
+        if (n_rec == 0) continue;
+        const BandLine *recs = recs_b + band_start[lt + ld];
+        const int base = ld * SP;
+        for (int w0 = part * WIN; w0 < n_rec; w0 += WIN * n_parts) {
+            const int nw = min(WIN, n_rec - w0);
+            // ---- phase A: lane = record.  The lane keeps its record for the flush, walks the record's in sweep, and prepares what
+            // its row will be handed in phase B: the reference colour of the OUT sweep (the in pixel, :594-601), |c0| (carrying
+            // the direction in its sign bit), |c1|, -direction * crossing point, the number of segments of the sweep.
+            int4 hh = hh_first;
+            float4 qq = qq_first;
+            if (!(vt == wave && w0 == part * WIN)) {  // (not the window requested in front of the staging)
+                hh = make_int4(1, 1, 0, 0);
+                qq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (lane < nw) {
+                    const BandLine *R = recs + w0 + lane;
+                    hh = *reinterpret_cast<const int4 *>(R);
+                    qq = *reinterpret_cast<const float4 *>(&R->cross);
+                }
+            }
+            const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
+            const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
+            const bool has_out = o_from <= o_to;  // (:604: the in pixel is the face's)
+            const bool dpos = (flags & 8) != 0;   // direction > 0: the sweep ends at the last pixel of the line, else it starts at pixel 0
+            float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (has_out) {
+                if constexpr (RGB) oref = lds_px4(px.c + 4 * (size_t)(base + d1_in));
+                else oref.x = px.c[base + d1_in];
+            }
+            // segments of the out sweep: [o_from / 16, nsl) or [0, o_to / 16]
+            const int nseg = has_out ? (dpos ? nsl - (o_from >> 4) : (o_to >> 4) + 1) : 0;
+            hist[lane] = 0;
+            double in0 = 0.0, in1 = 0.0;
+            {
+                const int in_from = hh.x & 0xffff, in_to = hh.x >> 16;
+                if (in_from <= in_to) {
+                    // reference colour of the IN sweep: the out pixel (:697-700)
+                    const int lref = base + d1_in + (dpos ? 1 : -1);
+                    float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
+                    if constexpr (RGB) {
+                        const float4 q = lds_px4(px.c + 4 * (size_t)lref);
+                        ra = q.x; rr = q.y; rg = q.z; rb = q.w;
+                    } else {
+                        ra = px.c[lref];
+                    }
+                    const float cross = qq.x, c0k = qq.y, c1k = qq.z;
+                    const int fnr = __float_as_int(qq.w);
+                    // (batches of IN_BATCH pixels whose LDS reads are requested together -- nine in-sweeps in ten are one batch;
+                    // IN_SEG float terms per double addition, like a piece of k_bpm_fast)
+                    for (int s0 = in_from; s0 <= in_to; s0 += IN_SEG) {
+                        const int s1 = min(s0 + IN_SEG - 1, in_to);
+                        float b0 = 0.0f, b1 = 0.0f;
+                        for (int q0 = s0; q0 <= s1; q0 += IN_BATCH) {
+                            int fi[IN_BATCH];
+                            float4 g4[IN_BATCH], c4[IN_BATCH];
+#pragma unroll
+                            for (int k = 0; k < IN_BATCH; ++k) {
+                                const int l = base + min(q0 + k, s1);
+                                fi[k] = px.fi[l];
+                                if constexpr (RGB) {
+                                    g4[k] = lds_px4(px.g + 4 * (size_t)l);
+                                    c4[k] = lds_px4(px.c + 4 * (size_t)l);
+                                } else {
+                                    g4[k] = make_float4(px.g[l], 0.0f, 0.0f, 0.0f);
+                                    c4[k] = make_float4(px.c[l], 0.0f, 0.0f, 0.0f);
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < IN_BATCH; ++k) {
+                                float diff;
+                                if constexpr (RGB) {
+                                    diff = ALPHA ? __builtin_fmaf(c4[k].y - rr, g4[k].y, (c4[k].x - ra) * g4[k].x) : (c4[k].y - rr) * g4[k].y;  // :709-716
+                                    diff = __builtin_fmaf(c4[k].z - rg, g4[k].z, diff);
+                                    diff = __builtin_fmaf(c4[k].w - rb, g4[k].w, diff);
+                                } else {
+                                    diff = (c4[k].x - ra) * g4[k].x;
+                                }
+                                // :707, :717 (a NaN diff goes through); a pixel beyond the batch's end repeats the last one: dropped
+                                const bool take = (q0 + k <= s1) & (fi[k] == fnr) & !(diff <= 0.0f);
+                                const float t = (float)(q0 + k) - cross;
+                                const float x0 = c0k * t, x1 = c1k * t;                               // :719 / :724 (2 / S folded into c)
+                                const float y0 = x0 + ((0.0f < x0) ? eps_v : -eps_v);                 // :720-721 / :725-726
+                                const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
+                                const float dm = take ? diff : 0.0f;
+                                // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
+                                b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
+                                b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
+                            }
+                        }
+                        in0 += (double)b0;
+                        in1 += (double)b1;
+                    }
+                }
+            }
+            // ---- the order of phase B: records by falling number of segments (counting sort: a counter per key in LDS)
+            wave_lds_handover();
+            const int key = MAX_SEGS - nseg;  // (only of records with an out sweep: 0 .. MAX_SEGS - 1)
+            int rank = 0;
+            if (has_out) rank = atomicAdd(&hist[key], 1);
+            wave_lds_handover();
+            const int cnt = hist[lane], incl = wave_incl_sum_dpp(cnt);
+            const int n_out = __builtin_amdgcn_readlane(incl, 63);
+            wave_lds_handover();
+            hist[lane] = incl - cnt;
+            wave_lds_handover();
+            if (has_out) sorted[hist[key] + rank] = (unsigned char)lane;
+            wave_lds_handover();
+            // ---- phase B: four records at a time, one per row of 16 lanes
+            // what a row is handed (from the lane that holds the record)
+            const float v_ncd = dpos ? -qq.x : qq.x;
+            const float v_ac0 = __uint_as_float((__float_as_uint(qq.y) & 0x7fffffffu) | (dpos ? 0u : 0x80000000u));
+            const float v_ac1 = fabsf(qq.z);
+            for (int g0 = 0; g0 < n_out; g0 += 4) {
+                const int q = g0 + row;
+                const bool act = q < n_out;
+                const int src = act ? (int)sorted[q] : 0;
+                const int sa = src << 2;
+                const int r_nseg = __builtin_amdgcn_ds_bpermute(sa, nseg);
+                float ncd = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ncd)));
+                const float ac0s = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ac0)));
+                const float ac1 = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ac1)));
+                const float ra = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.x)));
+                float rr = 0.0f, rg = 0.0f, rb = 0.0f;
+                if constexpr (RGB) {
+                    rr = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.y)));
+                    rg = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.z)));
+                    rb = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.w)));
+                }
+                // (a row without a record: td = -Inf for every pixel, nothing is taken, nothing stored)
+                if (!act) ncd = -__builtin_inff();
+                const float sdir = __uint_as_float(0x3f800000u | (__float_as_uint(ac0s) & 0x80000000u));
+                // the group walks as many steps as its longest sweep has segments (the first row's: the order of the sort), an
+                // even number; a sweep towards the end of the line ENDS with the group's last step, one from pixel 0 starts with its first
+                const int steps = __builtin_amdgcn_readfirstlane(r_nseg), steps2 = (steps + 1) & ~1;
+                const bool rpos = !(__float_as_uint(ac0s) >> 31);
+                const int seg0 = rpos ? nsl - steps2 : 0;
+                const int p0 = seg0 * SEG + l16;
+                float pf = (float)p0;
+                const unsigned char *gp = (const unsigned char *)px.g + (size_t)(base + p0) * (NC * 4);
+                double A0 = 0.0, A1 = 0.0;
+                auto visit = [&](const float4 &g4, const float4 &c4, const float pfv, float &a0, float &a1) {
+                    float d;                                                                      // :631-638
+                    if constexpr (RGB) {
+                        d = ALPHA ? __builtin_fmaf(c4.y - rr, g4.y, (c4.x - ra) * g4.x) : (c4.y - rr) * g4.y;
+                        d = __builtin_fmaf(c4.z - rg, g4.z, d);
+                        d = __builtin_fmaf(c4.w - rb, g4.w, d);
+                    } else {
+                        d = (c4.x - ra) * g4.x;
+                    }
+                    const float td = __builtin_fmaf(sdir, pfv, ncd);  // direction * (d1 - d1_cross): > 0 exactly on the sweep's pixels
+                    const bool keep = !(td <= 0.0f) && !(d <= 0.0f);  // (:647: a NaN diff goes through)
+                    const float dm = keep ? d : 0.0f;
+                    const float y0 = __builtin_fmaf(fabsf(ac0s), fabsf(td), eps_v), y1 = __builtin_fmaf(ac1, fabsf(td), eps_v);  // :649-650 / :654-655
+                    a0 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y0), a0);                        // :651 (sign: the flush)
+                    a1 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y1), a1);                        // :656
+                };
+                // (plain 16-byte reads: lds_px4's barrier would make every read wait for its data on the spot; the instance without
+                // alpha keeps its first components formally alive BEHIND the visit instead, see lds_px4)
+                auto load = [&](const unsigned char *p, float4 &g4, float4 &c4) {
+                    if constexpr (RGB) {
+                        g4 = *reinterpret_cast<const float4 *>(p);
+                        c4 = *reinterpret_cast<const float4 *>(p + C_OFF);
+                    } else {
+                        g4 = make_float4(*reinterpret_cast<const float *>(p), 0.0f, 0.0f, 0.0f);
+                        c4 = make_float4(*reinterpret_cast<const float *>(p + C_OFF), 0.0f, 0.0f, 0.0f);
+                    }
+                };
+                auto used = [&](const float4 &g4, const float4 &c4) {
+                    if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x), "v"(c4.x));
+                };
+                constexpr int STEP_BYTES = SEG * NC * 4;
+                for (int c0 = 0; c0 < steps2; c0 += CHUNK_STEPS) {
+                    const int c1 = min(c0 + CHUNK_STEPS, steps2);
+                    float a0 = 0.0f, a1 = 0.0f;
+                    float4 gA, cA, gB, cB;
+                    load(gp, gA, cA);
+                    load(gp + STEP_BYTES, gB, cB);
+                    for (int s = c0; s < c1; s += 2) {
+                        // (the next pair is requested as soon as a visit has consumed its registers; behind the last step of a
+                        // line the reads fetch what is never used)
+                        gp += 2 * STEP_BYTES;
+                        visit(gA, cA, pf, a0, a1);
+                        used(gA, cA);
+                        load(gp, gA, cA);
+                        visit(gB, cB, pf + (float)SEG, a0, a1);
+                        used(gB, cB);
+                        load(gp + STEP_BYTES, gB, cB);
+                        pf += (float)(2 * SEG);
+                    }
+                    // the row's two sums (float tree over its 16 lanes; lane 15 holds them)
+                    a0 += dpp_row_shr_v<1>(a0); a1 += dpp_row_shr_v<1>(a1);
+                    a0 += dpp_row_shr_v<2>(a0); a1 += dpp_row_shr_v<2>(a1);
+                    a0 += dpp_row_shr_v<4>(a0); a1 += dpp_row_shr_v<4>(a1);
+                    a0 += dpp_row_shr_v<8>(a0); a1 += dpp_row_shr_v<8>(a1);
+                    A0 += (double)a0;
+                    A1 += (double)a1;
+                }
+                if (act && l16 == 15) acc[src] = make_float2((float)A0, (float)A1);
+            }
+            wave_lds_handover();
+            // ---- flush: in sweep + out sweep of each record -> global double scratch [list position][vertex][x|y].
+            // Out sweep: grad -= diff / (sigma * |dist|), sigma = sign(c) * sign(t), sign(t) = the direction (t = d1 - d1_cross
+            // keeps its sign beyond the crossing point): the magnitudes were summed, the sign goes on here.  :648 / :653 (and
+            // :718 / :723): a contribution whose vertex sits on the line is not taken (its coefficient was Inf / NaN).
+            if (lane < nw) {
+                float2 a = make_float2(0.0f, 0.0f);
+                if (has_out) a = acc[lane];
+                const bool tneg = !dpos;
+                const bool neg0 = ((__float_as_uint(qq.y) >> 31) != 0) != tneg, neg1 = ((__float_as_uint(qq.z) >> 31) != 0) != tneg;
+                const double t0 = (flags & 2) ? in0 + (double)(neg0 ? a.x : -a.x) : 0.0;
+                const double t1 = (flags & 4) ? in1 + (double)(neg1 ? a.y : -a.y) : 0.0;
+                const int tgt = hh.w, pos = tgt & 0x0fffffff;
+                double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
+                if (t0 != 0.0) atomicAdd(dst + 2 * ((tgt >> 28) & 3), t0);
+                if (t1 != 0.0) atomicAdd(dst + 2 * ((tgt >> 30) & 3), t1);
+            }
+            wave_lds_handover();
+        }
+    }
+}
+
 // add: grad_faces holds what K8 left for the face (zeros from the compaction, then the gather's sums: the fused backward whose
 // gather runs beside the line setup) and K6's rounded sums go on top -- the one float addition per element that the in-gather
 // finish makes, operands exchanged
@@ -1935,12 +2264,33 @@ int px_band_config(int S, bool rgb, int B, size_t *lds_bytes)
     return 0;
 }
 
+// k_bpm_row's band: the widest power of two of lines (<= one per wave) whose gradients / colours fit their fixed LDS regions;
+// 0: the raster is too large for it (k_bpm_fast takes the launch)
+int row_band_config(int S, bool rgb, int B, size_t *lds_bytes)
+{
+    const size_t nc = rgb ? 4 : 1, c_off = rgb ? rowk::c_off<true>() : rowk::c_off<false>(), SP = ((size_t)S + 31) & ~(size_t)31;
+    if (SP / rowk::SEG > (size_t)rowk::MAX_SEGS) return 0;
+    for (int W = rowk::NW; W >= 1; W >>= 1) {
+        if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::PX_MIN_WGS) continue;  // (small launches: narrower bands, see px_band_config)
+        if ((size_t)W * SP * nc * 4 > c_off) continue;
+        *lds_bytes = 2 * c_off + align_up((size_t)W * SP * 4, 16) + (size_t)rowk::NW * (rowk::WIN * 8 + rowk::WIN);
+        return W;
+    }
+    return 0;
+}
+
 template <bool RGB, bool ALPHA>
 int launch_px(const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb, const float *g_alpha, double *scratch,
               const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap, int B,
               int F, int S, int W, size_t lds, double eps, hipStream_t st, void *zero_ptr, size_t zero_bytes)
 {
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
+    if constexpr (k6::PX_ROWS) {
+        hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb, g_alpha,
+                           scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, B, (uint4 *)zero_ptr,
+                           zero_bytes / 16);
+        return 0;
+    }
     hipLaunchKernelGGL((k_bpm_px<RGB, ALPHA>), dim3(xcd_grid(total_wg)), dim3(pxk::NT), lds, st, fi, rgb, alpha, g_rgb, g_alpha,
                        scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, B, (uint4 *)zero_ptr,
                        zero_bytes / 16);
@@ -1994,7 +2344,8 @@ int k6_px_band(int B, int F, int S, bool rgb, bool alpha, double eps, int flags,
          (F >= k6::PX_DENSE_FACES || px_raster));
     (void)rgb;
     (void)alpha;
-    return px_possible && px_wanted ? px_band_config(S, rgb, B, px_lds) : 0;
+    if (!(px_possible && px_wanted)) return 0;
+    return k6::PX_ROWS ? row_band_config(S, rgb, B, px_lds) : px_band_config(S, rgb, B, px_lds);
 }
 
 // Measurement hook (include/nr_hip_profile.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.  Only in the

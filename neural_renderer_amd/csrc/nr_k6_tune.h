@@ -64,6 +64,10 @@
 #define NR_PX_MIN_WGS 8192
 #endif
 
+#ifndef NR_PX_ROWS          // the lane-parallel band kernel: 1 k_bpm_row (a record per row of 16 lanes, round 6), 0 k_bpm_px (round 5)
+#define NR_PX_ROWS 1
+#endif
+
 #ifndef NR_PX_MIN_FACES     // k_bpm_px is considered from this many faces in the call (batch x faces) on; with both gradients up to
 #define NR_PX_MIN_FACES 262144  // raster 256 from twice as many (run_backward_pixel_map: the rule and what it was measured on)
 #endif
@@ -94,6 +98,7 @@ constexpr unsigned long PX_MIN_WGS = NR_PX_MIN_WGS;
 constexpr unsigned long PX_MIN_FACES = NR_PX_MIN_FACES;
 constexpr int PX_DENSE_FACES = NR_PX_DENSE_FACES;
 constexpr bool PX_PDOT = NR_PX_PDOT != 0;
+constexpr bool PX_ROWS = NR_PX_ROWS != 0;
 constexpr int PX_RED_LEVELS = NR_PX_RED_LEVELS;
 constexpr unsigned OVF_GRID = NR_K6_OVF_GRID;
 constexpr int WIDE_BUDGET_FROM = NR_K6_WIDE_BUDGET_FROM, WIDE_BUDGET_TO = NR_K6_WIDE_BUDGET_TO;
