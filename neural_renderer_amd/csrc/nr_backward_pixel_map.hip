@@ -1717,35 +1717,58 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
 }
 
 // ==================================================================================================
-// k_bpm_row (round 6): the out sweeps on ROWS of 16 lanes -- four records per wave instruction.
+// k_bpm_row (round 6): the out sweeps on BLOCKS of 16 lanes -- four records per wave instruction.
 //
 // k_bpm_px visits one record at a time with all 64 lanes: a sweep of ~66 pixels (the average of a 256 x 256 teapot view) fills
 // two 64-lane chunks half, and every record pays a frame of its own (8 v_readlane, four chunk branches, two DPP trees, two
 // LDS atomics): 45 instructions of frame around 32 of visits, one third of the issued lanes useful (profiles/r05_pmc_k6.txt).
-// Here a DPP row of 16 lanes takes a record, the four rows of a wave four different ones:
-//   * the band's pixels stay in LDS (as in k_bpm_fast); a row reads 16 consecutive pixels of its line per step, in segments
-//     ALIGNED to 16 pixels -- 256 contiguous bytes per row and array: every ds_read_b128 is conflict-free whatever segments the
-//     four rows are at;
+// Here 16 lanes take a record, the four such blocks of a wave four different ones:
+//   * the band's pixels stay in LDS (as in k_bpm_fast); a block reads 16 consecutive pixels of its line per step, in segments
+//     ALIGNED to 16 pixels -- 256 contiguous bytes per block and array;
 //   * an out sweep runs from the crossing point to the image border (:607-609), so "inside the sweep" is the sign of
-//     td = direction * (d1 - d1_cross), a value the visit needs anyway: no range arithmetic, and a row may start segments
+//     td = direction * (d1 - d1_cross), a value the visit needs anyway: no range arithmetic, and a block may start segments
 //     before its sweep or run on behind it -- those lanes are masked by the same comparison;
-//   * the records of a window are SORTED by their number of segments (a counting sort in LDS) and dealt to the rows four at a
-//     time: the rows of a group walk (nearly) the same number of steps, so the group is one loop with a uniform trip count, one
-//     DPP tree over the rows (8 operations for four records) and one store per record -- no atomics: every record is reduced
-//     exactly once;
-//   * a record's constants reach its row by ds_bpermute_b32 from the lane that prepared them in phase A.
+//   * the records of a window are SORTED by their number of segments (a counting sort in LDS) and dealt to the blocks four at a
+//     time: the blocks of a group walk (nearly) the same number of steps, so the group is one loop with a uniform trip count and
+//     ONE reduction for four records;
+//   * that reduction is the matrix pipe's: a block is the 16 lanes of one block of v_mfma_f64_4x4x4_4b_f64 -- lanes
+//     4 b .. 4 b + 3 of each of the wave's four rows -- and two of these instructions with a matrix of ones add up a block's 16
+//     values in DOUBLE (the first contracts over the rows, the second over the four lanes), the sum arriving in every lane of
+//     the block: no DPP tree in float (whose roundings of the TOTALS cost dense meshes a factor two in the error level),
+//     no LDS atomics, and the vector pipe issues 4 instructions instead of 16;
+//   * a block's pixel quads are dealt to its four rows so that the 16-byte LDS reads stay conflict-free whatever segments the
+//     four blocks are at (the LDS serves lanes {0-3, 12-15, 20-27}, ... together: quad = (row + 2 (b >> 1)) mod 4);
+//   * a record's constants reach its block by ds_bpermute_b32 from the lane that prepared them in phase A.
 // A visit is the arithmetic of k_bpm_fast's class M (diff = sum (I - ref) g with fused multiply-adds, dist = |c| |t| + eps,
 // v_rcp_f32; the sign of the record goes on at the flush as in k_bpm_px): 19 vector operations and two LDS reads for up to 64
 // useful lanes.  Phase A (in sweeps, a lane per record) and the flush are k_bpm_px's.
+#ifndef NR_ROW_OFF  // (development: switch-off builds -- 1 no out sweeps, 2 no in sweeps, 4 no sort / groups at all, 8 no visits inside the groups)
+#define NR_ROW_OFF 0
+#endif
+#ifndef NR_ROW_LDS_PAD  // (development: unused LDS per workgroup, to probe what a workgroup less per CU costs)
+#define NR_ROW_LDS_PAD 0
+#endif
 namespace rowk {
 constexpr int NT = 256, NW = NT / 64;
 constexpr int WIN = 64;            // records per window (a lane each in phase A)
 constexpr int SEG = 16;            // pixels per step of a row
 constexpr int MAX_SEGS = 64;       // segments of a line, at most (raster <= 1024): the sort's keys
 constexpr int IN_SEG = 16, IN_BATCH = 4;  // (in sweeps: as k_bpm_px)
-constexpr int CHUNK_STEPS = 16;    // float terms per lane before the DPP tree (a piece of k_bpm_fast holds 15)
 template <bool RGB> constexpr int c_off() { return RGB ? 16384 : 4096; }  // bytes from the gradient array to the colour array
 }  // namespace rowk
+
+#ifdef NR_ROW_STATS  // development builds (scripts/row_stats.py): work counters of k_bpm_row
+__device__ unsigned long long g_row_stats[8];
+NR_API int nr_dev_row_stats(unsigned long long *out8)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_row_stats), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_row_stats), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#define NR_ROW_STAT(i, v) do { if (lane == 0) atomicAdd(&g_row_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define NR_ROW_STAT(i, v) ((void)0)
+#endif
 
 template <bool RGB, bool ALPHA>
 __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
@@ -1783,10 +1806,9 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
     px.c = (float *)(smem + C_OFF);
     px.fi = (int *)(smem + 2 * C_OFF);
     px.bg = nullptr; px.cov = nullptr; px.CW = 0; px.span = nullptr;
-    unsigned char *wave_mem = smem + 2 * C_OFF + (((size_t)W * SP * 4 + 15) & ~(size_t)15) + (size_t)wave * (WIN * 8 + WIN);
-    float2 *acc = (float2 *)wave_mem;            // [WIN] a record's two out-sweep sums (magnitudes) ...
-    int *hist = (int *)wave_mem;                 // ... after the sort's counters are done with the same bytes
-    unsigned char *sorted = wave_mem + WIN * 8;  // [WIN] lane of the k-th record in the order of the sort
+    unsigned char *wave_mem = smem + 2 * C_OFF + (((size_t)W * SP * 4 + 15) & ~(size_t)15) + (size_t)wave * (WIN * 16);
+    double2 *acc = (double2 *)wave_mem;  // [WIN] a record's two out-sweep sums (magnitudes) ...
+    int *hist = (int *)wave_mem;         // ... after the sort's counters are done with the same bytes
     const int n_parts = max(1, NW / W);  // (a band narrower than the workgroup has waves: they share the windows of a line)
     const BandLine *recs_b = line_buf + (size_t)b * cap;
     // (the first window of the wave's first line is requested in front of the staging loads: one global round trip less on the
@@ -1821,7 +1843,8 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
 
     float eps_v = eps_f;
     asm volatile("" : "+v"(eps_v));
-    const int row = lane >> 4, l16 = lane & 15;
+    // the lane's block (record of a group) and its pixel inside a segment (see above)
+    const int row = (lane >> 2) & 3, l16 = ((((lane >> 4) + ((lane >> 2) & 2)) & 3) << 2) | (lane & 3);
     for (int vt = wave; vt < nld * n_parts; vt += NW) {
         const int ld = vt / n_parts, part = vt - ld * n_parts;
         const int n_rec = band_lines[lt + ld];
@@ -1858,7 +1881,7 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
             hist[lane] = 0;
             double in0 = 0.0, in1 = 0.0;
             {
-                const int in_from = hh.x & 0xffff, in_to = hh.x >> 16;
+                const int in_from = hh.x & 0xffff, in_to = (NR_ROW_OFF & 2) ? -1 : (hh.x >> 16);
                 if (in_from <= in_to) {
                     // reference colour of the IN sweep: the out pixel (:697-700)
                     const int lref = base + d1_in + (dpos ? 1 : -1);
@@ -1918,7 +1941,9 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
                     }
                 }
             }
-            // ---- the order of phase B: records by falling number of segments (counting sort: a counter per key in LDS)
+            // ---- the order of phase B: records by falling number of segments (counting sort: a counter per key in LDS; the
+            // records without an out sweep behind the others, so that the positions are a permutation of the lanes, which one
+            // ds_permute_b32 inverts: lane k then knows which lane holds the k-th record)
             wave_lds_handover();
             const int key = MAX_SEGS - nseg;  // (only of records with an out sweep: 0 .. MAX_SEGS - 1)
             int rank = 0;
@@ -1929,17 +1954,30 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
             wave_lds_handover();
             hist[lane] = incl - cnt;
             wave_lds_handover();
-            if (has_out) sorted[hist[key] + rank] = (unsigned char)lane;
+            const unsigned long long no_out = __ballot(!has_out);
+            int pos = n_out + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(no_out >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)no_out, 0u));
+            if (has_out) pos = hist[key] + rank;
+            const int inv = __builtin_amdgcn_ds_permute(pos << 2, lane);
             wave_lds_handover();
+            NR_ROW_STAT(0, 1);        // windows
+            NR_ROW_STAT(1, nw);       // records
+            NR_ROW_STAT(2, n_out);    // records with an out sweep
+            {
+                int sn = nseg, si = has_out ? (o_to - o_from + 1) : 0;
+                for (int o = 32; o > 0; o >>= 1) { sn += __shfl_xor(sn, o, WAVE); si += __shfl_xor(si, o, WAVE); }
+                NR_ROW_STAT(3, sn);   // segments of the out sweeps
+                NR_ROW_STAT(4, si);   // pixels of the out sweeps
+            }
             // ---- phase B: four records at a time, one per row of 16 lanes
             // what a row is handed (from the lane that holds the record)
             const float v_ncd = dpos ? -qq.x : qq.x;
             const float v_ac0 = __uint_as_float((__float_as_uint(qq.y) & 0x7fffffffu) | (dpos ? 0u : 0x80000000u));
             const float v_ac1 = fabsf(qq.z);
-            for (int g0 = 0; g0 < n_out; g0 += 4) {
-                const int q = g0 + row;
-                const bool act = q < n_out;
-                const int src = act ? (int)sorted[q] : 0;
+            int src_next = __builtin_amdgcn_ds_bpermute(row << 2, inv);
+            for (int g0 = 0; g0 < ((NR_ROW_OFF & 1) ? 0 : n_out); g0 += 4) {
+                const bool act = g0 + row < n_out;
+                const int src = src_next;  // (of a row without a record: some lane; nothing of it is used)
+                src_next = __builtin_amdgcn_ds_bpermute(((g0 + 4 + row) & 63) << 2, inv);
                 const int sa = src << 2;
                 const int r_nseg = __builtin_amdgcn_ds_bpermute(sa, nseg);
                 float ncd = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ncd)));
@@ -1956,14 +1994,17 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
                 if (!act) ncd = -__builtin_inff();
                 const float sdir = __uint_as_float(0x3f800000u | (__float_as_uint(ac0s) & 0x80000000u));
                 // the group walks as many steps as its longest sweep has segments (the first row's: the order of the sort), an
-                // even number; a sweep towards the end of the line ENDS with the group's last step, one from pixel 0 starts with its first
+                // even number; a sweep towards the end of the line ENDS with the group's last step, one from pixel 0 starts with its
+                // first; pixels in front of a sweep or behind it are masked (td <= 0)
                 const int steps = __builtin_amdgcn_readfirstlane(r_nseg), steps2 = (steps + 1) & ~1;
+                NR_ROW_STAT(5, 1);       // groups
+                NR_ROW_STAT(6, steps2);  // steps walked
                 const bool rpos = !(__float_as_uint(ac0s) >> 31);
                 const int seg0 = rpos ? nsl - steps2 : 0;
                 const int p0 = seg0 * SEG + l16;
+                constexpr int STEP_BYTES = SEG * NC * 4;
                 float pf = (float)p0;
                 const unsigned char *gp = (const unsigned char *)px.g + (size_t)(base + p0) * (NC * 4);
-                double A0 = 0.0, A1 = 0.0;
                 auto visit = [&](const float4 &g4, const float4 &c4, const float pfv, float &a0, float &a1) {
                     float d;                                                                      // :631-638
                     if constexpr (RGB) {
@@ -1994,34 +2035,56 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
                 auto used = [&](const float4 &g4, const float4 &c4) {
                     if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x), "v"(c4.x));
                 };
-                constexpr int STEP_BYTES = SEG * NC * 4;
-                for (int c0 = 0; c0 < steps2; c0 += CHUNK_STEPS) {
-                    const int c1 = min(c0 + CHUNK_STEPS, steps2);
-                    float a0 = 0.0f, a1 = 0.0f;
-                    float4 gA, cA, gB, cB;
+                // a lane adds the terms of its even and of its odd steps in float (chains of up to ROW_CHAIN / 2 terms); everything
+                // above is double: the matrix pipe adds the 2 x 16 chain sums of a block (C operand: chain after chain)
+                double A0 = 0.0, A1 = 0.0;
+                for (int c0 = 0; c0 < ((NR_ROW_OFF & 8) ? 0 : steps2); c0 += k6::ROW_CHAIN) {
+                    const int c1 = min(c0 + k6::ROW_CHAIN, steps2);
+                    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+                    // Two steps per pair, two pairs of registers: while one pair is visited the other pair's reads are in flight
+                    // (the scheduling barriers keep the compiler from gathering the reads at the top of the loop, where every
+                    // iteration would wait for them).  Behind the last step of a chain the reads fetch what is never used (inside
+                    // the workgroup's LDS: at most two segments past a line).
+                    float4 gA, cA, gB, cB, gC, cC, gD, cD;
                     load(gp, gA, cA);
                     load(gp + STEP_BYTES, gB, cB);
-                    for (int s = c0; s < c1; s += 2) {
-                        // (the next pair is requested as soon as a visit has consumed its registers; behind the last step of a
-                        // line the reads fetch what is never used)
-                        gp += 2 * STEP_BYTES;
+                    int s = c0;
+                    for (; s + 4 <= c1; s += 4) {
+                        load(gp + 2 * STEP_BYTES, gC, cC);
+                        load(gp + 3 * STEP_BYTES, gD, cD);
+                        __builtin_amdgcn_sched_barrier(0);
                         visit(gA, cA, pf, a0, a1);
                         used(gA, cA);
-                        load(gp, gA, cA);
-                        visit(gB, cB, pf + (float)SEG, a0, a1);
+                        visit(gB, cB, pf + (float)SEG, b0, b1);
                         used(gB, cB);
-                        load(gp + STEP_BYTES, gB, cB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load(gp + 4 * STEP_BYTES, gA, cA);
+                        load(gp + 5 * STEP_BYTES, gB, cB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        visit(gC, cC, pf + (float)(2 * SEG), a0, a1);
+                        used(gC, cC);
+                        visit(gD, cD, pf + (float)(3 * SEG), b0, b1);
+                        used(gD, cD);
+                        __builtin_amdgcn_sched_barrier(0);
+                        gp += 4 * STEP_BYTES;
+                        pf += (float)(4 * SEG);
+                    }
+                    if (s < c1) {  // (the chain's last pair: already requested)
+                        visit(gA, cA, pf, a0, a1);
+                        used(gA, cA);
+                        visit(gB, cB, pf + (float)SEG, b0, b1);
+                        used(gB, cB);
+                        gp += 2 * STEP_BYTES;
                         pf += (float)(2 * SEG);
                     }
-                    // the row's two sums (float tree over its 16 lanes; lane 15 holds them)
-                    a0 += dpp_row_shr_v<1>(a0); a1 += dpp_row_shr_v<1>(a1);
-                    a0 += dpp_row_shr_v<2>(a0); a1 += dpp_row_shr_v<2>(a1);
-                    a0 += dpp_row_shr_v<4>(a0); a1 += dpp_row_shr_v<4>(a1);
-                    a0 += dpp_row_shr_v<8>(a0); a1 += dpp_row_shr_v<8>(a1);
-                    A0 += (double)a0;
-                    A1 += (double)a1;
+                    double t0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, 1.0, 0.0, 0, 0, 0);
+                    double t1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a1, 1.0, 0.0, 0, 0, 0);
+                    t0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b0, 1.0, t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b1, 1.0, t1, 0, 0, 0);
+                    A0 = __builtin_amdgcn_mfma_f64_4x4x4f64(t0, 1.0, A0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f64_4x4x4f64(t1, 1.0, A1, 0, 0, 0);
                 }
-                if (act && l16 == 15) acc[src] = make_float2((float)A0, (float)A1);
+                if (act && lane == (row << 2)) acc[src] = make_double2(A0, A1);  // (every lane of the block holds the sums)
             }
             wave_lds_handover();
             // ---- flush: in sweep + out sweep of each record -> global double scratch [list position][vertex][x|y].
@@ -2029,14 +2092,14 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
             // keeps its sign beyond the crossing point): the magnitudes were summed, the sign goes on here.  :648 / :653 (and
             // :718 / :723): a contribution whose vertex sits on the line is not taken (its coefficient was Inf / NaN).
             if (lane < nw) {
-                float2 a = make_float2(0.0f, 0.0f);
+                double2 a = make_double2(0.0, 0.0);
                 if (has_out) a = acc[lane];
                 const bool tneg = !dpos;
                 const bool neg0 = ((__float_as_uint(qq.y) >> 31) != 0) != tneg, neg1 = ((__float_as_uint(qq.z) >> 31) != 0) != tneg;
-                const double t0 = (flags & 2) ? in0 + (double)(neg0 ? a.x : -a.x) : 0.0;
-                const double t1 = (flags & 4) ? in1 + (double)(neg1 ? a.y : -a.y) : 0.0;
-                const int tgt = hh.w, pos = tgt & 0x0fffffff;
-                double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
+                const double t0 = (flags & 2) ? in0 + (neg0 ? a.x : -a.x) : 0.0;
+                const double t1 = (flags & 4) ? in1 + (neg1 ? a.y : -a.y) : 0.0;
+                const int tgt = hh.w, lpos = tgt & 0x0fffffff;
+                double *dst = scratch + ((size_t)b * F + lpos) * 6 + (1 - axis);
                 if (t0 != 0.0) atomicAdd(dst + 2 * ((tgt >> 28) & 3), t0);
                 if (t1 != 0.0) atomicAdd(dst + 2 * ((tgt >> 30) & 3), t1);
             }
@@ -2273,7 +2336,7 @@ int row_band_config(int S, bool rgb, int B, size_t *lds_bytes)
     for (int W = rowk::NW; W >= 1; W >>= 1) {
         if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::PX_MIN_WGS) continue;  // (small launches: narrower bands, see px_band_config)
         if ((size_t)W * SP * nc * 4 > c_off) continue;
-        *lds_bytes = 2 * c_off + align_up((size_t)W * SP * 4, 16) + (size_t)rowk::NW * (rowk::WIN * 8 + rowk::WIN);
+        *lds_bytes = 2 * c_off + align_up((size_t)W * SP * 4, 16) + (size_t)rowk::NW * (rowk::WIN * 16) + NR_ROW_LDS_PAD;
         return W;
     }
     return 0;

@@ -68,6 +68,10 @@
 #define NR_PX_ROWS 1
 #endif
 
+#ifndef NR_ROW_CHAIN        // k_bpm_row: steps (an even number) of a chain: a lane adds the terms of its even and of its odd steps in float, the chains' sums go on in double
+#define NR_ROW_CHAIN 16
+#endif
+
 #ifndef NR_PX_MIN_FACES     // k_bpm_px is considered from this many faces in the call (batch x faces) on; with both gradients up to
 #define NR_PX_MIN_FACES 262144  // raster 256 from twice as many (run_backward_pixel_map: the rule and what it was measured on)
 #endif
@@ -99,6 +103,8 @@ constexpr unsigned long PX_MIN_FACES = NR_PX_MIN_FACES;
 constexpr int PX_DENSE_FACES = NR_PX_DENSE_FACES;
 constexpr bool PX_PDOT = NR_PX_PDOT != 0;
 constexpr bool PX_ROWS = NR_PX_ROWS != 0;
+constexpr int ROW_CHAIN = NR_ROW_CHAIN;
+static_assert(ROW_CHAIN >= 2 && ROW_CHAIN % 2 == 0, "a row walks two steps per iteration");
 constexpr int PX_RED_LEVELS = NR_PX_RED_LEVELS;
 constexpr unsigned OVF_GRID = NR_K6_OVF_GRID;
 constexpr int WIDE_BUDGET_FROM = NR_K6_WIDE_BUDGET_FROM, WIDE_BUDGET_TO = NR_K6_WIDE_BUDGET_TO;

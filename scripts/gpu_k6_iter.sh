@@ -31,7 +31,7 @@ if [ -n "$PMC" ]; then
              "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES"; do
     n=$((n+1))
     ITERS=3 timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT -o p$n -- python scripts/stage_times.py > $OUT/p$n.log 2>&1
-    python scripts/rocpd_pmc.py $OUT/p${n}_results.db k_bpm_px 2>&1 | cut -c1-30,60-200 | tee -a $OUT/pmc.txt
+    python scripts/rocpd_pmc.py $OUT/p${n}_results.db ${KNAME:-k_bpm_row} 2>&1 | cut -c1-30,60-200 | tee -a $OUT/pmc.txt
   done
   rm -f $OUT/*_results.db
 fi
