@@ -1719,42 +1719,47 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
 // ==================================================================================================
 // k_bpm_row (round 6): the out sweeps on BLOCKS of 16 lanes -- four records per wave instruction.
 //
-// k_bpm_px visits one record at a time with all 64 lanes: a sweep of ~66 pixels (the average of a 256 x 256 teapot view) fills
-// two 64-lane chunks half, and every record pays a frame of its own (8 v_readlane, four chunk branches, two DPP trees, two
-// LDS atomics): 45 instructions of frame around 32 of visits, one third of the issued lanes useful (profiles/r05_pmc_k6.txt).
+// k_bpm_px visits one record at a time with all 64 lanes: a sweep of ~127 pixels (the average of a 256 x 256 teapot view) leaves
+// its last 64-lane chunk half empty, and every record pays a frame of its own (8 v_readlane, four chunk branches, two DPP
+// trees, two LDS atomics): 45 instructions of frame around the visits (profiles/r05_pmc_k6.txt).
 // Here 16 lanes take a record, the four such blocks of a wave four different ones:
-//   * the band's pixels stay in LDS (as in k_bpm_fast); a block reads 16 consecutive pixels of its line per step, in segments
-//     ALIGNED to 16 pixels -- 256 contiguous bytes per block and array;
+//   * the band's pixels stay in LDS (as in k_bpm_fast) -- per pixel the four gradients g and ONE sum P = sum_c (I_c - K_c) g_c
+//     (formed in double at the staging, rounded once; K: the colour of the line's first pixel, i.e. the background almost
+//     always -- see k_bpm_px on why the sums are centred), 24 bytes with the face index: five workgroups per CU;
+//     a block reads 16 consecutive pixels of its line per step, in segments ALIGNED to 16 pixels;
 //   * an out sweep runs from the crossing point to the image border (:607-609), so "inside the sweep" is the sign of
 //     td = direction * (d1 - d1_cross), a value the visit needs anyway: no range arithmetic, and a block may start segments
 //     before its sweep or run on behind it -- those lanes are masked by the same comparison;
 //   * the records of a window are SORTED by their number of segments (a counting sort in LDS) and dealt to the blocks four at a
-//     time: the blocks of a group walk (nearly) the same number of steps, so the group is one loop with a uniform trip count and
-//     ONE reduction for four records;
+//     time: the blocks of a group walk (nearly) the same number of steps (lane efficiency 0.84 at raster 256, 0.90 at 512:
+//     scripts/row_stats.py), so the group is one loop with a uniform trip count and ONE reduction for four records;
 //   * that reduction is the matrix pipe's: a block is the 16 lanes of one block of v_mfma_f64_4x4x4_4b_f64 -- lanes
 //     4 b .. 4 b + 3 of each of the wave's four rows -- and two of these instructions with a matrix of ones add up a block's 16
 //     values in DOUBLE (the first contracts over the rows, the second over the four lanes), the sum arriving in every lane of
 //     the block: no DPP tree in float (whose roundings of the TOTALS cost dense meshes a factor two in the error level),
-//     no LDS atomics, and the vector pipe issues 4 instructions instead of 16;
+//     no LDS atomics, and the vector pipe issues 4 conversions instead of 16 operations;
 //   * a block's pixel quads are dealt to its four rows so that the 16-byte LDS reads stay conflict-free whatever segments the
 //     four blocks are at (the LDS serves lanes {0-3, 12-15, 20-27}, ... together: quad = (row + 2 (b >> 1)) mod 4);
 //   * a record's constants reach its block by ds_bpermute_b32 from the lane that prepared them in phase A.
-// A visit is the arithmetic of k_bpm_fast's class M (diff = sum (I - ref) g with fused multiply-adds, dist = |c| |t| + eps,
-// v_rcp_f32; the sign of the record goes on at the flush as in k_bpm_px): 19 vector operations and two LDS reads for up to 64
-// useful lanes.  Phase A (in sweeps, a lane per record) and the flush are k_bpm_px's.
-#ifndef NR_ROW_OFF  // (development: switch-off builds -- 1 no out sweeps, 2 no in sweeps, 4 no sort / groups at all, 8 no visits inside the groups)
-#define NR_ROW_OFF 0
-#endif
+// A visit: diff = P - sum_c (ref_c - K_c) g_c (four fused multiply-adds), dist = |c| |t| + eps for the two vertices, two
+// v_rcp_f32 (a quarter-rate instruction on this part: a third of the visit's issue time), two fused multiply-adds; the sign of
+// the record goes on at the flush as in k_bpm_px: 15 vector operations and two LDS reads for up to 64 useful lanes.
+// Phase A (a lane per record): the in sweeps (:665-728) in the same two-sum form, the two reference colours of a record
+// (the in and the out pixel, :594-601 / :697-700) straight from the maps -- no colours in LDS.
 #ifndef NR_ROW_LDS_PAD  // (development: unused LDS per workgroup, to probe what a workgroup less per CU costs)
 #define NR_ROW_LDS_PAD 0
 #endif
 namespace rowk {
 constexpr int NT = 256, NW = NT / 64;
 constexpr int WIN = 64;            // records per window (a lane each in phase A)
-constexpr int SEG = 16;            // pixels per step of a row
+constexpr int SEG = 16;            // pixels per step of a block
 constexpr int MAX_SEGS = 64;       // segments of a line, at most (raster <= 1024): the sort's keys
 constexpr int IN_SEG = 16, IN_BATCH = 4;  // (in sweeps: as k_bpm_px)
-template <bool RGB> constexpr int c_off() { return RGB ? 16384 : 4096; }  // bytes from the gradient array to the colour array
+constexpr int MAX_PX = 1024;       // pixels of a band, at most
+// LDS of a workgroup: gradients [W][SP][NC] | sums P [W][SP] | face indices [W][SP] | K of the band's lines | a window per wave
+template <bool RGB> constexpr int g_bytes() { return RGB ? MAX_PX * 16 : MAX_PX * 4; }
+constexpr int P_BYTES = MAX_PX * 4, FI_BYTES = MAX_PX * 4, K_BYTES = NW * 16, WAVE_BYTES = WIN * 16;
+template <bool RGB> constexpr size_t lds_bytes() { return g_bytes<RGB>() + P_BYTES + FI_BYTES + K_BYTES + NW * WAVE_BYTES + NR_ROW_LDS_PAD; }
 }  // namespace rowk
 
 #ifdef NR_ROW_STATS  // development builds (scripts/row_stats.py): work counters of k_bpm_row
@@ -1771,7 +1776,7 @@ NR_API int nr_dev_row_stats(unsigned long long *out8)
 #endif
 
 template <bool RGB, bool ALPHA>
-__global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
+__global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
     const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
     const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, double *__restrict__ scratch,
     const int *__restrict__ band_lines, const int *__restrict__ band_start, const int *__restrict__ lines_ok,
@@ -1797,20 +1802,39 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
     for (int l = 0; l < nld; ++l) n_tot += band_lines[lt + l];
     if (n_tot == 0) return;  // no visible face has a line here
 
-    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient / colour arrays: (alpha, r, g, b) or alpha alone
-    constexpr int C_OFF = c_off<RGB>();
-    // a line in LDS: SP pixels, a multiple of 32 (an even number of segments); the pixels behind the raster hold zero gradients
+    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient array: (alpha, r, g, b) or alpha alone
+    constexpr int G_BYTES = g_bytes<RGB>();
+    // a line in LDS: SP pixels, a multiple of 32 (an even number of segments); the pixels behind the raster hold zeros
     const int SP = (S + 31) & ~31, nsl = SP / SEG;
-    FastPx px;
-    px.g = (float *)smem;
-    px.c = (float *)(smem + C_OFF);
-    px.fi = (int *)(smem + 2 * C_OFF);
-    px.bg = nullptr; px.cov = nullptr; px.CW = 0; px.span = nullptr;
-    unsigned char *wave_mem = smem + 2 * C_OFF + (((size_t)W * SP * 4 + 15) & ~(size_t)15) + (size_t)wave * (WIN * 16);
+    float *const s_g = (float *)smem;                                  // [W][SP][NC] gradients
+    float *const s_p = (float *)(smem + G_BYTES);                      // [W][SP] sum_c (I_c - K_c) g_c
+    int *const s_fi = (int *)(smem + G_BYTES + P_BYTES);               // [W][SP] face index
+    float4 *const s_k = (float4 *)(smem + G_BYTES + P_BYTES + FI_BYTES);  // [W] K of each line: (alpha, r, g, b)
+    unsigned char *wave_mem = smem + G_BYTES + P_BYTES + FI_BYTES + K_BYTES + (size_t)wave * WAVE_BYTES;
     double2 *acc = (double2 *)wave_mem;  // [WIN] a record's two out-sweep sums (magnitudes) ...
     int *hist = (int *)wave_mem;         // ... after the sort's counters are done with the same bytes
     const int n_parts = max(1, NW / W);  // (a band narrower than the workgroup has waves: they share the windows of a line)
     const BandLine *recs_b = line_buf + (size_t)b * cap;
+    const size_t img = (size_t)b * S * S;
+    // map index of pixel d1 of band line ld (:587-593)
+    auto map_index = [&](int ld, int d1) { return axis ? img + (size_t)(band_lo + ld) * S + d1 : img + (size_t)d1 * S + band_lo + ld; };
+    // (alpha, r, g, b) of a pixel, straight from the maps
+    auto map_colour = [&](size_t gi) {
+        float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (!RGB || ALPHA) c.x = alpha_map[gi];
+        if constexpr (RGB) { c.y = rgb_map[3 * gi]; c.z = rgb_map[3 * gi + 1]; c.w = rgb_map[3 * gi + 2]; }
+        return c;
+    };
+    // K of a line: the colour of its first pixel -- an uncovered one in most images, whose sum P is then exactly 0 and whose visit
+    // computes (bg - ref) g like k_bpm_fast's class U; any colour NEAR the line's colours serves (with K = 0 a scene whose
+    // background is as bright as its faces -- every term the small difference of large products -- came out 3 ... 6e-4 off in
+    // round 5); not finite: 0
+    auto line_k = [&](int ld) {
+        float4 k = map_colour(map_index(ld, 0));
+        const bool fin = fabsf(k.x) <= 3.0e38f && fabsf(k.y) <= 3.0e38f && fabsf(k.z) <= 3.0e38f && fabsf(k.w) <= 3.0e38f;
+        if (!fin) k = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return k;
+    };
     // (the first window of the wave's first line is requested in front of the staging loads: one global round trip less on the
     // workgroup's critical path)
     int4 hh_first = make_int4(1, 1, 0, 0);
@@ -1824,21 +1848,85 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
             qq_first = *reinterpret_cast<const float4 *>(&R->cross);
         }
     }
-    if (SP != S) {  // the pixels behind the raster: no gradient, nobody's
-        const int pad = SP - S;
-        for (int i = tid; i < nld * pad; i += NT) {
-            const int ld = i / pad, l = ld * SP + S + (i - ld * pad);
-            px.fi[l] = -1;
+    // ---- stage the band: gradients, sums, face indices
+    {
+        auto put = [&](int ld, int d1, int fi, const float4 &k, float al, float ga, float r, float g, float bl, float gr, float gg, float gb) {
+            const int l = ld * SP + d1;
+            s_fi[l] = fi;
             if constexpr (RGB) {
-                *reinterpret_cast<float4 *>(px.g + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                *reinterpret_cast<float4 *>(px.c + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                *reinterpret_cast<float4 *>(s_g + 4 * (size_t)l) = make_float4(ga, gr, gg, gb);
+                s_p[l] = (float)((ALPHA ? (double)(al - k.x) * (double)ga : 0.0) + (double)(r - k.y) * (double)gr +
+                                 (double)(g - k.z) * (double)gg + (double)(bl - k.w) * (double)gb);
             } else {
-                px.g[l] = 0.0f;
-                px.c[l] = 0.0f;
+                s_g[l] = ga;
+                s_p[l] = (al - k.x) * ga;
+            }
+            if (d1 == 0) s_k[ld] = k;
+        };
+        // four adjacent pixels of a map row with one 16-byte load per field (see fast_stage)
+        auto put_quad = [&](size_t g, int ld0, int d10, int ld_step, int d1_step) {
+            const int4 vf = *reinterpret_cast<const int4 *>(fi_map + g);
+            float4 va = make_float4(0, 0, 0, 0), vg = va;
+            if (ALPHA) {
+                va = *reinterpret_cast<const float4 *>(alpha_map + g);
+                vg = *reinterpret_cast<const float4 *>(g_alpha + g);
+            }
+            float rr[12], qq[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) rr[k] = qq[k] = 0.0f;
+            if (RGB) {
+                const float4 *pr = reinterpret_cast<const float4 *>(rgb_map + 3 * g);
+                const float4 *pg = reinterpret_cast<const float4 *>(g_rgb + 3 * g);
+                const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2], q0 = pg[0], q1 = pg[1], q2 = pg[2];
+                rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+                rr[8] = r2.x; rr[9] = r2.y; rr[10] = r2.z; rr[11] = r2.w;
+                qq[0] = q0.x; qq[1] = q0.y; qq[2] = q0.z; qq[3] = q0.w; qq[4] = q1.x; qq[5] = q1.y; qq[6] = q1.z; qq[7] = q1.w;
+                qq[8] = q2.x; qq[9] = q2.y; qq[10] = q2.z; qq[11] = q2.w;
+            }
+            const int fis[4] = {vf.x, vf.y, vf.z, vf.w};
+            const float als[4] = {va.x, va.y, va.z, va.w}, gas[4] = {vg.x, vg.y, vg.z, vg.w};
+            float4 k = line_k(ld0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j > 0 && ld_step) k = line_k(ld0 + j * ld_step);
+                put(ld0 + j * ld_step, d10 + j * d1_step, fis[j], k, als[j], gas[j], rr[3 * j], rr[3 * j + 1], rr[3 * j + 2], qq[3 * j],
+                    qq[3 * j + 1], qq[3 * j + 2]);
+            }
+        };
+        auto put_one = [&](int ld, int d1) {
+            const size_t g = map_index(ld, d1);
+            float al = 0, ga = 0, r = 0, gn = 0, bl = 0, gr = 0, gg = 0, gb = 0;
+            if (ALPHA) { al = alpha_map[g]; ga = g_alpha[g]; }
+            if (RGB) {
+                r = rgb_map[3 * g]; gn = rgb_map[3 * g + 1]; bl = rgb_map[3 * g + 2];
+                gr = g_rgb[3 * g]; gg = g_rgb[3 * g + 1]; gb = g_rgb[3 * g + 2];
+            }
+            put(ld, d1, fi_map[g], line_k(ld), al, ga, r, gn, bl, gr, gg, gb);
+        };
+        if (SP != S) {  // the pixels behind the raster: no gradient, nobody's
+            const int pad = SP - S;
+            for (int i = tid; i < nld * pad; i += NT) {
+                const int ld = i / pad, l = ld * SP + S + (i - ld * pad);
+                s_fi[l] = -1;
+                s_p[l] = 0.0f;
+                if constexpr (RGB) *reinterpret_cast<float4 *>(s_g + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                else s_g[l] = 0.0f;
             }
         }
+        if (axis && (S & 3) == 0) {  // a band line is an image row: thread -> (line, quad of 4 consecutive pixels)
+            const int quads = S >> 2;
+            for (int i = tid; i < nld * quads; i += NT) {
+                const int ld = i / quads, x = (i - ld * quads) << 2;
+                put_quad(img + (size_t)(band_lo + ld) * S + x, ld, x, 0, 1);
+            }
+        } else if (axis) {  // thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
+            for (int i = tid; i < nld * S; i += NT) put_one(i / S, i % S);
+        } else if (nld == 4 && (S & 3) == 0 && (band_lo & 3) == 0) {  // 4 adjacent columns: one thread per row
+            for (int y = tid; y < S; y += NT) put_quad(img + (size_t)y * S + band_lo, 0, y, 1, 0);
+        } else {  // generic columns: thread -> (row d1, line ld) with ld fastest
+            for (int i = tid; i < nld * S; i += NT) put_one(i % nld, i / nld);
+        }
     }
-    fast_stage<RGB, ALPHA, NT>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, (size_t)b * S * S, axis, band_lo, nld, S, SP);
     __syncthreads();
 
     float eps_v = eps_f;
@@ -1851,11 +1939,12 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
         if (n_rec == 0) continue;
         const BandLine *recs = recs_b + band_start[lt + ld];
         const int base = ld * SP;
+        const float4 kc = s_k[ld];
         for (int w0 = part * WIN; w0 < n_rec; w0 += WIN * n_parts) {
             const int nw = min(WIN, n_rec - w0);
             // ---- phase A: lane = record.  The lane keeps its record for the flush, walks the record's in sweep, and prepares what
-            // its row will be handed in phase B: the reference colour of the OUT sweep (the in pixel, :594-601), |c0| (carrying
-            // the direction in its sign bit), |c1|, -direction * crossing point, the number of segments of the sweep.
+            // its block will be handed in phase B: the reference colour of the OUT sweep (the in pixel, :594-601) minus K, |c0|
+            // (carrying the direction in its sign bit), |c1|, -direction * crossing point, the number of segments of the sweep.
             int4 hh = hh_first;
             float4 qq = qq_first;
             if (!(vt == wave && w0 == part * WIN)) {  // (not the window requested in front of the staging)
@@ -1869,131 +1958,153 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
             }
             const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
             const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
+            const int in_from = hh.x & 0xffff, in_to = hh.x >> 16;
             const bool has_out = o_from <= o_to;  // (:604: the in pixel is the face's)
+            const bool has_in = in_from <= in_to;  // (every record whose in and out pixel lie inside the image)
             const bool dpos = (flags & 8) != 0;   // direction > 0: the sweep ends at the last pixel of the line, else it starts at pixel 0
-            float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (has_out) {
-                if constexpr (RGB) oref = lds_px4(px.c + 4 * (size_t)(base + d1_in));
-                else oref.x = px.c[base + d1_in];
+            const int d1_out = d1_in + (dpos ? 1 : -1);
+            // the two reference colours straight from the maps: the in pixel for the out sweep (:594-601), the out pixel for the
+            // in sweep (:697-700); minus K for the two-sum form of the visits
+            float4 c_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c_out = c_in;
+            if (has_in) {
+                c_in = map_colour(map_index(ld, d1_in));
+                c_out = map_colour(map_index(ld, d1_out));
             }
-            // segments of the out sweep: [o_from / 16, nsl) or [0, o_to / 16]
-            const int nseg = has_out ? (dpos ? nsl - (o_from >> 4) : (o_to >> 4) + 1) : 0;
+            const float4 oref = make_float4(c_in.x - kc.x, c_in.y - kc.y, c_in.z - kc.z, c_in.w - kc.w);
+            const float4 iref = make_float4(c_out.x - kc.x, c_out.y - kc.y, c_out.z - kc.z, c_out.w - kc.w);
+            // The two pixels next to the crossing point carry a record's largest terms (|t| <= 1).  Their colours are the two
+            // reference colours, so their colour differences are formed DIRECTLY here -- sum_c (I_c - ref_c) g_c, the reference's
+            // own expression -- and only the pixels further out go through the centred sums P: the in pixel is the first pixel
+            // of the in sweep (below), the out pixel the first one of the out sweep, which phase B then leaves out (td > 1).
+            auto direct_diff = [&](const float4 &ci, const float4 &cr, int l) {
+                float4 g4;
+                if constexpr (RGB) g4 = lds_px4(s_g + 4 * (size_t)l);
+                else g4 = make_float4(s_g[l], 0.0f, 0.0f, 0.0f);
+                float d;
+                if constexpr (RGB) {
+                    d = ALPHA ? __builtin_fmaf(ci.y - cr.y, g4.y, (ci.x - cr.x) * g4.x) : (ci.y - cr.y) * g4.y;
+                    d = __builtin_fmaf(ci.z - cr.z, g4.z, d);
+                    d = __builtin_fmaf(ci.w - cr.w, g4.w, d);
+                } else {
+                    d = (ci.x - cr.x) * g4.x;
+                }
+                return d;
+            };
+            float f0 = 0.0f, f1 = 0.0f;  // the out pixel's terms (magnitudes: the sign goes on at the flush, with the out sweep's)
+            if (has_out) {
+                const float d = direct_diff(c_out, c_in, base + d1_out);                           // :631-638
+                const float dm = !(d <= 0.0f) ? d : 0.0f;                                           // :647
+                const float t = fabsf((float)d1_out - qq.x);
+                f0 = dm * __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(qq.y), t, eps_v));            // :649-651
+                f1 = dm * __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(qq.z), t, eps_v));            // :654-656
+            }
+            // segments of what phase B walks of the out sweep -- [o_from + 1, S) or [0, o_to - 1]: [from / 16, nsl) or [0, to / 16]
+            const bool has_b = has_out && o_from < o_to;
+            const int nseg = has_b ? (dpos ? nsl - ((o_from + 1) >> 4) : ((o_to - 1) >> 4) + 1) : 0;
             hist[lane] = 0;
             double in0 = 0.0, in1 = 0.0;
-            {
-                const int in_from = hh.x & 0xffff, in_to = (NR_ROW_OFF & 2) ? -1 : (hh.x >> 16);
-                if (in_from <= in_to) {
-                    // reference colour of the IN sweep: the out pixel (:697-700)
-                    const int lref = base + d1_in + (dpos ? 1 : -1);
-                    float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
-                    if constexpr (RGB) {
-                        const float4 q = lds_px4(px.c + 4 * (size_t)lref);
-                        ra = q.x; rr = q.y; rg = q.z; rb = q.w;
-                    } else {
-                        ra = px.c[lref];
-                    }
-                    const float cross = qq.x, c0k = qq.y, c1k = qq.z;
-                    const int fnr = __float_as_int(qq.w);
-                    // (batches of IN_BATCH pixels whose LDS reads are requested together -- nine in-sweeps in ten are one batch;
-                    // IN_SEG float terms per double addition, like a piece of k_bpm_fast)
-                    for (int s0 = in_from; s0 <= in_to; s0 += IN_SEG) {
-                        const int s1 = min(s0 + IN_SEG - 1, in_to);
-                        float b0 = 0.0f, b1 = 0.0f;
-                        for (int q0 = s0; q0 <= s1; q0 += IN_BATCH) {
-                            int fi[IN_BATCH];
-                            float4 g4[IN_BATCH], c4[IN_BATCH];
+            if (has_in) {
+                const float cross = qq.x, c0k = qq.y, c1k = qq.z;
+                const int fnr = __float_as_int(qq.w);
+                const float d_first = direct_diff(c_in, c_out, base + d1_in);
+                // (batches of IN_BATCH pixels whose LDS reads are requested together -- nine in-sweeps in ten are one batch;
+                // IN_SEG float terms per double addition, like a piece of k_bpm_fast)
+                for (int s0 = in_from; s0 <= in_to; s0 += IN_SEG) {
+                    const int s1 = min(s0 + IN_SEG - 1, in_to);
+                    float b0 = 0.0f, b1 = 0.0f;
+                    for (int q0 = s0; q0 <= s1; q0 += IN_BATCH) {
+                        int fi[IN_BATCH];
+                        float4 g4[IN_BATCH];
+                        float p4[IN_BATCH];
 #pragma unroll
-                            for (int k = 0; k < IN_BATCH; ++k) {
-                                const int l = base + min(q0 + k, s1);
-                                fi[k] = px.fi[l];
-                                if constexpr (RGB) {
-                                    g4[k] = lds_px4(px.g + 4 * (size_t)l);
-                                    c4[k] = lds_px4(px.c + 4 * (size_t)l);
-                                } else {
-                                    g4[k] = make_float4(px.g[l], 0.0f, 0.0f, 0.0f);
-                                    c4[k] = make_float4(px.c[l], 0.0f, 0.0f, 0.0f);
-                                }
-                            }
-#pragma unroll
-                            for (int k = 0; k < IN_BATCH; ++k) {
-                                float diff;
-                                if constexpr (RGB) {
-                                    diff = ALPHA ? __builtin_fmaf(c4[k].y - rr, g4[k].y, (c4[k].x - ra) * g4[k].x) : (c4[k].y - rr) * g4[k].y;  // :709-716
-                                    diff = __builtin_fmaf(c4[k].z - rg, g4[k].z, diff);
-                                    diff = __builtin_fmaf(c4[k].w - rb, g4[k].w, diff);
-                                } else {
-                                    diff = (c4[k].x - ra) * g4[k].x;
-                                }
-                                // :707, :717 (a NaN diff goes through); a pixel beyond the batch's end repeats the last one: dropped
-                                const bool take = (q0 + k <= s1) & (fi[k] == fnr) & !(diff <= 0.0f);
-                                const float t = (float)(q0 + k) - cross;
-                                const float x0 = c0k * t, x1 = c1k * t;                               // :719 / :724 (2 / S folded into c)
-                                const float y0 = x0 + ((0.0f < x0) ? eps_v : -eps_v);                 // :720-721 / :725-726
-                                const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
-                                const float dm = take ? diff : 0.0f;
-                                // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
-                                b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
-                                b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
-                            }
+                        for (int k = 0; k < IN_BATCH; ++k) {
+                            const int l = base + min(q0 + k, s1);
+                            fi[k] = s_fi[l];
+                            p4[k] = s_p[l];
+                            if constexpr (RGB) g4[k] = lds_px4(s_g + 4 * (size_t)l);
+                            else g4[k] = make_float4(s_g[l], 0.0f, 0.0f, 0.0f);
                         }
-                        in0 += (double)b0;
-                        in1 += (double)b1;
+#pragma unroll
+                        for (int k = 0; k < IN_BATCH; ++k) {
+                            float diff = p4[k];                                                    // :709-716
+                            if constexpr (!RGB || ALPHA) diff = __builtin_fmaf(-iref.x, g4[k].x, diff);
+                            if constexpr (RGB) {
+                                diff = __builtin_fmaf(-iref.y, g4[k].y, diff);
+                                diff = __builtin_fmaf(-iref.z, g4[k].z, diff);
+                                diff = __builtin_fmaf(-iref.w, g4[k].w, diff);
+                            }
+                            if (q0 + k == d1_in) diff = d_first;
+                            // :707, :717 (a NaN diff goes through); a pixel beyond the batch's end repeats the last one: dropped
+                            const bool take = (q0 + k <= s1) & (fi[k] == fnr) & !(diff <= 0.0f);
+                            const float t = (float)(q0 + k) - cross;
+                            const float x0 = c0k * t, x1 = c1k * t;                               // :719 / :724 (2 / S folded into c)
+                            const float y0 = x0 + ((0.0f < x0) ? eps_v : -eps_v);                 // :720-721 / :725-726
+                            const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
+                            const float dm = take ? diff : 0.0f;
+                            // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
+                            b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
+                            b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
+                        }
                     }
+                    in0 += (double)b0;
+                    in1 += (double)b1;
                 }
             }
             // ---- the order of phase B: records by falling number of segments (counting sort: a counter per key in LDS; the
             // records without an out sweep behind the others, so that the positions are a permutation of the lanes, which one
             // ds_permute_b32 inverts: lane k then knows which lane holds the k-th record)
             wave_lds_handover();
-            const int key = MAX_SEGS - nseg;  // (only of records with an out sweep: 0 .. MAX_SEGS - 1)
+            const int key = MAX_SEGS - nseg;  // (only of records phase B walks: 0 .. MAX_SEGS - 1)
             int rank = 0;
-            if (has_out) rank = atomicAdd(&hist[key], 1);
+            if (has_b) rank = atomicAdd(&hist[key], 1);
             wave_lds_handover();
             const int cnt = hist[lane], incl = wave_incl_sum_dpp(cnt);
             const int n_out = __builtin_amdgcn_readlane(incl, 63);
             wave_lds_handover();
             hist[lane] = incl - cnt;
             wave_lds_handover();
-            const unsigned long long no_out = __ballot(!has_out);
+            const unsigned long long no_out = __ballot(!has_b);
             int pos = n_out + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(no_out >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)no_out, 0u));
-            if (has_out) pos = hist[key] + rank;
+            if (has_b) pos = hist[key] + rank;
             const int inv = __builtin_amdgcn_ds_permute(pos << 2, lane);
             wave_lds_handover();
             NR_ROW_STAT(0, 1);        // windows
             NR_ROW_STAT(1, nw);       // records
             NR_ROW_STAT(2, n_out);    // records with an out sweep
+#ifdef NR_ROW_STATS
             {
-                int sn = nseg, si = has_out ? (o_to - o_from + 1) : 0;
+                int sn = nseg, si = has_b ? (o_to - o_from) : 0;
                 for (int o = 32; o > 0; o >>= 1) { sn += __shfl_xor(sn, o, WAVE); si += __shfl_xor(si, o, WAVE); }
                 NR_ROW_STAT(3, sn);   // segments of the out sweeps
                 NR_ROW_STAT(4, si);   // pixels of the out sweeps
             }
-            // ---- phase B: four records at a time, one per row of 16 lanes
-            // what a row is handed (from the lane that holds the record)
+#endif
+            // ---- phase B: four records at a time, one per block of 16 lanes
+            // what a block is handed (from the lane that holds the record)
             const float v_ncd = dpos ? -qq.x : qq.x;
             const float v_ac0 = __uint_as_float((__float_as_uint(qq.y) & 0x7fffffffu) | (dpos ? 0u : 0x80000000u));
             const float v_ac1 = fabsf(qq.z);
             int src_next = __builtin_amdgcn_ds_bpermute(row << 2, inv);
-            for (int g0 = 0; g0 < ((NR_ROW_OFF & 1) ? 0 : n_out); g0 += 4) {
+            for (int g0 = 0; g0 < n_out; g0 += 4) {
                 const bool act = g0 + row < n_out;
-                const int src = src_next;  // (of a row without a record: some lane; nothing of it is used)
+                const int src = src_next;  // (of a block without a record: some lane; nothing of it is used)
                 src_next = __builtin_amdgcn_ds_bpermute(((g0 + 4 + row) & 63) << 2, inv);
                 const int sa = src << 2;
                 const int r_nseg = __builtin_amdgcn_ds_bpermute(sa, nseg);
                 float ncd = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ncd)));
                 const float ac0s = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ac0)));
                 const float ac1 = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ac1)));
-                const float ra = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.x)));
-                float rr = 0.0f, rg = 0.0f, rb = 0.0f;
+                float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
+                if constexpr (!RGB || ALPHA) ra = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.x)));
                 if constexpr (RGB) {
                     rr = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.y)));
                     rg = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.z)));
                     rb = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.w)));
                 }
-                // (a row without a record: td = -Inf for every pixel, nothing is taken, nothing stored)
+                // (a block without a record: td = -Inf for every pixel, nothing is taken, nothing stored)
                 if (!act) ncd = -__builtin_inff();
                 const float sdir = __uint_as_float(0x3f800000u | (__float_as_uint(ac0s) & 0x80000000u));
-                // the group walks as many steps as its longest sweep has segments (the first row's: the order of the sort), an
+                // the group walks as many steps as its longest sweep has segments (the first block's: the order of the sort), an
                 // even number; a sweep towards the end of the line ENDS with the group's last step, one from pixel 0 starts with its
                 // first; pixels in front of a sweep or behind it are masked (td <= 0)
                 const int steps = __builtin_amdgcn_readfirstlane(r_nseg), steps2 = (steps + 1) & ~1;
@@ -2002,79 +2113,78 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
                 const bool rpos = !(__float_as_uint(ac0s) >> 31);
                 const int seg0 = rpos ? nsl - steps2 : 0;
                 const int p0 = seg0 * SEG + l16;
-                constexpr int STEP_BYTES = SEG * NC * 4;
                 float pf = (float)p0;
-                const unsigned char *gp = (const unsigned char *)px.g + (size_t)(base + p0) * (NC * 4);
-                auto visit = [&](const float4 &g4, const float4 &c4, const float pfv, float &a0, float &a1) {
-                    float d;                                                                      // :631-638
+                const unsigned char *gp = (const unsigned char *)s_g + (size_t)(base + p0) * (NC * 4);
+                const float *pp = s_p + base + p0;
+                auto visit = [&](const float4 &g4, const float pv, const float pfv, float &a0, float &a1) {
+                    float d = pv;                                                                  // :631-638
+                    if constexpr (!RGB || ALPHA) d = __builtin_fmaf(-ra, g4.x, d);
                     if constexpr (RGB) {
-                        d = ALPHA ? __builtin_fmaf(c4.y - rr, g4.y, (c4.x - ra) * g4.x) : (c4.y - rr) * g4.y;
-                        d = __builtin_fmaf(c4.z - rg, g4.z, d);
-                        d = __builtin_fmaf(c4.w - rb, g4.w, d);
-                    } else {
-                        d = (c4.x - ra) * g4.x;
+                        d = __builtin_fmaf(-rr, g4.y, d);
+                        d = __builtin_fmaf(-rg, g4.z, d);
+                        d = __builtin_fmaf(-rb, g4.w, d);
                     }
-                    const float td = __builtin_fmaf(sdir, pfv, ncd);  // direction * (d1 - d1_cross): > 0 exactly on the sweep's pixels
-                    const bool keep = !(td <= 0.0f) && !(d <= 0.0f);  // (:647: a NaN diff goes through)
+                    // direction * (d1 - d1_cross): > 0 exactly on the sweep's pixels, in (0, 1] on its first one -- phase A's
+                    const float td = __builtin_fmaf(sdir, pfv, ncd);
+                    const bool keep = !(td <= 1.0f) && !(d <= 0.0f);  // (:647: a NaN diff goes through)
                     const float dm = keep ? d : 0.0f;
                     const float y0 = __builtin_fmaf(fabsf(ac0s), fabsf(td), eps_v), y1 = __builtin_fmaf(ac1, fabsf(td), eps_v);  // :649-650 / :654-655
                     a0 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y0), a0);                        // :651 (sign: the flush)
                     a1 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y1), a1);                        // :656
                 };
                 // (plain 16-byte reads: lds_px4's barrier would make every read wait for its data on the spot; the instance without
-                // alpha keeps its first components formally alive BEHIND the visit instead, see lds_px4)
-                auto load = [&](const unsigned char *p, float4 &g4, float4 &c4) {
-                    if constexpr (RGB) {
-                        g4 = *reinterpret_cast<const float4 *>(p);
-                        c4 = *reinterpret_cast<const float4 *>(p + C_OFF);
-                    } else {
-                        g4 = make_float4(*reinterpret_cast<const float *>(p), 0.0f, 0.0f, 0.0f);
-                        c4 = make_float4(*reinterpret_cast<const float *>(p + C_OFF), 0.0f, 0.0f, 0.0f);
-                    }
+                // alpha keeps its first component formally alive BEHIND the visit instead, see lds_px4)
+                auto load = [&](int k, float4 &g4, float &pv) {
+                    if constexpr (RGB) g4 = *reinterpret_cast<const float4 *>(gp + k * (SEG * NC * 4));
+                    else g4 = make_float4(*reinterpret_cast<const float *>(gp + k * (SEG * NC * 4)), 0.0f, 0.0f, 0.0f);
+                    pv = pp[k * SEG];
                 };
-                auto used = [&](const float4 &g4, const float4 &c4) {
-                    if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x), "v"(c4.x));
+                auto used = [&](const float4 &g4) {
+                    if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x));
                 };
                 // a lane adds the terms of its even and of its odd steps in float (chains of up to ROW_CHAIN / 2 terms); everything
                 // above is double: the matrix pipe adds the 2 x 16 chain sums of a block (C operand: chain after chain)
                 double A0 = 0.0, A1 = 0.0;
-                for (int c0 = 0; c0 < ((NR_ROW_OFF & 8) ? 0 : steps2); c0 += k6::ROW_CHAIN) {
+                for (int c0 = 0; c0 < steps2; c0 += k6::ROW_CHAIN) {
                     const int c1 = min(c0 + k6::ROW_CHAIN, steps2);
                     float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
                     // Two steps per pair, two pairs of registers: while one pair is visited the other pair's reads are in flight
                     // (the scheduling barriers keep the compiler from gathering the reads at the top of the loop, where every
                     // iteration would wait for them).  Behind the last step of a chain the reads fetch what is never used (inside
                     // the workgroup's LDS: at most two segments past a line).
-                    float4 gA, cA, gB, cB, gC, cC, gD, cD;
-                    load(gp, gA, cA);
-                    load(gp + STEP_BYTES, gB, cB);
+                    float4 gA, gB, gC, gD;
+                    float pA, pB, pC, pD;
+                    load(0, gA, pA);
+                    load(1, gB, pB);
                     int s = c0;
                     for (; s + 4 <= c1; s += 4) {
-                        load(gp + 2 * STEP_BYTES, gC, cC);
-                        load(gp + 3 * STEP_BYTES, gD, cD);
+                        load(2, gC, pC);
+                        load(3, gD, pD);
                         __builtin_amdgcn_sched_barrier(0);
-                        visit(gA, cA, pf, a0, a1);
-                        used(gA, cA);
-                        visit(gB, cB, pf + (float)SEG, b0, b1);
-                        used(gB, cB);
+                        visit(gA, pA, pf, a0, a1);
+                        used(gA);
+                        visit(gB, pB, pf + (float)SEG, b0, b1);
+                        used(gB);
                         __builtin_amdgcn_sched_barrier(0);
-                        load(gp + 4 * STEP_BYTES, gA, cA);
-                        load(gp + 5 * STEP_BYTES, gB, cB);
+                        load(4, gA, pA);
+                        load(5, gB, pB);
                         __builtin_amdgcn_sched_barrier(0);
-                        visit(gC, cC, pf + (float)(2 * SEG), a0, a1);
-                        used(gC, cC);
-                        visit(gD, cD, pf + (float)(3 * SEG), b0, b1);
-                        used(gD, cD);
+                        visit(gC, pC, pf + (float)(2 * SEG), a0, a1);
+                        used(gC);
+                        visit(gD, pD, pf + (float)(3 * SEG), b0, b1);
+                        used(gD);
                         __builtin_amdgcn_sched_barrier(0);
-                        gp += 4 * STEP_BYTES;
+                        gp += 4 * (SEG * NC * 4);
+                        pp += 4 * SEG;
                         pf += (float)(4 * SEG);
                     }
                     if (s < c1) {  // (the chain's last pair: already requested)
-                        visit(gA, cA, pf, a0, a1);
-                        used(gA, cA);
-                        visit(gB, cB, pf + (float)SEG, b0, b1);
-                        used(gB, cB);
-                        gp += 2 * STEP_BYTES;
+                        visit(gA, pA, pf, a0, a1);
+                        used(gA);
+                        visit(gB, pB, pf + (float)SEG, b0, b1);
+                        used(gB);
+                        gp += 2 * (SEG * NC * 4);
+                        pp += 2 * SEG;
                         pf += (float)(2 * SEG);
                     }
                     double t0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, 1.0, 0.0, 0, 0, 0);
@@ -2093,7 +2203,9 @@ __global__ __launch_bounds__(rowk::NT, 4) void k_bpm_row(
             // :718 / :723): a contribution whose vertex sits on the line is not taken (its coefficient was Inf / NaN).
             if (lane < nw) {
                 double2 a = make_double2(0.0, 0.0);
-                if (has_out) a = acc[lane];
+                if (has_b) a = acc[lane];
+                a.x += (double)f0;
+                a.y += (double)f1;
                 const bool tneg = !dpos;
                 const bool neg0 = ((__float_as_uint(qq.y) >> 31) != 0) != tneg, neg1 = ((__float_as_uint(qq.z) >> 31) != 0) != tneg;
                 const double t0 = (flags & 2) ? in0 + (neg0 ? a.x : -a.x) : 0.0;
@@ -2327,16 +2439,16 @@ int px_band_config(int S, bool rgb, int B, size_t *lds_bytes)
     return 0;
 }
 
-// k_bpm_row's band: the widest power of two of lines (<= one per wave) whose gradients / colours fit their fixed LDS regions;
-// 0: the raster is too large for it (k_bpm_fast takes the launch)
+// k_bpm_row's band: the widest power of two of lines (<= one per wave) whose pixels fit its LDS regions (rowk::MAX_PX); 0: the
+// raster is too large for it (k_bpm_fast takes the launch)
 int row_band_config(int S, bool rgb, int B, size_t *lds_bytes)
 {
-    const size_t nc = rgb ? 4 : 1, c_off = rgb ? rowk::c_off<true>() : rowk::c_off<false>(), SP = ((size_t)S + 31) & ~(size_t)31;
+    const size_t SP = ((size_t)S + 31) & ~(size_t)31;
     if (SP / rowk::SEG > (size_t)rowk::MAX_SEGS) return 0;
     for (int W = rowk::NW; W >= 1; W >>= 1) {
         if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::PX_MIN_WGS) continue;  // (small launches: narrower bands, see px_band_config)
-        if ((size_t)W * SP * nc * 4 > c_off) continue;
-        *lds_bytes = 2 * c_off + align_up((size_t)W * SP * 4, 16) + (size_t)rowk::NW * (rowk::WIN * 16) + NR_ROW_LDS_PAD;
+        if ((size_t)W * SP > (size_t)rowk::MAX_PX) continue;
+        *lds_bytes = rgb ? rowk::lds_bytes<true>() : rowk::lds_bytes<false>();
         return W;
     }
     return 0;
