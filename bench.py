@@ -152,16 +152,17 @@ def upstream_gradients(faces, textures, S, eps, seed, all_ones=False, z_ref=None
 
 # dominant kernel of each stage call (the rest of a stage are small helper launches, see profiles/README.md)
 STAGE_KERNEL = {
-    'forward_face_index_map': 'k_face_raster', 'forward_texture_sampling': 'k_shade', 'backward_pixel_map': 'k_bpm_fast',
+    'forward_face_index_map': 'k_face_raster', 'forward_texture_sampling': 'k_shade', 'backward_pixel_map': 'k_bpm_row',
     'backward_textures': 'k_backward_textures_face', 'backward_depth_map': 'k_backward_depth_face',
 }
 
 
 def k6_band_kernel(B, F, S, rgb, alpha, exact):
-    """Which of K6's two band kernels the library launched for the rgb + alpha stage call of this shape that time_stages()
-    timed through the measurement build (nr_profile_band_kernel_which: the library picks per launch, csrc/nr_backward_pixel_map.hip
-    run_backward_pixel_map).  Without a measurement of that shape: the kernel of small launches."""
-    return time_stages.band_kernel.get((B, F, S, bool(exact)), 'k_bpm_fast')
+    """Which band kernel the library launched for the rgb + alpha stage call of this shape that time_stages() timed through the
+    measurement build (nr_profile_band_kernel_which: asked, not re-derived -- k_bpm_row in the default mode wherever its band
+    fits, k_bpm_fast in the exact mode; csrc/nr_backward_pixel_map.hip k6_row_band).  None without a measurement of that
+    shape (no measurement build in the tree): the roofline then names no kernel and carries no per-kernel traffic."""
+    return time_stages.band_kernel.get((B, F, S, bool(exact)))
 
 
 def algorithmic_bytes(B, F, S, ts):
@@ -311,7 +312,7 @@ def time_stages(faces, textures, S, eps, g_rgb, g_alpha, g_depth, iters, k6_flag
                     if ms >= 0:
                         samples.append(ms * 1e3)
                         # (which of the two band kernels the library picked for this call: asked, not re-derived)
-                        time_stages.band_kernel[(B, F, S, bool(k6_flags & 2))] = ('k_bpm_fast', 'k_bpm_px')[plib.nr_profile_band_kernel_which() == 1]
+                        time_stages.band_kernel[(B, F, S, bool(k6_flags & 2))] = ('k_bpm_fast', 'k_bpm_row')[plib.nr_profile_band_kernel_which() == 1]
             finally:
                 plib.nr_profile_band_kernel(0)
             if samples:
@@ -875,12 +876,12 @@ def main():
         kname = STAGE_KERNEL.get(dominant, dominant)
         if dominant == 'backward_pixel_map':  # (the stage microbenchmark calls K6 with rgb + alpha)
             kname = k6_band_kernel(B, F, S, True, True, args.exact)
-        krec = {k: v for k, v in traffic_rec.get('kernels', {}).items() if k.startswith(kname)}
+        krec = {k: v for k, v in traffic_rec.get('kernels', {}).items() if kname and k.startswith(kname)}
         kernel_traffic = sum(v['fetch'] + v['write'] for v in krec.values()) if krec else None
         stage_traffic = traffic_rec.get('hbm_bytes_per_launch')
         step_bytes = (whole_step_bytes_rgb if c4 else whole_step_bytes)(G, F, S, ts)  # the whole job's compulsory bytes against its step time
         roofline = {
-            'bound': 'hbm', 'kernel': kname + (' (exact mode)' if args.exact and dominant == 'backward_pixel_map' else ''),
+            'bound': 'hbm', 'kernel': (kname + (' (exact mode)' if args.exact and dominant == 'backward_pixel_map' else '')) if kname else None,
             'stage': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': kernel_traffic,
             'traffic_ratio': (kernel_traffic / stage_bytes[dominant]) if kernel_traffic else None,

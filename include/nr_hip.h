@@ -56,7 +56,9 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 500 /* 0.5.0: K6's default mode on the lane-parallel band kernel (k_bpm_px; NR_FLAG_K6_LEGACY keeps k_bpm_fast); the
+#define NR_VERSION 600 /* 0.6.0: K6's default mode on ONE band kernel for every call size (k_bpm_row: a line record per 16 lanes, the
+                          *        sums of a record on the matrix pipe in double); NR_FLAG_K6_PX is ignored;
+                          * 0.5.0: K6's default mode on the lane-parallel band kernel (k_bpm_px; NR_FLAG_K6_LEGACY keeps k_bpm_fast); the
                           *        measurement hook nr_profile_band_kernel left the product ABI (include/nr_hip_profile.h, libnr_hip_prof.so);
                           * 0.4.1: NR_FLAG_SERIAL_BACKWARD (the fused backward's gather shares a launch with K6's line setup);
                           * 0.4.0: NR_FLAG_EXACT_GRADIENT and NR_FLAG_K6_SCAN combine (one band kernel, two arithmetic modes);
@@ -113,14 +115,14 @@ extern "C" {
                                          grad_faces last.  Same values: one float addition per element of grad_faces either
                                          way; a testing / measuring aid. */
 
-#define NR_FLAG_K6_LEGACY 128          /* K6, default arithmetic mode: always the piece-per-lane band kernel of rounds 3-4 (k_bpm_fast) */
-#define NR_FLAG_K6_PX 65536              /* K6, default arithmetic mode: always the lane-parallel band kernel (k_bpm_px, round 5: the pixels
-                                         of a sweep across the lanes of a wave, the line's records one after the other) where its
-                                         band fits the LDS (raster <= 1024 with colours) and eps > 0.  Without either flag the
-                                         library picks per launch by what was measured (large launches at rasters >= 512, single-
-                                         output modes and dense meshes: k_bpm_px; the rest: k_bpm_fast).  Same per-pixel terms,
-                                         summed in a different order; testing / measuring aids.  The exact mode and the scan path
-                                         run on k_bpm_fast. */
+#define NR_FLAG_K6_LEGACY 128          /* K6, default arithmetic mode: the piece-per-lane band kernel of rounds 3-4 (k_bpm_fast) instead of
+                                         k_bpm_row.  A testing / measuring aid: same sweeps, terms rounded and summed another way
+                                         (both within the default mode's bound of the oracle). */
+#define NR_FLAG_K6_PX 65536              /* accepted and ignored since 0.6.0 (it forced round 5's lane-parallel kernel, whose place
+                                         k_bpm_row has taken for every call: the default mode has one band kernel -- 16 lanes per
+                                         line record, four records per wave instruction -- wherever its band fits the LDS (raster
+                                         <= 1024) and eps > 0; the exact mode, the scan path, larger rasters and eps = 0 run on
+                                         k_bpm_fast).  Which kernel a call takes does not depend on its batch size. */
 
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):

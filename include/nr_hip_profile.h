@@ -23,10 +23,10 @@ extern "C" {
  * thread-safe, and the two event packets cost the stream a few microseconds per call: off outside measurements. */
 int nr_profile_band_kernel(int32_t enable);
 float nr_profile_band_kernel_ms(void);
-/* which band kernel the last bracketed launch was: 0 k_bpm_fast, 1 k_bpm_px (-1: none) -- the library picks per launch */
+/* which band kernel the last bracketed launch was: 0 k_bpm_fast, 1 k_bpm_row (-1: none) */
 int nr_profile_band_kernel_which(void);
-/* the per-launch rule itself, as a function of the call (host logic only, callable without a device): 1 when a default-mode call
- * of this shape takes k_bpm_px, 0 for k_bpm_fast */
+/* which band kernel a call takes, as a function of the call (host logic only, callable without a device): 1 k_bpm_row, 0
+ * k_bpm_fast (the exact mode, NR_FLAG_K6_SCAN / _LEGACY, rasters beyond 1024, eps = 0).  The batch size does not enter. */
 int nr_profile_k6_choice(int32_t B, int32_t F, int32_t S, int32_t return_rgb, int32_t return_alpha, double eps, int32_t flags);
 
 #ifdef __cplusplus

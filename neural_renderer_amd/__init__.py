@@ -29,7 +29,7 @@ if _os.environ.get('NR_BACKWARD_ON_CALLER_THREAD', '0') not in ('', '0'):
     graph.backward_on_caller_thread()
 
 # the C ABI's version (include/nr_hip.h NR_VERSION = major * 100 + minor), checked against the loaded library by _lib.load()
-__version__ = '0.5.0'
+__version__ = '0.6.0'
 __all__ = ['Rasterize', 'rasterize', 'rasterize_depth', 'rasterize_rgbad', 'rasterize_silhouettes', 'use_unsafe_rasterizer', 'use_graph_replay',
            'clear_workspace_cache',
            'Renderer', 'cross', 'get_points_from_angles', 'lighting', 'look', 'look_at', 'perspective', 'vertices_to_faces',

@@ -82,3 +82,4 @@ if __name__ == '__main__':
         print(build_variant(sys.argv[1], sys.argv[2:], verbose=True))
     else:
         print(build(force=True, verbose=True))
+        print(build_profile(force=True, verbose=True))

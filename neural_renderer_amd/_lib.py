@@ -58,7 +58,7 @@ SIGNATURES = {
     'nr_frontend_backward_light': (_c.c_int, [_vp] * 7 + [_i32] * 6 + [_cam_p, _light_p, _vp, _sz, _vp]),
 }
 
-NR_VERSION = 500  # include/nr_hip.h; load() refuses a library of another version (a stale build)
+NR_VERSION = 600  # include/nr_hip.h; load() refuses a library of another version (a stale build)
 NR_FLAG_FIX_TEXTURE_BATCH_Z = 1
 NR_FLAG_EXACT_GRADIENT = 2
 NR_FLAG_K6_GLOBAL = 4
@@ -67,7 +67,7 @@ NR_FLAG_ZBUF_EPOCH = 16  # + epoch number << 8 (include/nr_hip.h)
 NR_FLAG_SPARSE_WEIGHT_MAP = 32
 NR_FLAG_SERIAL_BACKWARD = 64
 NR_FLAG_K6_LEGACY = 128
-NR_FLAG_K6_PX = 65536  # (bits 8..15 of a forward's flags carry the epoch number)
+NR_FLAG_K6_PX = 65536  # (accepted and ignored since 0.6.0; bits 8..15 of a forward's flags carry the epoch number)
 NR_E_INDEX = -6
 NR_CAMERA_LOOK_AT = 1
 NR_CAMERA_LOOK = 2

@@ -638,7 +638,7 @@ __device__ __forceinline__ void fast_stage(const FastPx &px, const int32_t *__re
             px.c[l] = al;
             if (px.bg && fi < 0) px.bg[0] = al;
         }
-        if (px.cov && fi >= 0) atomicOr(px.cov + ld * px.CW + (d1 >> 5), 1u << (d1 & 31));  // (k_bpm_px keeps no coverage bits)
+        if (px.cov && fi >= 0) atomicOr(px.cov + ld * px.CW + (d1 >> 5), 1u << (d1 & 31));  // (callers without coverage bits pass none)
     };
     // four adjacent pixels of a map row with one 16-byte load per field: the 4 columns of a vertical band (one thread per
     // row; pixel j -> line j, d1 = y) or 4 consecutive pixels of a horizontal band's line (one thread per quad; pixel j ->
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     // (The same mapping on the forward and gather kernels changed nothing or cost 5 %: their reads are not shared.)
     const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
     const unsigned total_wg = n_bands * 2u * (unsigned)B;
-    // OVF: the launch behind k_bpm_px that serves the images whose records exceed the line buffer -- normally none -- by the scan
+    // OVF: the launch behind k_bpm_row that serves the images whose records exceed the line buffer -- normally none -- by the scan
     // path: a small grid whose workgroups first take one cooperative look at the images' verdicts (none over the buffer: leave)
     // and otherwise walk the bands in strides.  (An instantiation of its own: with the band loop around it the ordinary kernel
     // came out at 116 registers instead of 89 and 7 % slower.)
@@ -1224,8 +1224,8 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     const int band_lo = band * W, band_hi = min(band_lo + W, S) - 1;
     const int nld = band_hi - band_lo + 1;
     const size_t bidx = ((size_t)b * 2 + axis) * n_bands + band;
-    // overflow_only: this launch stands behind k_bpm_px and serves only the images whose records exceed the line buffer, by the
-    // scan path; the band tables are k_bpm_px's (per line), not this kernel's shape
+    // overflow_only: this launch stands behind k_bpm_row and serves only the images whose records exceed the line buffer, by the
+    // scan path; the band tables are k_bpm_row's (per line), not this kernel's shape
     if (overflow_only && lines_ok[b] != 0) return;
     const int n_band_lines = overflow_only ? 1 : band_lines[bidx];
     if (n_band_lines == 0) return;  // step 0: no visible face has a line here
@@ -1364,42 +1364,6 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     }
 }
 
-// ==================================================================================================
-// k_bpm_px (round 5): the band kernel with the sweeps laid ACROSS the lanes.
-//
-// k_bpm_fast gives a lane a PIECE (15 pixels of one sweep) and walks it pixel by pixel out of LDS: every visit is an LDS read,
-// every piece a descriptor, a record decode and a flush, every window a chain of barriers (profiles/r04_pmc_k6.txt: half of the
-// wave-cycles parked, the LDS array 45 % busy with 47 % of it bank conflicts, 48 lane-slots per 13-instruction visit).  Here a
-// WAVE owns a band line: its lanes hold the line's pixels in REGISTERS -- 64 consecutive pixels per chunk, pxk::CH chunks = one
-// group of 256 pixels: the four gradients and sum_c I_c g_c of each pixel -- and the line's records (contiguous: the line setup
-// bins per line, band width 1) are taken 64 at a time, a lane each.  A visit is 15 vector operations whose record constants are
-// SGPR operands and whose pixel data never leaves the registers; nothing is queued, classified or decoded.  Per window of records:
-//   phase A (lane = record)   the record's in sweep (:665-728; nine in ten are <= 4 pixels): k_bpm_fast's class G loop -- LDS
-//       reads, ownership test :707, per-pixel sign of +- eps --, float sums of <= 16 terms, double above; and what phase B
-//       broadcasts from the lane: the out sweep's reference colour (the in pixel, :594-601), |c0|, |c1|, the crossing point, the
-//       sweep's pixel range inside the group and the chunks it touches;
-//   phase B (one record after the other, v_readlane -> SGPRs)   out sweep (:604-657): every chunk the sweep overlaps is one
-//       visit of all 64 lanes (range test: one unsigned comparison); diff = (sum (I - K) g) - sum (ref - K) g, K a colour
-//       near the group's colours (the background), one fused multiply-add per channel; the record's two sums through 2^PX_RED_LEVELS-lane DPP trees in float and LDS atomics in double (ds_add_f64)
-//       onto the record's slot of the wave's window;
-//   flush   one lane per record adds the window's two sums to the double scratch (global_atomic_add_f64), as k_bpm_fast does.
-// Arithmetic of a visit: the tolerance mode of k_bpm_fast (fused multiply-adds, v_rcp_f32), with
-//   dist = sigma * (|c| * |t| + eps),  sigma = sign(c) * sign(t)  -- t = d1 - d1_cross keeps its sign along an out sweep, so
-//   sigma is a property of the record and is applied once to its sum (the rounding of fma(c, t, +-eps) is symmetric in sign:
-//   the same bits as k_bpm_fast's fma(c0k, t, e0)).
-// Images whose records exceed the line buffer (lines_ok == 0) are left to k_bpm_fast's scan path (launched behind this kernel
-// with overflow_only set).  The exact mode (NR_FLAG_EXACT_GRADIENT) stays with k_bpm_fast.
-namespace pxk {
-constexpr int NT = NR_PX_NT;      // threads per workgroup (nr_k6_tune.h: 256 = four waves), a band line per wave
-constexpr int NW = NT / 64;
-constexpr int CH = 4;             // chunks of 64 pixels a wave holds in registers
-constexpr int GROUP = 64 * CH;    // pixels of a line per task
-constexpr int WIN = 64;           // records per window (phase A gives each a lane)
-constexpr int IN_SEG = 16;        // float terms per double addition of an in sweep (a piece of k_bpm_fast holds 15)
-constexpr int IN_BATCH = 4;       // pixels of an in sweep whose LDS reads are requested together
-constexpr size_t LDS_BUDGET = (size_t)10 * 1024 * (NT / 64);  // sixteen waves per 160 KB CU
-}  // namespace pxk
-
 // LDS hand-over between the lanes of ONE wave (its LDS operations execute in order; the fences keep the compiler from moving
 // accesses across)
 __device__ __forceinline__ void wave_lds_handover()
@@ -1409,330 +1373,27 @@ __device__ __forceinline__ void wave_lds_handover()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool RGB, bool ALPHA>
-__global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
-    const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
-    const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, double *__restrict__ scratch,
-    const int *__restrict__ band_lines, const int *__restrict__ band_start, const int *__restrict__ lines_ok,
-    const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, float eps_f, int B,
-    uint4 *__restrict__ zero16, size_t n_zero16)
-{
-    using namespace pxk;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
-    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
-    const unsigned total_wg = n_bands * 2u * (unsigned)B;
-    const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_fast)
-    if (logical >= total_wg) return;
-    if (n_zero16) {  // the fused backward's zero fill of grad_textures rides along (see k_bpm_fast)
-        const size_t per = (n_zero16 + total_wg - 1) / total_wg, z_lo = (size_t)logical * per, z_hi = min(n_zero16, z_lo + per);
-        for (size_t k = z_lo + tid; k < z_hi; k += NT) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
-    if (lines_ok[b] == 0) return;  // records beyond the buffer: k_bpm_fast's scan path serves this image
-    const int band_lo = band * W, nld = min(W, S - band_lo);
-    const size_t lt = ((size_t)b * 2 + axis) * S + band_lo;  // the band's lines in the per-line tables (band width 1)
-    int n_tot = 0;
-    for (int l = 0; l < nld; ++l) n_tot += band_lines[lt + l];
-    if (n_tot == 0) return;  // no visible face has a line here
-
-    constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient / colour arrays: (alpha, r, g, b) or alpha alone
-    const int SP = S;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { unsigned char *p = smem + off; off += (bytes + 15) & ~(size_t)15; return p; };
-    FastPx px;
-    px.fi = (int *)carve((size_t)W * SP * 4);
-    px.g = (float *)carve((size_t)W * SP * NC * 4);
-    px.c = (float *)carve((size_t)W * SP * NC * 4);
-    px.bg = nullptr; px.cov = nullptr; px.CW = 0; px.span = nullptr;
-    double *s_acc = (double *)carve((size_t)NW * WIN * 16);
-    // a line longer than one group of GROUP pixels is cut into n_groups EQUAL runs of whole chunks (raster 384: 2 x 192, not
-    // 256 + 128 -- the waves of a workgroup finish together)
-    // (four runs instead of three for a one-line band of 576 ... 768 pixels, so that no wave idles, was measured: 0 ... +9 %)
-    const int n_groups = (S + GROUP - 1) / GROUP, gpx = (((S + n_groups - 1) / n_groups) + 63) & ~63;
-    // A band narrower than the workgroup has waves (small launches: the host narrows the bands to have enough workgroups) deals
-    // the records of a line to n_parts waves, in runs of WIN / n_parts: the critical path of a workgroup is its longest line.
-    const int n_parts = max(1, NW / (W * n_groups)), sub_win = WIN / n_parts;
-    const BandLine *recs_b = line_buf + (size_t)b * cap;
-    // (the first window of the wave's first line is requested in front of the staging loads: one global round trip less on the
-    // workgroup's critical path)
-    int4 hh_first = make_int4(1, 1, 0, 0);
-    float4 qq_first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (wave < nld * n_groups * n_parts) {
-        const int task = wave / n_parts, part = wave - task * n_parts, ld = task / n_groups;
-        const int n_rec = band_lines[lt + ld], r = part * sub_win + lane;
-        if (lane < sub_win && r < n_rec) {
-            const BandLine *R = recs_b + band_start[lt + ld] + r;
-            hh_first = *reinterpret_cast<const int4 *>(R);
-            qq_first = *reinterpret_cast<const float4 *>(&R->cross);
-        }
-    }
-    fast_stage<RGB, ALPHA, NT>(px, fi_map, rgb_map, alpha_map, g_rgb, g_alpha, (size_t)b * S * S, axis, band_lo, nld, S, SP);
-    __syncthreads();
-
-    int lane_zero = 0;
-    asm volatile("" : "+v"(lane_zero));
-    float eps_v = eps_f;
-    asm volatile("" : "+v"(eps_v));  // (a VGPR: the visit's fma takes |c| from an SGPR, and one SGPR is all a VALU operation reads)
-    double *acc = s_acc + wave * (WIN * 2);
-    for (int vt = wave; vt < nld * n_groups * n_parts; vt += NW) {
-        const int task = vt / n_parts, part = vt - task * n_parts;
-        const int ld = task / n_groups, grp = task - ld * n_groups;
-        const int n_rec = band_lines[lt + ld];
-        if (n_rec == 0) continue;
-        const BandLine *recs = recs_b + band_start[lt + ld];
-        const int base = ld * SP, gb = grp * gpx;
-        // ---- the group's pixels: gradients, colours, coordinate (a lane beyond the line repeats the last pixel; no mask reaches it)
-        // The colour difference of a visit in two sums: sum_c (I_c - ref_c) g_c = sum_c (I_c - K_c) g_c - sum_c (ref_c - K_c) g_c.
-        // The first sum is a property of the pixel (pq: formed once per group in double, rounded once), the second one fused
-        // multiply-add per channel on top of it -- four operations of a visit instead of eight, and the colours leave the registers.
-        // K is any colour NEAR the group's colours: with K = 0 the two sums are large where the colours are large, and a scene whose
-        // background is as bright as its faces (every term the small difference of large products) came out 3 ... 6e-4 off (a soak
-        // run of tests/test_fuzz_gpu.py found it).  K = the colour of an uncovered pixel of the group -- the background: the sum
-        // of a background pixel is then exactly 0 and a visit computes (bg - ref) g like k_bpm_fast's class U -- or, in a group
-        // without one, of its first pixel; not finite: 0.
-        float gq[CH][NC], cq[CH][NC], pq[CH], d1f[CH];
-        int fq[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int d1 = gb + 64 * j + lane, l = base + min(d1, S - 1);
-            d1f[j] = (float)d1;
-            fq[j] = d1 < S ? px.fi[l] : 0;
-            if constexpr (RGB) {
-                const float4 g4 = lds_px4(px.g + 4 * (size_t)l), c4 = lds_px4(px.c + 4 * (size_t)l);
-                gq[j][0] = g4.x; gq[j][NC - 3] = g4.y; gq[j][NC - 2] = g4.z; gq[j][NC - 1] = g4.w;
-                cq[j][0] = c4.x; cq[j][NC - 3] = c4.y; cq[j][NC - 2] = c4.z; cq[j][NC - 1] = c4.w;
-            } else {
-                gq[j][0] = px.g[l];
-                cq[j][0] = px.c[l];
-            }
-        }
-        float kc[NC];
-        {
-            bool found = false;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) kc[c] = bcast_f(cq[0][c], 0);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const unsigned long long m = __ballot(fq[j] < 0);
-                if (!found && m) {
-                    const int r = (int)__builtin_ctzll(m);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) kc[c] = bcast_f(cq[j][c], r);
-                    found = true;
-                }
-            }
-            bool fin = true;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) fin = fin && (fabsf(kc[c]) <= 3.0e38f);
-            if (!fin) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) kc[c] = 0.0f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if constexpr (RGB) {
-                pq[j] = (float)((ALPHA ? (double)(cq[j][0] - kc[0]) * (double)gq[j][0] : 0.0) +
-                                (double)(cq[j][NC - 3] - kc[NC - 3]) * (double)gq[j][NC - 3] +
-                                (double)(cq[j][NC - 2] - kc[NC - 2]) * (double)gq[j][NC - 2] +
-                                (double)(cq[j][NC - 1] - kc[NC - 1]) * (double)gq[j][NC - 1]);
-            } else {
-                pq[j] = (cq[j][0] - kc[0]) * gq[j][0];
-            }
-        }
-        for (int w0 = part * sub_win; w0 < n_rec; w0 += sub_win * n_parts) {
-            const int nw = min(sub_win, n_rec - w0);
-            // ---- phase A: lane = record.  The lane keeps its record for the flush, walks the record's in sweep, and prepares what
-            // phase B broadcasts from it: the reference colour of the OUT sweep (the in pixel, :594-601), |c0|, |c1|, the crossing
-            // point, and the sweep's pixel range with the chunks it touches.
-            int4 hh = hh_first;
-            float4 qq = qq_first;
-            if (!(vt == wave && w0 == part * sub_win)) {  // (not the window requested in front of the staging)
-                hh = make_int4(1, 1, 0, 0);
-                qq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (lane < nw) {
-                    const BandLine *R = recs + w0 + lane;
-                    hh = *reinterpret_cast<const int4 *>(R);
-                    qq = *reinterpret_cast<const float4 *>(&R->cross);
-                }
-            }
-            const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
-            const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
-            const bool has_out = o_from <= o_to && o_to >= gb && o_from < gb + gpx;  // (:604: the in pixel is the face's)
-            float4 oref = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // (minus K: see the group's pixels above)
-            if (has_out) {
-                if constexpr (RGB) {
-                    oref = lds_px4(px.c + 4 * (size_t)(base + d1_in));
-                    oref.x -= kc[0]; oref.y -= kc[NC - 3]; oref.z -= kc[NC - 2]; oref.w -= kc[NC - 1];
-                } else {
-                    oref.x = px.c[base + d1_in] - kc[0];
-                }
-            }
-            // the sweep inside this group: first pixel, last pixel (relative to the group), chunks touched
-            const int rel_from = max(o_from - gb, 0), rel_to = min(o_to - gb, gpx - 1);
-            const int pk = has_out ? (rel_from | (rel_to - rel_from) << 8 | ((2 << (rel_to >> 6)) - (1 << (rel_from >> 6))) << 16) : 0;
-            double in0 = 0.0, in1 = 0.0;
-            if (grp == 0) {
-                const int in_from = hh.x & 0xffff, in_to = hh.x >> 16;
-                if (in_from <= in_to) {
-                    // reference colour of the IN sweep: the out pixel (:697-700)
-                    const int lref = base + d1_in + ((flags & 8) ? 1 : -1);
-                    float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
-                    if constexpr (RGB) {
-                        const float4 q = lds_px4(px.c + 4 * (size_t)lref);
-                        ra = q.x; rr = q.y; rg = q.z; rb = q.w;
-                    } else {
-                        ra = px.c[lref];
-                    }
-                    const float cross = qq.x, c0k = qq.y, c1k = qq.z;
-                    const int fnr = __float_as_int(qq.w);
-                    // (batches of IN_BATCH pixels whose LDS reads are requested together -- nine in-sweeps in ten are one batch;
-                    // IN_SEG float terms per double addition, like a piece of k_bpm_fast)
-                    for (int s0 = in_from; s0 <= in_to; s0 += IN_SEG) {
-                        const int s1 = min(s0 + IN_SEG - 1, in_to);
-                        float b0 = 0.0f, b1 = 0.0f;
-                        for (int q0 = s0; q0 <= s1; q0 += IN_BATCH) {
-                            int fi[IN_BATCH];
-                            float4 g4[IN_BATCH], c4[IN_BATCH];
-#pragma unroll
-                            for (int k = 0; k < IN_BATCH; ++k) {
-                                const int l = base + min(q0 + k, s1);
-                                fi[k] = px.fi[l];
-                                if constexpr (RGB) {
-                                    g4[k] = lds_px4(px.g + 4 * (size_t)l);
-                                    c4[k] = lds_px4(px.c + 4 * (size_t)l);
-                                } else {
-                                    g4[k] = make_float4(px.g[l], 0.0f, 0.0f, 0.0f);
-                                    c4[k] = make_float4(px.c[l], 0.0f, 0.0f, 0.0f);
-                                }
-                            }
-#pragma unroll
-                            for (int k = 0; k < IN_BATCH; ++k) {
-                                float diff;
-                                if constexpr (RGB) {
-                                    diff = ALPHA ? __builtin_fmaf(c4[k].y - rr, g4[k].y, (c4[k].x - ra) * g4[k].x) : (c4[k].y - rr) * g4[k].y;  // :709-716
-                                    diff = __builtin_fmaf(c4[k].z - rg, g4[k].z, diff);
-                                    diff = __builtin_fmaf(c4[k].w - rb, g4[k].w, diff);
-                                } else {
-                                    diff = (c4[k].x - ra) * g4[k].x;
-                                }
-                                // :707, :717 (a NaN diff goes through); a pixel beyond the batch's end repeats the last one: dropped
-                                const bool take = (q0 + k <= s1) & (fi[k] == fnr) & !(diff <= 0.0f);
-                                const float t = (float)(q0 + k) - cross;
-                                const float x0 = c0k * t, x1 = c1k * t;                               // :719 / :724 (2 / S folded into c)
-                                const float y0 = x0 + ((0.0f < x0) ? eps_v : -eps_v);                 // :720-721 / :725-726
-                                const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
-                                const float dm = take ? diff : 0.0f;
-                                // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
-                                b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
-                                b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
-                            }
-                        }
-                        in0 += (double)b0;
-                        in1 += (double)b1;
-                    }
-                }
-            }
-            reinterpret_cast<double2 *>(acc)[lane] = make_double2(0.0, 0.0);  // the window's out-sweep sums (magnitudes)
-            wave_lds_handover();
-            // ---- phase B: the window's out sweeps, one record after the other; the record's constants come from its lane of
-            // phase A (v_readlane: SGPR operands of the visits)
-            float v_ac0 = fabsf(qq.y), v_ac1 = fabsf(qq.z);
-            asm volatile("" : "+v"(v_ac0), "+v"(v_ac1));  // (computed here, once, not per record)
-            // (everything phase A requested has arrived: inside the loop nothing then waits for an LDS counter, behind which the
-            // four-lane atomics of the previous record would stand)
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            for (unsigned long long todo = __ballot(has_out); todo; todo &= todo - 1) {
-                const int r = (int)__builtin_ctzll(todo);
-                const int spk = __builtin_amdgcn_readlane(pk, r);
-                const float cross = bcast_f(qq.x, r), ac0 = bcast_f(v_ac0, r), ac1 = bcast_f(v_ac1, r);
-                const float ra = bcast_f(oref.x, r);
-                float rr = 0.0f, rg = 0.0f, rb = 0.0f;
-                if constexpr (RGB) { rr = bcast_f(oref.y, r); rg = bcast_f(oref.z, r); rb = bcast_f(oref.w, r); }
-                const unsigned rel0 = (unsigned)(spk & 0xff), len = (unsigned)((spk >> 8) & 0xff);
-                float a0 = 0.0f, a1 = 0.0f;
-                // (A straight-line block per possible run of chunks, so that the visits of a record's chunks could be interleaved, was
-                // built and measured: the compiler keeps the visits one after the other in either scheduling strategy, and the
-                // ten blocks cost 23 % more instructions -- 217 vs 172 us.)
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    if (!(spk & (0x10000 << j))) continue;  // (bits 16..19: the chunks the sweep touches)
-                    float d;                                                                   // :631-638
-                    if constexpr (k6::PX_PDOT) {
-                        d = pq[j];
-                        if constexpr (!RGB || ALPHA) d = __builtin_fmaf(-ra, gq[j][0], d);
-                        if constexpr (RGB) {
-                            d = __builtin_fmaf(-rr, gq[j][NC - 3], d);
-                            d = __builtin_fmaf(-rg, gq[j][NC - 2], d);
-                            d = __builtin_fmaf(-rb, gq[j][NC - 1], d);
-                        }
-                    } else if constexpr (RGB) {
-                        d = ALPHA ? __builtin_fmaf(cq[j][NC - 3] - rr, gq[j][NC - 3], (cq[j][0] - ra) * gq[j][0])
-                                  : (cq[j][NC - 3] - rr) * gq[j][NC - 3];
-                        d = __builtin_fmaf(cq[j][NC - 2] - rg, gq[j][NC - 2], d);
-                        d = __builtin_fmaf(cq[j][NC - 1] - rb, gq[j][NC - 1], d);
-                    } else {
-                        d = (cq[j][0] - ra) * gq[j][0];
-                    }
-                    // inside the sweep (one unsigned comparison) and :647 (a NaN diff goes through)
-                    const bool keep = ((unsigned)(64 * j + lane) - rel0 <= len) && !(d <= 0.0f);
-                    const float dm = keep ? d : 0.0f;
-                    const float t = d1f[j] - cross;
-                    const float y0 = __builtin_fmaf(ac0, fabsf(t), eps_v), y1 = __builtin_fmaf(ac1, fabsf(t), eps_v);  // :649-650 / :654-655
-                    a0 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y0), a0);                     // :651 (sign: the flush)
-                    a1 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y1), a1);                     // :656
-                }
-                // runs of 2^PX_RED_LEVELS lanes in float (a DPP tree), their sums in double onto the record's slot
-                a0 += dpp_row_shr_v<1>(a0); a1 += dpp_row_shr_v<1>(a1);
-                a0 += dpp_row_shr_v<2>(a0); a1 += dpp_row_shr_v<2>(a1);
-                if constexpr (k6::PX_RED_LEVELS >= 3) { a0 += dpp_row_shr_v<4>(a0); a1 += dpp_row_shr_v<4>(a1); }
-                if constexpr (k6::PX_RED_LEVELS >= 4) { a0 += dpp_row_shr_v<8>(a0); a1 += dpp_row_shr_v<8>(a1); }
-                if ((lane & ((1 << k6::PX_RED_LEVELS) - 1)) == (1 << k6::PX_RED_LEVELS) - 1) {
-                    // (lane_zero: an address the compiler cannot prove uniform -- for a uniform one its atomic optimizer replaces
-                    // the four-lane ds_add_f64 by a readlane loop of double additions, ~50 instructions per record)
-                    atomicAdd(&acc[2 * r + lane_zero], (double)a0);
-                    atomicAdd(&acc[2 * r + 1 + lane_zero], (double)a1);
-                }
-            }
-            wave_lds_handover();
-            // ---- flush: in sweep + out sweep of each record -> global double scratch [list position][vertex][x|y].
-            // Out sweep: grad -= diff / (sigma * |dist|), sigma = sign(c) * sign(t), sign(t) = the direction (t = d1 - d1_cross
-            // keeps its sign beyond the crossing point): the magnitudes were summed, the sign goes on here.  :648 / :653 (and
-            // :718 / :723): a contribution whose vertex sits on the line is not taken (its coefficient was Inf / NaN).
-            if (lane < nw) {
-                const double2 a = reinterpret_cast<const double2 *>(acc)[lane];
-                const bool tneg = !(flags & 8);
-                const bool neg0 = ((__float_as_uint(qq.y) >> 31) != 0) != tneg, neg1 = ((__float_as_uint(qq.z) >> 31) != 0) != tneg;
-                const double t0 = (flags & 2) ? in0 + (neg0 ? a.x : -a.x) : 0.0;
-                const double t1 = (flags & 4) ? in1 + (neg1 ? a.y : -a.y) : 0.0;
-                const int tgt = hh.w, pos = tgt & 0x0fffffff;
-                double *dst = scratch + ((size_t)b * F + pos) * 6 + (1 - axis);
-                if (t0 != 0.0) atomicAdd(dst + 2 * ((tgt >> 28) & 3), t0);
-                if (t1 != 0.0) atomicAdd(dst + 2 * ((tgt >> 30) & 3), t1);
-            }
-            wave_lds_handover();
-        }
-    }
-}
-
 // ==================================================================================================
-// k_bpm_row (round 6): the out sweeps on BLOCKS of 16 lanes -- four records per wave instruction.
+// k_bpm_row (round 6): the band kernel of the default arithmetic mode.  A WAVE owns a band line, a BLOCK of 16 lanes a line
+// record: four records per wave instruction.
 //
-// k_bpm_px visits one record at a time with all 64 lanes: a sweep of ~127 pixels (the average of a 256 x 256 teapot view) leaves
-// its last 64-lane chunk half empty, and every record pays a frame of its own (8 v_readlane, four chunk branches, two DPP
-// trees, two LDS atomics): 45 instructions of frame around the visits (profiles/r05_pmc_k6.txt).
-// Here 16 lanes take a record, the four such blocks of a wave four different ones:
-//   * the band's pixels stay in LDS (as in k_bpm_fast) -- per pixel the four gradients g and ONE sum P = sum_c (I_c - K_c) g_c
-//     (formed in double at the staging, rounded once; K: the colour of the line's first pixel, i.e. the background almost
-//     always -- see k_bpm_px on why the sums are centred), 24 bytes with the face index: five workgroups per CU;
-//     a block reads 16 consecutive pixels of its line per step, in segments ALIGNED to 16 pixels;
+// k_bpm_fast gives a lane a PIECE (15 pixels of one sweep) and walks it pixel by pixel out of LDS: every piece a descriptor, a
+// record decode and a flush, every window a chain of barriers.  Round 5's k_bpm_px (gone) held a line's pixels in registers and
+// visited ONE record at a time with all 64 lanes: 45 instructions of frame per record around its visits, and a sweep's last
+// 64-lane chunk half empty.  Both ran at one third of the issued lanes useful.  Here:
+//   * the band's pixels stay in LDS -- per pixel the four gradients g and ONE sum P = sum_c (I_c - K_c) g_c (formed in double at
+//     the staging, rounded once), 24 bytes with the face index: five workgroups per CU.  K is the colour of the line's first
+//     pixel, i.e. the background almost always: the sum of a background pixel is then exactly 0, and any colour NEAR the line's
+//     colours serves -- with K = 0 a scene whose background is as bright as its faces (every term the small difference of
+//     large products) came out 3 ... 6e-4 off in round 5;
+//   * a block reads 16 consecutive pixels of its line per step, in segments ALIGNED to 16 pixels;
 //   * an out sweep runs from the crossing point to the image border (:607-609), so "inside the sweep" is the sign of
 //     td = direction * (d1 - d1_cross), a value the visit needs anyway: no range arithmetic, and a block may start segments
 //     before its sweep or run on behind it -- those lanes are masked by the same comparison;
-//   * the records of a window are SORTED by their number of segments (a counting sort in LDS) and dealt to the blocks four at a
-//     time: the blocks of a group walk (nearly) the same number of steps (lane efficiency 0.84 at raster 256, 0.90 at 512:
-//     scripts/row_stats.py), so the group is one loop with a uniform trip count and ONE reduction for four records;
+//   * the records of a window (64: a lane each in phase A) are SORTED by their number of segments (a counting sort in LDS) and
+//     dealt to the blocks four at a time: the blocks of a group walk (nearly) the same number of steps (lane efficiency 0.84 at
+//     raster 256, 0.90 at 512: scripts/row_stats.py), so the group is one loop with a uniform trip count and ONE reduction for
+//     four records;
 //   * that reduction is the matrix pipe's: a block is the 16 lanes of one block of v_mfma_f64_4x4x4_4b_f64 -- lanes
 //     4 b .. 4 b + 3 of each of the wave's four rows -- and two of these instructions with a matrix of ones add up a block's 16
 //     values in DOUBLE (the first contracts over the rows, the second over the four lanes), the sum arriving in every lane of
@@ -1741,11 +1402,19 @@ __global__ __launch_bounds__(pxk::NT, 4) void k_bpm_px(
 //   * a block's pixel quads are dealt to its four rows so that the 16-byte LDS reads stay conflict-free whatever segments the
 //     four blocks are at (the LDS serves lanes {0-3, 12-15, 20-27}, ... together: quad = (row + 2 (b >> 1)) mod 4);
 //   * a record's constants reach its block by ds_bpermute_b32 from the lane that prepared them in phase A.
-// A visit: diff = P - sum_c (ref_c - K_c) g_c (four fused multiply-adds), dist = |c| |t| + eps for the two vertices, two
-// v_rcp_f32 (a quarter-rate instruction on this part: a third of the visit's issue time), two fused multiply-adds; the sign of
-// the record goes on at the flush as in k_bpm_px: 15 vector operations and two LDS reads for up to 64 useful lanes.
-// Phase A (a lane per record): the in sweeps (:665-728) in the same two-sum form, the two reference colours of a record
-// (the in and the out pixel, :594-601 / :697-700) straight from the maps -- no colours in LDS.
+// A visit (:630-657): diff = P - sum_c (ref_c - K_c) g_c (four fused multiply-adds), dist = |c| |t| + eps for the two vertices
+// (t = d1 - d1_cross keeps its sign along an out sweep, so sigma = sign(c) sign(t) is a property of the record: the magnitudes
+// are summed, the sign goes on once, at the flush), two v_rcp_f32 (a quarter-rate instruction on this part: a third of the
+// visit's issue time, scripts/dev/valu_rate_probe.hip), two fused multiply-adds: 15 vector operations and two LDS reads for up
+// to 64 useful lanes.
+// Phase A (a lane per record): the record, its two reference colours straight from the maps (the in and the out pixel,
+// :594-601 / :697-700 -- no colours in LDS), its in sweep (:665-728; nine in ten are <= 4 pixels) in the same two-sum form --
+// and the two pixels next to the crossing point, which carry a record's largest terms, in the reference's DIRECT form
+// sum_c (I_c - ref_c) g_c: their colours are the two reference colours (error levels, direct / centred sums for them: config 4
+// 4.6e-5 / 5.9e-5, headline 3.3e-5 / 4.1e-5).
+// Flush: one lane per record adds in sweep + out sweep to the double scratch (global_atomic_add_f64), as k_bpm_fast does.
+// Images whose records exceed the line buffer (lines_ok == 0) are left to k_bpm_fast's scan path (launched behind this kernel
+// with overflow_only set).  The exact mode (NR_FLAG_EXACT_GRADIENT) stays with k_bpm_fast.
 #ifndef NR_ROW_LDS_PAD  // (development: unused LDS per workgroup, to probe what a workgroup less per CU costs)
 #define NR_ROW_LDS_PAD 0
 #endif
@@ -1754,7 +1423,8 @@ constexpr int NT = 256, NW = NT / 64;
 constexpr int WIN = 64;            // records per window (a lane each in phase A)
 constexpr int SEG = 16;            // pixels per step of a block
 constexpr int MAX_SEGS = 64;       // segments of a line, at most (raster <= 1024): the sort's keys
-constexpr int IN_SEG = 16, IN_BATCH = 4;  // (in sweeps: as k_bpm_px)
+constexpr int IN_SEG = 16;        // float terms per double addition of an in sweep (a piece of k_bpm_fast holds 15)
+constexpr int IN_BATCH = 4;       // pixels of an in sweep whose LDS reads are requested together
 constexpr int MAX_PX = 1024;       // pixels of a band, at most
 // LDS of a workgroup: gradients [W][SP][NC] | sums P [W][SP] | face indices [W][SP] | K of the band's lines | a window per wave
 template <bool RGB> constexpr int g_bytes() { return RGB ? MAX_PX * 16 : MAX_PX * 4; }
@@ -1825,10 +1495,7 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
         if constexpr (RGB) { c.y = rgb_map[3 * gi]; c.z = rgb_map[3 * gi + 1]; c.w = rgb_map[3 * gi + 2]; }
         return c;
     };
-    // K of a line: the colour of its first pixel -- an uncovered one in most images, whose sum P is then exactly 0 and whose visit
-    // computes (bg - ref) g like k_bpm_fast's class U; any colour NEAR the line's colours serves (with K = 0 a scene whose
-    // background is as bright as its faces -- every term the small difference of large products -- came out 3 ... 6e-4 off in
-    // round 5); not finite: 0
+    // K of a line: the colour of its first pixel (see above); not finite: 0
     auto line_k = [&](int ld) {
         float4 k = map_colour(map_index(ld, 0));
         const bool fin = fabsf(k.x) <= 3.0e38f && fabsf(k.y) <= 3.0e38f && fabsf(k.z) <= 3.0e38f && fabsf(k.w) <= 3.0e38f;
@@ -2142,22 +1809,23 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                 auto used = [&](const float4 &g4) {
                     if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x));
                 };
-                // a lane adds the terms of its even and of its odd steps in float (chains of up to ROW_CHAIN / 2 terms); everything
-                // above is double: the matrix pipe adds the 2 x 16 chain sums of a block (C operand: chain after chain)
-                double A0 = 0.0, A1 = 0.0;
-                for (int c0 = 0; c0 < steps2; c0 += k6::ROW_CHAIN) {
-                    const int c1 = min(c0 + k6::ROW_CHAIN, steps2);
-                    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+                // A lane adds the terms of its even and of its odd segments in float (<= 8 terms each at raster 256, 32 at 1024: the
+                // terms fall off like 1 / t); everything above is double: the matrix pipe adds the 2 x 16 sums of a block.  seg0 is
+                // even, so which of a sweep's terms share a float sum does not depend on the other records of its group: a record's
+                // sums are the same bits whatever window, group or launch it is part of.  (Chains cut every 16 / 8 / 4 steps,
+                // each with a reduction of its own: +0 / +4 / +12 % kernel time at raster 256, error levels unchanged.)
+                float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+                {
                     // Two steps per pair, two pairs of registers: while one pair is visited the other pair's reads are in flight
                     // (the scheduling barriers keep the compiler from gathering the reads at the top of the loop, where every
-                    // iteration would wait for them).  Behind the last step of a chain the reads fetch what is never used (inside
+                    // iteration would wait for them).  Behind the group's last step the reads fetch what is never used (inside
                     // the workgroup's LDS: at most two segments past a line).
                     float4 gA, gB, gC, gD;
                     float pA, pB, pC, pD;
                     load(0, gA, pA);
                     load(1, gB, pB);
-                    int s = c0;
-                    for (; s + 4 <= c1; s += 4) {
+                    int s = 0;
+                    for (; s + 4 <= steps2; s += 4) {
                         load(2, gC, pC);
                         load(3, gD, pD);
                         __builtin_amdgcn_sched_barrier(0);
@@ -2178,22 +1846,19 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                         pp += 4 * SEG;
                         pf += (float)(4 * SEG);
                     }
-                    if (s < c1) {  // (the chain's last pair: already requested)
+                    if (s < steps2) {  // (the last pair: already requested)
                         visit(gA, pA, pf, a0, a1);
                         used(gA);
                         visit(gB, pB, pf + (float)SEG, b0, b1);
                         used(gB);
-                        gp += 2 * (SEG * NC * 4);
-                        pp += 2 * SEG;
-                        pf += (float)(2 * SEG);
                     }
-                    double t0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, 1.0, 0.0, 0, 0, 0);
-                    double t1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a1, 1.0, 0.0, 0, 0, 0);
-                    t0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b0, 1.0, t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b1, 1.0, t1, 0, 0, 0);
-                    A0 = __builtin_amdgcn_mfma_f64_4x4x4f64(t0, 1.0, A0, 0, 0, 0);
-                    A1 = __builtin_amdgcn_mfma_f64_4x4x4f64(t1, 1.0, A1, 0, 0, 0);
                 }
+                double A0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, 1.0, 0.0, 0, 0, 0);
+                double A1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a1, 1.0, 0.0, 0, 0, 0);
+                A0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b0, 1.0, A0, 0, 0, 0);
+                A1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b1, 1.0, A1, 0, 0, 0);
+                A0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, 1.0, 0.0, 0, 0, 0);
+                A1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, 1.0, 0.0, 0, 0, 0);
                 if (act && lane == (row << 2)) acc[src] = make_double2(A0, A1);  // (every lane of the block holds the sums)
             }
             wave_lds_handover();
@@ -2267,9 +1932,11 @@ struct BpmLayout {
 size_t line_capacity(int F, int S)
 {
     // + S sqrt(F): a mesh whose V visible faces tile a fixed share of the image has ~ sqrt(V) S records (teapot views: ~100 k at
-    // 1024^2, over 8 F + 32 S from raster ~600 on: the scan path cost k_bpm_fast 30 % there and k_bpm_px -- whose overflow launch
-    // strides over one-line bands -- a factor)
-    const size_t want = (size_t)8 * F + (size_t)32 * S + (size_t)((double)S * sqrt((double)F));
+    // 1024^2, over 8 F + 32 S from raster ~600 on: the scan path cost k_bpm_fast 30 % there and the lane-parallel kernel -- whose
+    // overflow launch strides over one-line bands -- a factor).  1.2 S sqrt(F): a mesh that FILLS the image has ~2.1 sqrt(F) S
+    // records, which this holds for every raster up to 1264 -- so up to k_bpm_row's largest raster nothing about a mesh's
+    // coverage has to be guessed when the band kernel is chosen
+    const size_t want = (size_t)8 * F + (size_t)32 * S + (size_t)(1.2 * (double)S * sqrt((double)F));
     // (the images' buffers follow one another: a stride near a multiple of 2 MiB -- 65 579 records x 32 B at the headline shape --
     // puts the same band of every image on the same memory channels and cost k_line_setup 3 us of 25; the stride is kept at
     // 34 KiB past a multiple of 64 KiB)
@@ -2412,30 +2079,12 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     // 1-D grid: the kernel maps ids to (image, axis, band) per XCD
-    // (overflow-only launch behind k_bpm_px: a resident grid that strides over the bands.  1024 workgroups: with nothing to do
+    // (overflow-only launch behind k_bpm_row: a resident grid that strides over the bands.  1024 workgroups: with nothing to do
     // it costs ~4 us (256: ~3), with every image over the line buffer -- 32 teapot views at 1024^2 -- 5.0 instead of 7.3 ms)
     const unsigned grid = overflow_only ? (total_wg < k6::OVF_GRID ? total_wg : k6::OVF_GRID) : xcd_grid(total_wg);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
                        eps, k2s, B, win_lines, qcap, (uint4 *)zero_ptr, zero_bytes / 16);
-    return 0;
-}
-
-// k_bpm_px's band: the widest power of two of lines (<= one per wave) whose pixels fit the LDS budget beside the waves'
-// windows; 0: the raster is too large for it (k_bpm_fast takes the launch)
-int px_band_config(int S, bool rgb, int B, size_t *lds_bytes)
-{
-    const size_t nc = rgb ? 4 : 1;
-    for (int W = pxk::NW; W >= 1; W >>= 1) {
-        // (small launches: narrower bands until there are k6::PX_MIN_WGS band workgroups; the waves of a workgroup then share
-        // the records of a line)
-        if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::PX_MIN_WGS) continue;
-        const size_t bytes = align_up((size_t)W * S * 4, 16) + 2 * align_up((size_t)W * S * nc * 4, 16) + (size_t)pxk::NW * pxk::WIN * 16;
-        if (bytes <= pxk::LDS_BUDGET) {
-            *lds_bytes = bytes;
-            return W;
-        }
-    }
     return 0;
 }
 
@@ -2446,7 +2095,7 @@ int row_band_config(int S, bool rgb, int B, size_t *lds_bytes)
     const size_t SP = ((size_t)S + 31) & ~(size_t)31;
     if (SP / rowk::SEG > (size_t)rowk::MAX_SEGS) return 0;
     for (int W = rowk::NW; W >= 1; W >>= 1) {
-        if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::PX_MIN_WGS) continue;  // (small launches: narrower bands, see px_band_config)
+        if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::ROW_MIN_WGS) continue;  // (small launches: narrower bands until there are k6::ROW_MIN_WGS band workgroups; the waves of a workgroup then share the records of a line)
         if ((size_t)W * SP > (size_t)rowk::MAX_PX) continue;
         *lds_bytes = rgb ? rowk::lds_bytes<true>() : rowk::lds_bytes<false>();
         return W;
@@ -2455,18 +2104,12 @@ int row_band_config(int S, bool rgb, int B, size_t *lds_bytes)
 }
 
 template <bool RGB, bool ALPHA>
-int launch_px(const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb, const float *g_alpha, double *scratch,
-              const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap, int B,
-              int F, int S, int W, size_t lds, double eps, hipStream_t st, void *zero_ptr, size_t zero_bytes)
+int launch_row(const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb, const float *g_alpha, double *scratch,
+               const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap, int B,
+               int F, int S, int W, size_t lds, double eps, hipStream_t st, void *zero_ptr, size_t zero_bytes)
 {
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
-    if constexpr (k6::PX_ROWS) {
-        hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb, g_alpha,
-                           scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, B, (uint4 *)zero_ptr,
-                           zero_bytes / 16);
-        return 0;
-    }
-    hipLaunchKernelGGL((k_bpm_px<RGB, ALPHA>), dim3(xcd_grid(total_wg)), dim3(pxk::NT), lds, st, fi, rgb, alpha, g_rgb, g_alpha,
+    hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb, g_alpha,
                        scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, B, (uint4 *)zero_ptr,
                        zero_bytes / 16);
     return 0;
@@ -2482,45 +2125,21 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
     return bpm_layout(B, F, S).total;
 }
 
-// Which band kernel a default-mode call takes: the band width (lines per workgroup) of k_bpm_px and its LDS bytes, or 0 for
-// k_bpm_fast.
-// Two band kernels serve the default arithmetic mode on line records (same per-pixel terms): k_bpm_fast (a piece of a sweep
-// per lane) and the lane-parallel k_bpm_px (a sweep across the lanes, round 5).  Which one a launch takes is decided by what
-// was measured (profiles/r05_raster_sweep.md, r05_k6_kernels.md: K6 stage calls and whole steps of 64 teapot views at rasters
-// 256 ... 1024 in the three gradient modes, config 4 / 5, low-poly spheres; same process).  k_bpm_px is a kernel for large
-// launches (>= 2^18 faces in the call) whose images stay inside the line buffer (an image beyond it goes to the overflow-only
-// launch of k_bpm_fast on one-line bands: 2.5 x slower than k_bpm_fast's own handling -- so a pessimistic estimate of the
-// records, a mesh that fills the image, has to fit).  There it wins
-//   * on dense meshes (>= 8192 faces per image) at every raster (config 4: 0.73 vs 0.79 ms a step; config 5, 655 360 faces at
-//     1024^2: 397 vs 533 us);
-//   * at the reference's default raster 512 and just below (448 ... 512: -5 ... -9 % in every gradient mode; all outputs 1.00 vs
-//     1.07 ms a step), but not at 320 ... 384 (+4 ... +17 %) nor from 576 on (k_bpm_fast with its two-line bands of band_shape:
-//     +2 ... +16 %; 32 views at 1024^2 it is 8 % ahead again);
-//   * up to raster 256 (silhouettes 0.243 vs 0.257 ms a step, colour only -6 %, 128 views -10 %; the headline shape -- rgb +
-//     alpha, 64 views at 256^2 -- K6 stage 204 ... 210 vs 207 ... 219 us in six same-process pairs, fused backward 253 ... 255 vs
-//     255 ... 265, bench.py 0.335 ... 0.336 vs 0.347 ... 0.348 ms a step on the one box both were run on; k_bpm_fast's time varies
-//     more from box to box); k_bpm_fast keeps small launches (8-32 views: 0 ... 4 % faster).
-// NR_FLAG_K6_LEGACY / NR_FLAG_K6_PX force one of them (tests, measurements).  The exact mode, the scan path and rasters
-// beyond k_bpm_px's LDS band are k_bpm_fast's.
-// With k_bpm_px the band tables and the line records are binned per LINE (band width 1).
-// (eps must be positive as a float: a lane outside a sweep multiplies 0 by 1 / (|c t| + eps), and t = 0 -- the crossing
-// point on a pixel centre -- would make that 0 * Inf)
-int k6_px_band(int B, int F, int S, bool rgb, bool alpha, double eps, int flags, bool fast_fits, size_t *px_lds)
+// Which band kernel a call takes: the band width (lines per workgroup) of k_bpm_row and its LDS bytes, or 0 for k_bpm_fast.
+// The default arithmetic mode has ONE band kernel since round 6, k_bpm_row: it is ahead of k_bpm_fast on every shape measured
+// (profiles/r06_k6_kernels.md: 8 ... 128 teapot views at 256^2, 64 views at rasters 320 ... 768, 32 and 4 views at 1024^2, 256
+// views at 128^2, 1024 at 32^2, configs 4 and 5), so nothing about the call's size enters the choice -- a batch and its shards
+// take the same kernel.  k_bpm_fast keeps what k_bpm_row does not do: the exact mode (NR_FLAG_EXACT_GRADIENT), the in-kernel
+// face scan (NR_FLAG_K6_SCAN, and the images of a call whose records exceed the line buffer: an overflow-only launch behind
+// k_bpm_row), rasters beyond k_bpm_row's LDS band (> 1024), eps = 0 (a lane outside a sweep multiplies 0 by 1 / (|c t| + eps),
+// and t = 0 -- the crossing point on a pixel centre -- would make that 0 * Inf), and NR_FLAG_K6_LEGACY (tests, measurements).
+// With k_bpm_row the band tables and the line records are binned per LINE (band width 1).
+int k6_row_band(int B, int S, bool rgb, double eps, int flags, bool fast_fits, size_t *row_lds)
 {
     const bool exact = (flags & NR_FLAG_EXACT_GRADIENT) != 0;
-    const bool px_possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY | NR_FLAG_K6_GLOBAL)) && B <= 65535 && S <= 3072 &&
-                             fast_fits && (float)eps >= 1e-30f;
-    const size_t call_faces = (size_t)B * F;
-    const bool px_fits = 2.1 * sqrt((double)F) * (double)S <= (double)line_capacity(F, S);  // (~6 sqrt(coverage x visible faces) S records)
-    const bool px_raster = S <= pxk::GROUP || (S >= 448 && S <= 2 * pxk::GROUP);
-    const bool px_wanted =
-        (flags & NR_FLAG_K6_PX) ||
-        (px_fits && call_faces >= k6::PX_MIN_FACES &&
-         (F >= k6::PX_DENSE_FACES || px_raster));
-    (void)rgb;
-    (void)alpha;
-    if (!(px_possible && px_wanted)) return 0;
-    return k6::PX_ROWS ? row_band_config(S, rgb, B, px_lds) : px_band_config(S, rgb, B, px_lds);
+    const bool possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY | NR_FLAG_K6_GLOBAL)) && B <= 65535 && fast_fits &&
+                          (float)eps >= 1e-30f;
+    return possible ? row_band_config(S, rgb, B, row_lds) : 0;
 }
 
 // Measurement hook (include/nr_hip_profile.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.  Only in the
@@ -2531,7 +2150,7 @@ int k6_px_band(int B, int F, int S, bool rgb, bool alpha, double eps, int flags,
 namespace {
 struct BandKernelTimer {
     bool on = false, recorded = false;
-    int which = -1;  // the bracketed launch: 0 k_bpm_fast, 1 k_bpm_px
+    int which = -1;  // the bracketed launch: 0 k_bpm_fast, 1 k_bpm_row
     hipEvent_t start = nullptr, stop = nullptr;
 } g_band_timer;
 }  // namespace
@@ -2568,9 +2187,11 @@ NR_API int nr_profile_k6_choice(int32_t B, int32_t F, int32_t S, int32_t return_
     int win = 0, qcap = 0;
     const BandShape shape = band_shape(S);
     const bool fast_fits = fast_band_config(S, return_rgb != 0, shape, shape.w_max, &fl, &win, &qcap) != 0;
-    return k6_px_band(B, F, S, return_rgb != 0, return_alpha != 0, eps, flags, fast_fits, &lds) > 0 ? 1 : 0;
+    (void)F;
+    (void)return_alpha;
+    return k6_row_band(B, S, return_rgb != 0, eps, flags, fast_fits, &lds) > 0 ? 1 : 0;
 }
-#define NR_BAND_TIMER_START(st) if (g_band_timer.on) { g_band_timer.which = use_px ? 1 : 0; g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess; }
+#define NR_BAND_TIMER_START(st) if (g_band_timer.on) { g_band_timer.which = use_row ? 1 : 0; g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess; }
 #define NR_BAND_TIMER_STOP(st) if (g_band_timer.on && g_band_timer.recorded) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess
 #else
 #define NR_BAND_TIMER_START(st) ((void)0)
@@ -2608,10 +2229,10 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     int w_max = shape.w_max;
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
     const int W_fast = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
-    size_t px_lds = 0;
-    const int W_px = k6_px_band(B, F, S, rgb, alpha, eps, flags, W_fast != 0, &px_lds);  // (the rule and its measurements: there)
-    const bool use_px = W_px > 0;
-    const int W = use_px ? 1 : W_fast;  // the band width of the tables
+    size_t row_lds = 0;
+    const int W_row = k6_row_band(B, S, rgb, eps, flags, W_fast != 0, &row_lds);  // (which launches take k_bpm_row: there)
+    const bool use_row = W_row > 0;
+    const int W = use_row ? 1 : W_fast;  // the band width of the tables
     if (W_fast == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
         const dim3 grid((unsigned)n), block(WAVE);
         if (rgb && alpha)
@@ -2700,18 +2321,18 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         // (a fill that rides in the band kernel: 16-byte words, and a slice per workgroup that is small next to the
         // workgroup's own work -- k6::FOLD_KB per band workgroup: 4 KB at the headline size, 61 KB on config 4; config 5's
         // 4 GB would be 2 MB for each of 2048 workgroups and go at 7 TB/s through a fill launch instead)
-        const int W_band = use_px ? W_px : W_fast;  // lines per band workgroup of the kernel that carries the fill
+        const int W_band = use_row ? W_row : W_fast;  // lines per band workgroup of the kernel that carries the fill
         const size_t band_wgs = (size_t)((S + W_band - 1) / W_band) * 2 * (size_t)B;
         // (per workgroup: a 256-thread workgroup takes half of what a 512-thread one does)
         const bool zero_ok = !hook && zero_ptr && zero_bytes > 0 && zero_bytes % 16 == 0 && ((size_t)zero_ptr & 15) == 0 &&
-                             zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10) * (size_t)(use_px ? pxk::NT : shape.threads) / 512;
+                             zero_bytes <= band_wgs * ((size_t)k6::FOLD_KB << 10) * (size_t)(use_row ? rowk::NT : shape.threads) / 512;
         const int mode = !exact ? K6_FAST : ((S & (S - 1)) == 0 ? K6_EXACT_POW2 : K6_EXACT);
         auto launch = [&](auto r, auto a, auto m, auto nt) {
             constexpr bool R = decltype(r)::value, A = decltype(a)::value;
             constexpr int M = decltype(m)::value, NTH = decltype(nt)::value;
             if constexpr (M == K6_FAST) {
-                // (behind k_bpm_px: only the images whose records exceed the line buffer, by the scan path, no fill)
-                if (use_px)
+                // (behind k_bpm_row: only the images whose records exceed the line buffer, by the scan path, no fill)
+                if (use_row)
                     return launch_fast<R, A, M, NTH, true>(
                         faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
                         band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W_fast, lds, eps, k2s, win_lines, qcap, st, nullptr, 0);
@@ -2734,17 +2355,17 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         };
         NR_BAND_TIMER_START(st);
         rc = 0;
-        if (use_px) {
+        if (use_row) {
             auto lp = [&](auto r, auto a) {
-                return launch_px<decltype(r)::value, decltype(a)::value>(
+                return launch_row<decltype(r)::value, decltype(a)::value>(
                     face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, scratch, band_lines, band_start, lines_ok,
-                    line_buf, L.cap, B, F, S, W_px, px_lds, eps, st, zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
+                    line_buf, L.cap, B, F, S, W_row, row_lds, eps, st, zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
             };
             rc = (rgb && alpha) ? lp(T(), T()) : (rgb ? lp(T(), N()) : lp(N(), T()));
             NR_BAND_TIMER_STOP(st);
         }
         if (rc == 0) rc = (rgb && alpha) ? by_mode(T(), T()) : (rgb ? by_mode(T(), N()) : by_mode(N(), T()));
-        if (!use_px) NR_BAND_TIMER_STOP(st);
+        if (!use_row) NR_BAND_TIMER_STOP(st);
         if (rc == 0 && zero_ok && zeroed) *zeroed = 1;
     }
     if (rc) return rc;

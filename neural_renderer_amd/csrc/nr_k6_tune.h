@@ -42,43 +42,18 @@
 #define NR_K6_LDS_BUDGET (53 * 1024)
 #endif
 
-#ifndef NR_PX_NT            // k_bpm_px: threads per workgroup (one band line per wave; 10 KB of LDS per wave)
-#define NR_PX_NT 256
-#endif
-#ifndef NR_PX_PDOT          // k_bpm_px: a visit's diff as (sum I g) - sum ref g, the first sum held per pixel (0: sum (I - ref) g)
-#define NR_PX_PDOT 1
-#endif
-#ifndef NR_PX_RED_LEVELS    // k_bpm_px: DPP levels (float) of a record's two sums before the LDS atomics in double take over (4: rows of 16 lanes, 3: of 8 -- same time, errors 5 % lower; 2: +12 %)
-#define NR_PX_RED_LEVELS 3
-#endif
 #ifndef NR_K6_WIDE_BUDGET_FROM  // rasters in (FROM, TO]: the 512-thread shape with 80 KB of LDS per workgroup (band_shape)
 #define NR_K6_WIDE_BUDGET_FROM 576
 #endif
 #ifndef NR_K6_WIDE_BUDGET_TO
 #define NR_K6_WIDE_BUDGET_TO 832
 #endif
-#ifndef NR_K6_OVF_GRID      // workgroups of k_bpm_fast's overflow-only launch behind k_bpm_px (images whose records exceed the line buffer)
+#ifndef NR_K6_OVF_GRID      // workgroups of k_bpm_fast's overflow-only launch behind k_bpm_row (images whose records exceed the line buffer)
 #define NR_K6_OVF_GRID 1024
 #endif
-#ifndef NR_PX_MIN_WGS       // k_bpm_px: bands are narrowed (4 -> 2 -> 1 lines) while the launch has fewer band workgroups than this
-#define NR_PX_MIN_WGS 8192
+#ifndef NR_ROW_MIN_WGS      // k_bpm_row: bands are narrowed (4 -> 2 -> 1 lines) while the launch has fewer band workgroups than this
+#define NR_ROW_MIN_WGS 8192
 #endif
-
-#ifndef NR_PX_ROWS          // the lane-parallel band kernel: 1 k_bpm_row (a record per row of 16 lanes, round 6), 0 k_bpm_px (round 5)
-#define NR_PX_ROWS 1
-#endif
-
-#ifndef NR_ROW_CHAIN        // k_bpm_row: steps (an even number) of a chain: a lane adds the terms of its even and of its odd steps in float, the chains' sums go on in double
-#define NR_ROW_CHAIN 16
-#endif
-
-#ifndef NR_PX_MIN_FACES     // k_bpm_px is considered from this many faces in the call (batch x faces) on; with both gradients up to
-#define NR_PX_MIN_FACES 262144  // raster 256 from twice as many (run_backward_pixel_map: the rule and what it was measured on)
-#endif
-#ifndef NR_PX_DENSE_FACES   // ... or from this many faces per image on
-#define NR_PX_DENSE_FACES 8192
-#endif
-
 #ifndef NR_SHARED_LAUNCH_MAX_FACES  // fused backward: calls of up to this many faces (batch x faces) put the line setup and the
 #define NR_SHARED_LAUNCH_MAX_FACES 98304  // K7 / K8 gather into one launch (nr_backward_rasterize_lit; measured: LAB-NOTEBOOK, late round 4)
 #endif
@@ -98,14 +73,7 @@ constexpr int MINWAVES_256 = NR_K6_MINWAVES_256;
 constexpr int WMAX = NR_K6_WMAX;
 constexpr int FOLD_KB = NR_K6_FOLD_KB;
 constexpr unsigned long LDS_BUDGET = NR_K6_LDS_BUDGET;
-constexpr unsigned long PX_MIN_WGS = NR_PX_MIN_WGS;
-constexpr unsigned long PX_MIN_FACES = NR_PX_MIN_FACES;
-constexpr int PX_DENSE_FACES = NR_PX_DENSE_FACES;
-constexpr bool PX_PDOT = NR_PX_PDOT != 0;
-constexpr bool PX_ROWS = NR_PX_ROWS != 0;
-constexpr int ROW_CHAIN = NR_ROW_CHAIN;
-static_assert(ROW_CHAIN >= 2 && ROW_CHAIN % 2 == 0, "a row walks two steps per iteration");
-constexpr int PX_RED_LEVELS = NR_PX_RED_LEVELS;
+constexpr unsigned long ROW_MIN_WGS = NR_ROW_MIN_WGS;
 constexpr unsigned OVF_GRID = NR_K6_OVF_GRID;
 constexpr int WIDE_BUDGET_FROM = NR_K6_WIDE_BUDGET_FROM, WIDE_BUDGET_TO = NR_K6_WIDE_BUDGET_TO;
 constexpr unsigned long SHARED_LAUNCH_MAX_FACES = NR_SHARED_LAUNCH_MAX_FACES;

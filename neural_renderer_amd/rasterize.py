@@ -48,7 +48,6 @@ EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
 _BACKWARD_ORDER_FLAG = _lib.NR_FLAG_SERIAL_BACKWARD if int(os.environ.get('NR_SERIAL_BACKWARD', '0')) else 0
 # (measuring aid, read once: NR_K6_LEGACY=1 keeps K6's default mode on the piece-per-lane band kernel -- NR_FLAG_K6_LEGACY)
 _BACKWARD_ORDER_FLAG |= _lib.NR_FLAG_K6_LEGACY if int(os.environ.get('NR_K6_LEGACY', '0')) else 0
-_BACKWARD_ORDER_FLAG |= _lib.NR_FLAG_K6_PX if int(os.environ.get('NR_K6_PX', '0')) else 0  # (... NR_K6_PX=1: always k_bpm_px)
 
 
 _RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)

@@ -24,7 +24,7 @@ import sys
 CALL_ORDER = ['forward_face_index_map', 'forward_texture_sampling', 'backward_pixel_map', 'backward_textures',
               'backward_depth_map', 'fused_forward_rasterize', 'fused_backward_rasterize']
 K6 = ['k_mark_visible', 'k_compact_par', 'k_count_visible', 'k_compact_visible', 'k_band_scan', 'k_band_total',
-      'k_line_setup', 'k_bpm_px', 'k_bpm_fast', 'k_bpm_band', 'k_bpm_global', 'k_bpm_finalize']
+      'k_line_setup', 'k_bpm_row', 'k_bpm_fast', 'k_bpm_band', 'k_bpm_global', 'k_bpm_finalize']
 # kernel-name pattern -> the stage calls that launch it (in CALL_ORDER order); patterns are tried in this order
 KERNEL_STAGES = [
     ('k_face_raster', ['forward_face_index_map', 'fused_forward_rasterize']),

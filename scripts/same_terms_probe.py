@@ -11,7 +11,7 @@ textures = rng.uniform(0, 1, (16, faces.shape[1], 2, 2, 2, 3)).astype(np.float32
 fw = abi.forward(faces, textures, 256, 0.1, 100.0, 1e-3, (0.2, 0.4, 0.6), 0, True, True, True)
 rng = np.random.default_rng(23)
 g_rgb = rng.normal(size=(16, 256, 256, 3)).astype(np.float32); g_alpha = rng.normal(size=(16, 256, 256)).astype(np.float32); g_depth = rng.normal(size=(16, 256, 256)).astype(np.float32)
-for flags in (0, 65536, 2):  # the kernel the library picks (k_bpm_fast at this size), k_bpm_px by name (NR_FLAG_K6_PX), the exact mode
+for flags in (0, 128, 2):  # the default mode (k_bpm_row), k_bpm_fast (NR_FLAG_K6_LEGACY), the exact mode
     base = abi.host(abi.backward(fw, g_rgb, g_alpha, g_depth, k6_flags=flags)[0])
     worst = {}
     for it in range(40):

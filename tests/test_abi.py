@@ -20,6 +20,7 @@ def declared_functions():
 
 @pytest.fixture(scope='module')
 def lib_path():
+    _build.build_profile()  # (the measurement build, with the same staleness check: tests below read the kernel choice through it)
     return _build.build()
 
 
@@ -71,7 +72,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_host_only_entry_points(lib_path):
     lib = _lib.load()
-    assert lib.nr_version() == 500 == _lib.NR_VERSION
+    assert lib.nr_version() == 600 == _lib.NR_VERSION
     import neural_renderer_amd
     v = _lib.NR_VERSION
     assert neural_renderer_amd.__version__ == '%d.%d.%d' % (v // 1000, v // 100 % 10, v % 100)
@@ -86,30 +87,26 @@ def test_host_only_entry_points(lib_path):
 
 
 def test_k6_band_kernel_choice_table(lib_path):
-    """Which of K6's two band kernels a default-mode call takes (run_backward_pixel_map's rule, read through the measurement build:
-    host logic, no device).  The rows are the shapes the rule was measured on (profiles/r05_k6_kernels.md, r05_raster_sweep.md): a
-    change of the rule that moves one of them has to come with a measurement."""
+    """Which band kernel a K6 call takes (k6_row_band, read through the measurement build: host logic, no device).  The default mode
+    has one band kernel since 0.6.0 -- k_bpm_row, ahead of k_bpm_fast on every shape of profiles/r06_k6_kernels.md --, so the call's
+    batch size must not enter: a batch and its shards take the same kernel (tests/test_full_size_gpu.py checks the results)."""
     choice = _lib.load_profile().nr_profile_k6_choice
-    PX, FAST, T = 1, 0, 4928  # (teapot with fill_back)
+    ROW, FAST, T = 1, 0, 4928  # (teapot with fill_back)
     table = [
         # B, F, S, rgb, alpha, eps, flags -> kernel
-        ((64, T, 256, 1, 1, 1e-3, 0), PX),          # the headline shape
-        ((64, T, 256, 0, 1, 1e-3, 0), PX),          # silhouettes
-        ((64, T, 256, 1, 0, 1e-3, 0), PX),          # colour only
-        ((128, T, 256, 1, 1, 1e-3, 0), PX),         # very large batches
-        ((32, T, 256, 1, 1, 1e-3, 0), FAST), ((16, T, 256, 1, 0, 1e-3, 0), FAST), ((8, T, 256, 0, 1, 1e-3, 0), FAST),  # shards
-        ((64, T, 512, 1, 1, 1e-3, 0), PX), ((64, T, 512, 0, 1, 1e-3, 0), PX), ((64, T, 448, 0, 1, 1e-3, 0), PX),    # the reference's default raster
-        ((64, T, 512, 1, 0, 1e-3, 0), PX),
-        ((64, T, 384, 1, 1, 1e-3, 0), FAST), ((64, T, 320, 0, 1, 1e-3, 0), FAST), ((64, T, 384, 1, 0, 1e-3, 0), FAST),
-        ((64, T, 576, 1, 1, 1e-3, 0), FAST), ((64, T, 640, 1, 0, 1e-3, 0), FAST), ((64, T, 768, 0, 1, 1e-3, 0), FAST),
-        ((64, T, 1024, 1, 0, 1e-3, 0), FAST),
-        ((64, 10240, 256, 1, 0, 1e-3, 0), PX),      # config 4
-        ((1, 655360, 1024, 1, 1, 1e-3, 0), PX),     # config 5 (dense: 397 vs 533 us)
-        ((4, T, 1024, 1, 1, 1e-3, 0), FAST), ((1, T, 2048, 1, 1, 1e-3, 0), FAST),
-        ((64, T, 256, 0, 1, 0.0, 0), FAST),         # eps = 0: k_bpm_px needs a positive eps
-        ((64, T, 512, 1, 1, 1e-3, 2), FAST),        # NR_FLAG_EXACT_GRADIENT
-        ((64, T, 512, 1, 1, 1e-3, 128), FAST), ((2, 40, 64, 1, 1, 1e-3, 65536), PX),  # forced by name
-        ((64, T, 512, 1, 1, 1e-3, 65536 | 2), FAST),
+        ((64, T, 256, 1, 1, 1e-3, 0), ROW), ((64, T, 256, 0, 1, 1e-3, 0), ROW), ((64, T, 256, 1, 0, 1e-3, 0), ROW),
+        ((128, T, 256, 1, 1, 1e-3, 0), ROW), ((32, T, 256, 1, 1, 1e-3, 0), ROW), ((16, T, 256, 1, 0, 1e-3, 0), ROW),
+        ((8, T, 256, 0, 1, 1e-3, 0), ROW), ((1, T, 256, 1, 1, 1e-3, 0), ROW),           # shards: the same kernel as the batch
+        ((64, T, 512, 1, 1, 1e-3, 0), ROW), ((64, T, 384, 1, 1, 1e-3, 0), ROW), ((64, T, 640, 1, 0, 1e-3, 0), ROW),
+        ((64, T, 1024, 1, 0, 1e-3, 0), ROW), ((4, T, 1024, 1, 1, 1e-3, 0), ROW), ((3, 40, 33, 1, 1, 1e-3, 0), ROW),
+        ((64, 10240, 256, 1, 0, 1e-3, 0), ROW),      # config 4
+        ((1, 655360, 1024, 1, 1, 1e-3, 0), ROW),     # config 5
+        ((1, T, 1056, 1, 1, 1e-3, 0), FAST), ((1, T, 2048, 1, 1, 1e-3, 0), FAST),   # beyond k_bpm_row's LDS band
+        ((64, T, 256, 0, 1, 0.0, 0), FAST),          # eps = 0: k_bpm_row needs a positive eps
+        ((64, T, 512, 1, 1, 1e-3, 2), FAST),         # NR_FLAG_EXACT_GRADIENT
+        ((64, T, 512, 1, 1, 1e-3, 8), FAST),         # NR_FLAG_K6_SCAN
+        ((64, T, 512, 1, 1, 1e-3, 128), FAST),       # NR_FLAG_K6_LEGACY
+        ((2, 40, 64, 1, 1, 1e-3, 65536), ROW), ((64, T, 512, 1, 1, 1e-3, 65536 | 2), FAST),  # NR_FLAG_K6_PX: ignored
     ]
     wrong = [(args, want, choice(*args)) for args, want in table if choice(*args) != want]
     assert not wrong, wrong

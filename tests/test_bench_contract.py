@@ -45,7 +45,7 @@ def test_bench_json_line():
     # `traffic`: the dominant kernel's own HBM bytes from the committed counter passes -- of the profiled shape (64 views at
     # 256 x 256) only, hence null in this 4-view run; the fields and their scope are on the line all the same
     assert r['traffic'] is None and r['traffic_ratio'] is None and 'traffic_scope' in r and 'traffic' in r['stage_call']
-    assert r['kernel'] == 'k_bpm_fast'
+    assert r['kernel'] == 'k_bpm_row'  # (one band kernel in the default mode, whatever the batch size)
     assert d['cold']['ms_per_step'] > 0 and d['exact']['ms_per_step'] > 0 and d['exact']['value'] > 0
     assert len(d['extra_rows']) == 5 and all(x['ms_per_step'] > 0 for x in d['extra_rows'])
     assert any('forward_gpu' in x['row'] for x in d['extra_rows'])

@@ -28,8 +28,8 @@ EXACT = 2  # _lib.NR_FLAG_EXACT_GRADIENT
 K6_GLOBAL = 4  # _lib.NR_FLAG_K6_GLOBAL
 K6_SCAN = 8    # _lib.NR_FLAG_K6_SCAN
 SERIAL = 64    # _lib.NR_FLAG_SERIAL_BACKWARD
-K6_LEGACY = 128  # _lib.NR_FLAG_K6_LEGACY: the default mode always on the piece-per-lane band kernel (k_bpm_fast)
-K6_PX = 65536      # _lib.NR_FLAG_K6_PX: ... always on the lane-parallel one (k_bpm_px); without either the library picks per launch
+K6_LEGACY = 128  # _lib.NR_FLAG_K6_LEGACY: the default mode on the piece-per-lane band kernel (k_bpm_fast) instead of k_bpm_row
+K6_PX = 65536    # _lib.NR_FLAG_K6_PX: accepted and ignored since 0.6.0 (the default mode has one band kernel, k_bpm_row)
 
 
 def report(test, **values):
@@ -286,10 +286,10 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
             gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                   use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
             assert H.rel_err(abi.host(gf3), gf) <= SAME_TERMS
-            # ... and each of the two band kernels of the default mode by name (without a flag the library picks per launch by
-            # size and mode: small test scenes would never reach k_bpm_px): both against the oracle and against each other
+            # ... and the default mode's terms on the other band kernel (the call above ran k_bpm_row wherever its band fits;
+            # NR_FLAG_K6_LEGACY: k_bpm_fast): against the oracle and against k_bpm_row's
             if not (flags & (EXACT | K6_GLOBAL | K6_SCAN | K6_LEGACY | K6_PX)):
-                for kflag, kname in ((K6_LEGACY, 'k_bpm_fast'), (K6_PX, 'k_bpm_px')):
+                for kflag, kname in ((K6_LEGACY, 'k_bpm_fast'),):
                     gf4, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                           use_face_inv_map=residual_maps, k6_flags=flags | kflag)
                     gf4 = abi.host(gf4)
@@ -299,8 +299,9 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
                            vs_default=H.rel_err(gf4, gf))
                     assert err_k <= bound, 'grad_faces (%s) vs double-summed oracle: %g' % (kname, err_k)
                     # (two kernels, two ways to round a term -- k_bpm_fast steps t = d1 - d1_cross by additions of 1 along a
-                    # piece, k_bpm_px subtracts per pixel like the reference: not the same terms in another order, so not
-                    # SAME_TERMS; measured <= 3.5e-5, each kernel being within `bound` of the oracle)
+                    # piece and forms sum (I - ref) g, k_bpm_row subtracts per pixel like the reference and forms the colour
+                    # difference from centred sums: not the same terms in another order, so not SAME_TERMS; each kernel is
+                    # within `bound` of the oracle)
                     assert H.rel_err(gf4, gf) <= K6_BOUND_DEFAULT
     if rgb:
         gt = abi.host(gt)
@@ -324,11 +325,11 @@ def test_teapot_views_backward(modes):
 
 @pytest.mark.parametrize('S,modes', [(300, (True, True, False)), (512, (True, True, False)), (512, (False, True, False)),
                                      (1024, (True, False, False))], ids=['S300', 'S512', 'S512_alpha', 'S1024_rgb'])
-def test_k6_lane_parallel_kernel_on_rasters_beyond_one_group(S, modes):
-    """k_bpm_px holds 256 pixels of a band line per wave (four chunks of 64): larger rasters split a line into groups of 256 --
-    two lines per workgroup with two groups each at 512 (the reference's default raster: anti-aliasing), one line with four
-    groups at 1024, a last group of 44 pixels at 300.  check_backward runs both band kernels by name against the oracle and
-    against each other (NR_FLAG_K6_PX / NR_FLAG_K6_LEGACY)."""
+def test_k6_row_kernel_band_shapes(S, modes):
+    """k_bpm_row keeps up to 1024 pixels of a band in LDS, a line per wave: four lines per workgroup up to raster 256, two at 512
+    (the reference's default raster: anti-aliasing; small launches narrow the bands further and deal a line's windows to
+    several waves), one line of 64 segments at 1024; 300 is no multiple of 16: a line ends in 20 padding pixels.  check_backward
+    runs k_bpm_row (the default) and k_bpm_fast (NR_FLAG_K6_LEGACY) against the oracle and against each other."""
     faces, _ = H.teapot_views(2, S)
     rng = np.random.default_rng(300 + S)
     textures = rng.uniform(0, 1, (2, faces.shape[1], 2, 2, 2, 3)).astype(np.float32)
@@ -377,10 +378,10 @@ def test_big_triangles_long_sweeps():
 
 
 def test_line_buffer_overflow_in_some_images_of_a_batch():
-    """Images whose line records exceed the buffer (8 F + 32 S + S sqrt(F) per image) beside images that fit: 120 faces that
-    span most of a 128 x 128 image have tens of thousands of records against a capacity of ~6 400, the image between them a
-    handful.  k_bpm_fast walks such an image by its in-kernel face scan inside the normal grid; behind k_bpm_px the overflow-only
-    launch of k_bpm_fast takes it (check_backward runs both kernels by name, and the exact mode)."""
+    """Images whose line records exceed the buffer (8 F + 32 S + 1.2 S sqrt(F) per image) beside images that fit: 120 faces that
+    span most of a 128 x 128 image have tens of thousands of records against a capacity of ~6 700, the image between them a
+    handful.  k_bpm_fast walks such an image by its in-kernel face scan inside the normal grid; behind k_bpm_row the overflow-only
+    launch of k_bpm_fast takes it (check_backward runs both kernels, and the exact mode)."""
     rng = np.random.default_rng(321)
     big = H.random_scene(rng, 3, 120, spread=0.4, size=1.2)
     small = H.random_scene(rng, 3, 120, spread=0.5, size=0.05)
@@ -389,7 +390,7 @@ def test_line_buffer_overflow_in_some_images_of_a_batch():
     S, F = 128, 120
     # the records of an image: one per visible face, edge, axis and integer line inside the edge's extent (rasterize.py:567-569)
     fn = oracle_forward(faces, textures, S, 0.1, 100, 1e-3, (0.2, 0.4, 0.6), True, True, False)
-    capacity = 8 * F + 32 * S + int(S * np.sqrt(F))
+    capacity = 8 * F + 32 * S + int(1.2 * S * np.sqrt(F))
     records = []
     for b in range(3):
         vis = np.unique(fn.face_index_map[b][fn.face_index_map[b] >= 0])
@@ -613,6 +614,32 @@ def test_unsafe_rasterizer_against_the_k3_oracle(S):
     assert d_err <= 2.7e-6
     assert w_err <= 1.1e-4
     assert float(np.abs(fim - k3.face_inv_map).max()) <= 1e-5 * float(np.abs(k3.face_inv_map).max())
+    # What a user of the switch observes beyond the maps: colours and texture gradients.  K3's weights (x-sorted vertices,
+    # rasterize.py:210-214) feed K4's texture coordinates (:399-404): tif = w (ts - 1) depth / z, so a weight difference of 1e-4
+    # moves a texture coordinate by (ts - 1) 1e-4 and a trilinear sample of textures in [0, 1] by at most 3 x that.
+    ts = 4
+    rng = np.random.default_rng(1300 + S)
+    textures = rng.uniform(0, 1, (1, faces.shape[1], ts, ts, ts, 3)).astype(np.float32)
+    g_rgb = rng.normal(size=(1, S, S, 3)).astype(np.float32)
+    k3c = O.Rasterize(S, 0.1, 100, 1e-3, (0.1, 0.2, 0.3), True, False, False)
+    k3c.unsafe = True
+    ref_rgb = k3c(faces, textures)[0]
+    ref_gt = k3c.backward(g_rgb, None, None, accumulate_double=True)[1]
+    try:
+        nr.use_unsafe_rasterizer(True)
+        fn = nr.Rasterize(S, 0.1, 100, 1e-3, (0.1, 0.2, 0.3), True, False, False)
+        tt = torch.tensor(textures, device='cuda', requires_grad=True)
+        rgb = fn(torch.tensor(faces, device='cuda'), tt)[0]
+        rgb.backward(torch.tensor(g_rgb, device='cuda'))
+    finally:
+        nr.use_unsafe_rasterizer(False)
+    c_err = float(np.abs(rgb.detach().cpu().numpy() - ref_rgb).max())
+    gt_err = H.rel_err(tt.grad.cpu().numpy(), ref_gt)
+    report('unsafe_vs_k3_oracle_colours', S=S, ts=ts, rgb_abs=c_err, grad_textures_rel=gt_err)
+    assert c_err <= 3 * (ts - 1) * 1.1e-4
+    # (grad_textures[texel] = sum over the face's pixels of corner weight x g: every corner weight moves by <= 3 (ts - 1) 1.1e-4 =
+    # 1e-3 -- against corner weights of ~0.1 and gradients of random sign that is ~1e-2 of a texel's gradient; measured 0.6 ... 1.3e-2)
+    assert gt_err <= 2e-2
 
 
 def test_unsafe_rasterizer_flag_is_equivalent(monkeypatch):
@@ -1243,10 +1270,10 @@ def test_band_kernel_timing_hook():
         abi.backward(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
         t_staged = lib.nr_profile_band_kernel_ms()
         assert lib.nr_profile_band_kernel_which() == 0  # (the exact mode: k_bpm_fast)
-        abi.backward(fw, g_rgb, g_alpha, None, k6_flags=K6_PX)  # (k_bpm_px is bracketed as well, and named)
+        abi.backward(fw, g_rgb, g_alpha, None)  # (the default mode: k_bpm_row is bracketed as well, and named)
         t_px = lib.nr_profile_band_kernel_ms()
         assert lib.nr_profile_band_kernel_which() == 1
-        abi.backward(fw, g_rgb, g_alpha, None)  # (a launch this small: the library picks k_bpm_fast)
+        abi.backward(fw, g_rgb, g_alpha, None, k6_flags=K6_LEGACY)
         assert lib.nr_profile_band_kernel_ms() > 0 and lib.nr_profile_band_kernel_which() == 0
     finally:
         lib.nr_profile_band_kernel(0)
