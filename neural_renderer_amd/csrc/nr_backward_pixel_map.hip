@@ -1415,6 +1415,9 @@ __device__ __forceinline__ void wave_lds_handover()
 // Flush: one lane per record adds in sweep + out sweep to the double scratch (global_atomic_add_f64), as k_bpm_fast does.
 // Images whose records exceed the line buffer (lines_ok == 0) are left to k_bpm_fast's scan path (launched behind this kernel
 // with overflow_only set).  The exact mode (NR_FLAG_EXACT_GRADIENT) stays with k_bpm_fast.
+#ifndef NR_ROW_OFF  // (development, switch-off builds -- results wrong by construction: 1 no out sweeps, 2 no in sweeps, 4 no global atomics at the flush)
+#define NR_ROW_OFF 0
+#endif
 #ifndef NR_ROW_LDS_PAD  // (development: unused LDS per workgroup, to probe what a workgroup less per CU costs)
 #define NR_ROW_LDS_PAD 0
 #endif
@@ -1670,7 +1673,7 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
             const int nseg = has_b ? (dpos ? nsl - ((o_from + 1) >> 4) : ((o_to - 1) >> 4) + 1) : 0;
             hist[lane] = 0;
             double in0 = 0.0, in1 = 0.0;
-            if (has_in) {
+            if (has_in && !(NR_ROW_OFF & 2)) {
                 const float cross = qq.x, c0k = qq.y, c1k = qq.z;
                 const int fnr = __float_as_int(qq.w);
                 const float d_first = direct_diff(c_in, c_out, base + d1_in);
@@ -1752,7 +1755,7 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
             const float v_ac0 = __uint_as_float((__float_as_uint(qq.y) & 0x7fffffffu) | (dpos ? 0u : 0x80000000u));
             const float v_ac1 = fabsf(qq.z);
             int src_next = __builtin_amdgcn_ds_bpermute(row << 2, inv);
-            for (int g0 = 0; g0 < n_out; g0 += 4) {
+            for (int g0 = 0; g0 < ((NR_ROW_OFF & 1) ? 0 : n_out); g0 += 4) {
                 const bool act = g0 + row < n_out;
                 const int src = src_next;  // (of a block without a record: some lane; nothing of it is used)
                 src_next = __builtin_amdgcn_ds_bpermute(((g0 + 4 + row) & 63) << 2, inv);
@@ -1877,8 +1880,12 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                 const double t1 = (flags & 4) ? in1 + (neg1 ? a.y : -a.y) : 0.0;
                 const int tgt = hh.w, lpos = tgt & 0x0fffffff;
                 double *dst = scratch + ((size_t)b * F + lpos) * 6 + (1 - axis);
-                if (t0 != 0.0) atomicAdd(dst + 2 * ((tgt >> 28) & 3), t0);
-                if (t1 != 0.0) atomicAdd(dst + 2 * ((tgt >> 30) & 3), t1);
+                if (NR_ROW_OFF & 4) {
+                    asm volatile("" : : "v"(t0), "v"(t1), "v"(dst));
+                } else {
+                    if (t0 != 0.0) atomicAdd(dst + 2 * ((tgt >> 28) & 3), t0);
+                    if (t1 != 0.0) atomicAdd(dst + 2 * ((tgt >> 30) & 3), t1);
+                }
             }
             wave_lds_handover();
         }

@@ -38,11 +38,23 @@ namespace {
 // negative ones), so any `near` -- the reference accepts any, :331 -- orders correctly, faces behind the camera
 // (negative zp with near < 0) included.  The result does not depend on the order of the atomics:
 // face_index_map is bit-reproducible.
-constexpr size_t SMALL_LAUNCH_FACES = (size_t)16384 * 32;  // launches of fewer faces take 16 faces per raster wave (k_face_raster)
+#ifndef NR_FWD_SMALL_FACES  // (development knob)
+#define NR_FWD_SMALL_FACES (16384 * 32)
+#endif
+constexpr size_t SMALL_LAUNCH_FACES = (size_t)NR_FWD_SMALL_FACES;  // launches of fewer faces take 16 faces per raster wave (k_face_raster)
 constexpr int SMALL_AREA = 256;   // boxes up to this many pixels: rasterized by k_face_raster (measured with the round-2 form of
                                   // the kernel: 128 / 64 make config 4 15 % / 28 % slower, the headline +0 / +11 %)
 constexpr int WAVE_AREA = 4096;   // up to this: one wave per face (wave_raster); beyond, and strips: one workgroup (k_large_raster)
 constexpr unsigned long long ZEMPTY = ~0ull;
+// The two queues of k_face_raster (faces for a wave each, faces for a workgroup each) are SHARDED: a raster workgroup appends to
+// shard blockIdx & 15, every shard with its own pair of counters on its own 128 bytes.  One pair for the whole launch was the
+// limit of dense meshes: a word takes ~88 returning atomics per microsecond (MI355X_MICROARCH.md, "dequeue"), and config 4 --
+// 10 240 raster waves, nearly every one with a face to queue -- spent 66 of its 152 us there (profiles/r06_pmc_fwd_C4.txt:
+// 54 % of the wave-cycles parked; with the queues switched off: 86 us).  16 shards: ~1400 atomics per microsecond, and a
+// consumer workgroup reads 16 cache lines to learn that there is nothing to do (64 shards, every consumer WAVE reading 64
+// lines: the headline's forward 72 -> 85 us for its empty queues).
+constexpr int QSHARDS = 16;
+constexpr int QSTRIDE = 32;  // ints between the counter pairs of neighbouring shards
 
 // monotone float -> uint32 key: a < b  <=>  depth_key(a) < depth_key(b) for all non-NaN floats; -0 is keyed as +0 (the
 // reference's `zp < depth_min` does not tell them apart, so the lower face index must win between them).  A candidate
@@ -212,7 +224,7 @@ template <bool POW2, int FACES, int GROUP>
 __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ faces,
                                                      unsigned long long *__restrict__ zbuf,
                                                      int *__restrict__ large_list, int *__restrict__ wave_list,
-                                                     int *__restrict__ n_large,
+                                                     int *__restrict__ n_large, int qcap, int nshards,
                                                      unsigned char *__restrict__ visible_faces, int n_faces_total, int F,
                                                      int S, double near_d, double far_d, int epoch,
                                                      unsigned char *__restrict__ touched)
@@ -235,11 +247,22 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     {
         float *stage = &L.g[0][0];  // half of its floats; the slot constants move in after the hand-over
         const size_t n_words = (size_t)n_faces_total * 9;
+        // (all loads first, from clamped addresses, then the stores: a load under its own condition is a basic block of its own,
+        // and each then waits for its data before the next is issued -- nine dependent round trips per wave at FACES = 64:
+        // profiles/r06_pmc_fwd_C4.txt, 54 % of config 4's wave-cycles parked)
+        constexpr int NLOAD = (9 * FACES + 63) / 64;
+        float word[NLOAD];
 #pragma unroll
-        for (int k = 0; k < (9 * FACES + 63) / 64; k++) {
+        for (int k = 0; k < NLOAD; k++) {
             const int d = k * 64 + lane, run = d / (9 * GROUP), off = d - run * (9 * GROUP);
             const size_t src = ((size_t)run * n_waves + (t >> 6)) * (9 * GROUP) + off;
-            if (d < 9 * FACES) stage[d] = src < n_words ? faces[src] : 0.0f;
+            const float v = faces[src < n_words ? src : n_words - 1];
+            word[k] = src < n_words ? v : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NLOAD; k++) {
+            const int d = k * 64 + lane;
+            if (d < 9 * FACES) stage[d] = word[k];
         }
         wave_lds_sync();
 #pragma unroll
@@ -250,25 +273,32 @@ __global__ __launch_bounds__(256) void k_face_raster(const float *__restrict__ f
     if (!live) cd.n = 0;
     // Boxes too large for this kernel are queued: medium ones for a wave each, strips (needles) and large ones for a whole
     // workgroup each (k_large_raster).  One atomic per wave and queue (a same-address atomic per face from all over the chip
-    // serialises at the memory side); both counters start at -1 (one fill with the z-buffer).
+    // serialises at the memory side), on the counters of the workgroup's shard (QSHARDS); all counters start at -1 (one fill
+    // with the z-buffer).  A shard holds qcap entries: what its workgroups can queue at most.
     const bool queued = cd.n > 0 && (cd.strip || cd.n > SMALL_AREA);
     const bool to_wave = queued && !cd.strip && cd.n <= WAVE_AREA;
     const bool to_large = queued && !to_wave;
     {
+#ifdef NR_FWD_NOQUEUE  // (development: queued faces are dropped -- what do the queues' counters cost?)
+        const unsigned long long mw = 0, ml = 0;
+#else
         const unsigned long long mw = __ballot(to_wave), ml = __ballot(to_large);
+#endif
+        const int shard = (int)(blockIdx.x & (unsigned)(nshards - 1));  // (1 or QSHARDS)
+        int *qc = n_large + shard * QSTRIDE;
         if (mw) {
             const int leader = __ffsll((long long)mw) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(n_large + 1, __popcll(mw)) + 1;
+            if (lane == leader) base = atomicAdd(qc + 1, __popcll(mw)) + 1;
             base = __shfl(base, leader, WAVE);
-            if (to_wave) wave_list[base + __popcll(mw & ((1ull << lane) - 1ull))] = i;
+            if (to_wave) wave_list[(size_t)shard * qcap + base + __popcll(mw & ((1ull << lane) - 1ull))] = i;
         }
         if (ml) {
             const int leader = __ffsll((long long)ml) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(n_large, __popcll(ml)) + 1;
+            if (lane == leader) base = atomicAdd(qc, __popcll(ml)) + 1;
             base = __shfl(base, leader, WAVE);
-            if (to_large) large_list[base + __popcll(ml & ((1ull << lane) - 1ull))] = i;
+            if (to_large) large_list[(size_t)shard * qcap + base + __popcll(ml & ((1ull << lane) - 1ull))] = i;
         }
     }
     // 1. kept faces -> slots (lane order), their constants -> LDS
@@ -398,30 +428,41 @@ __device__ __forceinline__ void raster_candidates(const FaceGeo &g, unsigned fnu
 
 // Faces whose box is too large for k_face_raster and too small for a workgroup (a mesh of spiky or close-up triangles: config 4
 // queues 1/5 of its faces): one wave per face, lanes stride over the box.
+// Entry j of shard s is taken by consumer (j + s * units / QSHARDS) mod units -- the shards' entries start at different
+// consumers, so that short shards do not all land on the first ones -- i.e. consumer u takes the entries j = u - start (mod
+// units), j += units.
+__device__ __forceinline__ int shard_first(int u, int s, int units, int nshards)
+{
+    const int start = (s * units) / nshards;  // (< units; units <= 2^13 consumers: no overflow)
+    return u >= start ? u - start : u - start + units;
+}
+
 __device__ __forceinline__ void wave_raster(const float *__restrict__ faces, unsigned long long *__restrict__ zbuf,
-                                            const int *__restrict__ wave_list, const int *__restrict__ n_wave, int F, int S,
+                                            const int *__restrict__ wave_list, const int cnt, int qcap, int nshards, int F, int S,
                                             double near_d, double far_d, int *__restrict__ queue, int epoch,
                                             unsigned char *__restrict__ touched)
 {
-    const int n = *n_wave + 1;  // the counter starts at -1
-    const int waves = gridDim.x * (blockDim.x >> 6);
-    for (int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < n; j += waves) {
-        const int i = wave_list[j];
-        const float *f = faces + (size_t)i * 9;
-        FaceGeo g;
-        float inv[9];
-        load_face_geo(f, S, g, inv);
-        const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
-        const int b = i / F;
-        raster_candidates(
-            g, (unsigned)(i - b * F), cd.n, 0, 64,
-            [&](int k, int &x, int &y) {
-                const int yy = k / cd.bw;
-                x = cd.x_lo + (k - yy * cd.bw);
-                y = cd.y_lo + yy;
-                return true;
-            },
-            queue, S, near_d, far_d, zbuf + (size_t)b * S * S, epoch, touched, (size_t)b * S * S);
+    const int waves = gridDim.x * (blockDim.x >> 6), u = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (int s = 0; s < nshards; ++s) {
+        const int n = __builtin_amdgcn_readlane(cnt, 2 * s + 1);
+        for (int j = shard_first(u, s, waves, nshards); j < n; j += waves) {
+            const int i = wave_list[(size_t)s * qcap + j];
+            const float *f = faces + (size_t)i * 9;
+            FaceGeo g;
+            float inv[9];
+            load_face_geo(f, S, g, inv);
+            const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
+            const int b = i / F;
+            raster_candidates(
+                g, (unsigned)(i - b * F), cd.n, 0, 64,
+                [&](int k, int &x, int &y) {
+                    const int yy = k / cd.bw;
+                    x = cd.x_lo + (k - yy * cd.bw);
+                    y = cd.y_lo + yy;
+                    return true;
+                },
+                queue, S, near_d, far_d, zbuf + (size_t)b * S * S, epoch, touched, (size_t)b * S * S);
+        }
     }
 }
 
@@ -430,26 +471,35 @@ __device__ __forceinline__ void wave_raster(const float *__restrict__ faces, uns
 __global__ __launch_bounds__(256) void k_large_raster(const float *__restrict__ faces,
                                                       unsigned long long *__restrict__ zbuf,
                                                       const int *__restrict__ large_list, const int *__restrict__ wave_list,
-                                                      const int *__restrict__ n_large, int F, int S, double near_d,
-                                                      double far_d, int epoch, unsigned char *__restrict__ touched)
+                                                      const int *__restrict__ n_large, int qcap, int nshards, int F, int S,
+                                                      double near_d, double far_d, int epoch, unsigned char *__restrict__ touched)
 {
     __shared__ int s_queue[4][CQ];
+    __shared__ int s_cnt[2 * QSHARDS];  // entries of each shard's two queues (the counters start at -1)
     int *queue = s_queue[threadIdx.x >> 6];
-    const int n = *n_large + 1;  // the counter starts at -1
-    for (int j = blockIdx.x; j < n; j += gridDim.x) {
-        const int i = large_list[j];
-        const float *f = faces + (size_t)i * 9;
-        FaceGeo g;
-        float inv[9];
-        load_face_geo(f, S, g, inv);
-        const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
-        const int b = i / F;
-        raster_candidates(
-            g, (unsigned)(i - b * F), cd.n, (int)(threadIdx.x >> 6) * 64, 256,
-            [&](int k, int &x, int &y) { return cand_pixel(cd, k, S, x, y); }, queue, S, near_d, far_d,
-            zbuf + (size_t)b * S * S, epoch, touched, (size_t)b * S * S);
+    int any = 0;
+    if (threadIdx.x < 2 * QSHARDS) {
+        any = s_cnt[threadIdx.x] = (int)threadIdx.x < 2 * nshards ? n_large[(threadIdx.x >> 1) * QSTRIDE + (threadIdx.x & 1)] + 1 : 0;
     }
-    wave_raster(faces, zbuf, wave_list, n_large + 1, F, S, near_d, far_d, queue, epoch, touched);
+    if (!__syncthreads_or(any)) return;  // (a fine mesh: both queues empty)
+    const int cnt = s_cnt[threadIdx.x & (2 * QSHARDS - 1)];  // lane 2 s / 2 s + 1: the entries of shard s's two queues
+    for (int s = 0; s < nshards; ++s) {
+        const int n = __builtin_amdgcn_readlane(cnt, 2 * s);
+        for (int j = shard_first((int)blockIdx.x, s, (int)gridDim.x, nshards); j < n; j += gridDim.x) {
+            const int i = large_list[(size_t)s * qcap + j];
+            const float *f = faces + (size_t)i * 9;
+            FaceGeo g;
+            float inv[9];
+            load_face_geo(f, S, g, inv);
+            const Cand cd = face_candidates(g.x0, g.y0, g.x1, g.y1, g.x2, g.y2, S);
+            const int b = i / F;
+            raster_candidates(
+                g, (unsigned)(i - b * F), cd.n, (int)(threadIdx.x >> 6) * 64, 256,
+                [&](int k, int &x, int &y) { return cand_pixel(cd, k, S, x, y); }, queue, S, near_d, far_d,
+                zbuf + (size_t)b * S * S, epoch, touched, (size_t)b * S * S);
+        }
+    }
+    wave_raster(faces, zbuf, wave_list, cnt, qcap, nshards, F, S, near_d, far_d, queue, epoch, touched);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -612,11 +662,14 @@ __device__ __forceinline__ void resolve_pixel(const ResolveArgs &a, size_t i, bo
                     a.bg_per_batch, a.alpha_map, F, a.ts, a.eps, a.fix_batch_z, a.lit);
 }
 
-// epoch mode: nobody fills the workspace for the next call, so the two queue counters go back to -1 in the resolve pass (the
+// epoch mode: nobody fills the workspace for the next call, so the queue counters go back to -1 in the resolve pass (the
 // raster kernels that read them are done: this launch is behind them on the stream)
 __device__ __forceinline__ void reset_queue_counters(const ResolveArgs &a)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.epoch >= 0) { a.queue_counters[0] = -1; a.queue_counters[1] = -1; }
+    if (blockIdx.x == 0 && threadIdx.x < QSHARDS && a.epoch >= 0) {
+        a.queue_counters[threadIdx.x * QSTRIDE] = -1;
+        a.queue_counters[threadIdx.x * QSTRIDE + 1] = -1;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_resolve(ResolveArgs a)
@@ -697,14 +750,23 @@ namespace {
 struct FwdLayout {
     size_t zbuf_off, list_off, count_off, touch_off, total;
 };
+// entries a queue shard can receive: the faces of the raster workgroups blockIdx = shard (mod nshards), 4 x faces_per_wave each
+size_t queue_shard_capacity(size_t n_faces, int faces_per_wave, int nshards)
+{
+    const size_t per_wg = (size_t)4 * faces_per_wave, n_wg = (n_faces + per_wg - 1) / per_wg;
+    return (n_wg + nshards - 1) / nshards * per_wg;
+}
+
 FwdLayout fwd_layout(int B, int F, int S)
 {
     FwdLayout L;
     const size_t n = (size_t)B * F, P = (size_t)B * S * S;
     L.zbuf_off = 0;
-    L.count_off = L.zbuf_off + P * sizeof(unsigned long long);  // the counter sits right behind the z-buffer
-    L.list_off = align_up(L.count_off + sizeof(long long), 256);
-    L.touch_off = align_up(L.list_off + 2 * n * sizeof(int), 256);  // the queue of large faces, then the queue of medium ones
+    L.count_off = L.zbuf_off + P * sizeof(unsigned long long);  // the queue counters sit right behind the z-buffer (one fill)
+    L.list_off = align_up(L.count_off + (size_t)QSHARDS * QSTRIDE * sizeof(int), 256);
+    // the queue of large faces, then the queue of medium ones: QSHARDS shards each, a shard as long as what the raster
+    // workgroups that feed it hold (queue_shard_capacity; over all shards at most n + QSHARDS * 256 entries)
+    L.touch_off = align_up(L.list_off + 2 * (n + (size_t)QSHARDS * 256) * sizeof(int), 256);
     L.total = L.touch_off + (P + 63) / 64;  // epoch mode: one byte per 64 pixels, "drawn in this call" (k_resolve)
     return L;
 }
@@ -735,21 +797,26 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
 
     // Epoch mode (NR_FLAG_ZBUF_EPOCH, see zword): the caller keeps the workspace, filled it with 0xff bytes once and counts
     // the epoch down; nothing is filled here.  It needs face indices below 2^24; otherwise, and without the flag:
-    // one fill: ZEMPTY words and, right behind them, the two queue counters at -1
+    // one fill: ZEMPTY words and, right behind them, the queue counters at -1
     int epoch = -1;
     if ((flags & NR_FLAG_ZBUF_EPOCH) && F < (1 << 24)) {
         epoch = (flags >> 8) & 0xff;
         if (epoch > 254) return NR_E_MODE;  // 255 is the epoch of a freshly filled word
     } else {
-        if (int he = fill_bytes(zbuf, 0xff, (P + 1) * sizeof(unsigned long long), st)) return he;  // (nr_device.h: not a memset node)
+        if (int he = fill_bytes(zbuf, 0xff, P * sizeof(unsigned long long) + (size_t)QSHARDS * QSTRIDE * sizeof(int), st)) return he;  // (nr_device.h: not a memset node)
     }
-    int *wave_list = large_list + n;
+    const bool small_launch = n < SMALL_LAUNCH_FACES;
+    // (launches of the 16-faces-per-wave kernel keep one shard: fine meshes queue a few faces, and a consumer that walks 16
+    // nearly empty shards costs the headline 2.4 us)
+    const int nshards = small_launch ? 1 : QSHARDS;
+    const int qcap = (int)queue_shard_capacity(n, small_launch ? 16 : 64, nshards);
+    int *wave_list = large_list + (size_t)nshards * qcap;
     unsigned char *touched = epoch >= 0 ? ws + L.touch_off : nullptr;
     {
-        const bool pow2 = (S & (S - 1)) == 0, small = n < SMALL_LAUNCH_FACES;
+        const bool pow2 = (S & (S - 1)) == 0, small = small_launch;
 #define NR_FACE_RASTER(P, FC, G)                                                                                           \
     hipLaunchKernelGGL((k_face_raster<P, FC, G>), dim3((unsigned)((n + 4 * FC - 1) / (4 * FC))), dim3(256), 0, st, faces, zbuf, \
-                       large_list, wave_list, n_large, visible_faces, (int)n, F, S, near, far, epoch, touched)
+                       large_list, wave_list, n_large, qcap, nshards, visible_faces, (int)n, F, S, near, far, epoch, touched)
         if (small) { if (pow2) NR_FACE_RASTER(true, 16, 4); else NR_FACE_RASTER(false, 16, 4); }
         else { if (pow2) NR_FACE_RASTER(true, 64, 16); else NR_FACE_RASTER(false, 64, 16); }
 #undef NR_FACE_RASTER
@@ -758,8 +825,8 @@ int run_forward(const float *faces, int32_t *face_index_map, float *weight_map, 
     // which costs what dispatching them costs (2048 workgroups: 4.7 us), so small launches get a smaller grid (a face per 256
     // of the call's, 256 .. 2048 workgroups: the queues hold a fraction of the faces, and each large face is a workgroup's work)
     const unsigned queue_wgs = (unsigned)(n / 256 < 256 ? 256 : (n / 256 > 2048 ? 2048 : n / 256));
-    hipLaunchKernelGGL(k_large_raster, dim3(queue_wgs), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, F, S, near,
-                       far, epoch, touched);
+    hipLaunchKernelGGL(k_large_raster, dim3(queue_wgs), dim3(256), 0, st, faces, zbuf, large_list, wave_list, n_large, qcap, nshards,
+                       F, S, near, far, epoch, touched);
     ResolveArgs ra;
     ra.faces = faces; ra.zbuf = zbuf; ra.face_index_map = face_index_map; ra.weight_map = weight_map; ra.depth_map = depth_map;
     ra.face_inv_map = face_inv_map; ra.visible_faces = visible_faces; ra.F = F; ra.S = S; ra.near_d = near; ra.far_d = far;
