@@ -521,6 +521,19 @@ def shard_rows(device, total_views, S, ts, eps, steps, gpus=(2, 4, 8)):
         row['ms_function_protocol'] = runs[2]
         for k in ('ms_autograd', 'ms_autograd_caller_thread', 'ms_function_protocol'):
             row[k.replace('ms_', 'mpixel_per_s_')] = b * S * S / (row[k] * 1e-3) / 1e6
+        # the row's roofline: the whole step's compulsory bytes over its time, and how much of the step is NOT inside the two
+        # fused C-ABI calls when they are issued back to back (HIP events around each on the stream: the kernels plus the gaps
+        # between them) -- the launch-latency / host share of a small shard's step as a number
+        st = time_stages(fd, td, S, eps, grads[0], grads[1], grads[2], 20, 0, only=('fused_forward_rasterize', 'fused_backward_rasterize'))
+        calls_us = st.get('fused_forward_rasterize', 0.0) + st.get('fused_backward_rasterize', 0.0)
+        wb = whole_step_bytes(b, faces.shape[1], S, ts)
+        row['roofline'] = {'bound': 'hbm', 'algorithmic_bytes': wb, 'achieved': wb / (row['ms_function_protocol'] * 1e-3) / 1e9,
+                           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': wb / (row['ms_function_protocol'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           'fused_calls_us': calls_us, 'step_us': row['ms_function_protocol'] * 1e3,
+                           'outside_the_calls_us': row['ms_function_protocol'] * 1e3 - calls_us,
+                           'what': 'whole-step compulsory bytes over the function-protocol step; fused_calls_us: nr_forward_rasterize + '
+                                   'nr_backward_rasterize timed alone with events on the stream (9 launches at these sizes: '
+                                   'profiles/*_step_sequence_shards.txt)'}
         rows.append(row)
         del faces, textures, grads
     return rows
@@ -650,14 +663,36 @@ def grad_check(nr_fn_fi, faces, textures, S, eps, g_rgb, g_alpha, g_depth, n_vie
                        'that cancel to ~0 (the tests bound the floor form by the north star\'s 1e-4; NR_FLAG_EXACT_GRADIENT: 2e-6)' % n_views}
 
 
+def csrc_tree_hash():
+    """sha1 over the library's sources (neural_renderer_amd/csrc/*, include/*.h, the compiler flags): the stamp the counter passes
+    carry (scripts/pmc_traffic.py) -- counters of another build are not this build's traffic."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    from neural_renderer_amd import _build
+    h = hashlib.sha1()
+    for p in sorted(_build.SOURCES + [x for x in _build.HEADERS if x.endswith('.h')]):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, 'rb').read())
+    h.update(' '.join(_build.HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def profile_records():
     """Counter-derived figures of the committed profiles (they cannot be collected inside a timed run): HBM traffic of the
-    dominant stage and the VALU instruction count of the K6 kernel.  Labelled with their source file."""
+    dominant stage and the VALU instruction count of the K6 kernel.  Labelled with their source file.  The file carries the hash
+    of the sources it was collected on (`_build.csrc_sha1`); on another tree the records are dropped (`stale`): the line then
+    has null traffic instead of another build's."""
     out = {}
     p = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
     if os.path.exists(p):
         try:
-            out['pmc'] = json.load(open(p))
+            rec = json.load(open(p))
+            stamp = rec.get('_build', {}).get('csrc_sha1')
+            out['stamp'] = {'file_csrc_sha1': stamp, 'tree_csrc_sha1': csrc_tree_hash()}
+            if stamp == out['stamp']['tree_csrc_sha1']:
+                out['pmc'] = rec
+            else:
+                out['stale'] = True
         except Exception:
             pass
     return out
@@ -869,7 +904,8 @@ def main():
         kernel_us = stages.get('k6_band_kernel_alone') if dominant == 'backward_pixel_map' else None
         launch_us = kernel_us or stages[dominant]
         achieved = stage_bytes[dominant] / (launch_us * 1e-6) / 1e9
-        prof = profile_records().get('pmc', {})
+        prof_all = profile_records()
+        prof = prof_all.get('pmc', {})
         # (the committed counters are launches of the headline shape: 64 teapot views at 256 x 256)
         traffic_rec = prof.get(dominant, {}) if (B == 64 and S == 256 and not c4) else {}
         # HBM bytes of the dominant KERNEL alone (the scope of `avg_launch_us`) and of the whole stage call (the scope of `stage_call`)
@@ -887,9 +923,11 @@ def main():
             'traffic_ratio': (kernel_traffic / stage_bytes[dominant]) if kernel_traffic else None,
             'traffic_scope': 'HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) of the dominant kernel '
                              'ALONE per launch -- the scope of avg_launch_us; the whole stage call with its helper launches: stage_call.traffic',
-            'traffic_source': {'file': 'profiles/pmc_latest.json',
+            'traffic_source': {'file': 'profiles/pmc_latest.json', 'stamp': prof_all.get('stamp'),
+                               'stale': bool(prof_all.get('stale')),
                                'note': 'separate --pmc passes of scripts/gpu_profile_round.sh on the committed build (counters cannot be '
-                                       'collected inside a timed run); null when this run is not the profiled shape (64 teapot views, 256 x 256)'},
+                                       'collected inside a timed run); null when this run is not the profiled shape (64 teapot views, 256 x 256) or when '
+                                       'the file was collected on other sources than this tree (`stale`: the stamps differ)'},
             'algorithmic_bytes_per_launch': stage_bytes[dominant], 'avg_launch_us': launch_us,
             'timing': ('HIP events recorded by the library on the launch stream right in front of and behind the launch of the '
                        'dominant kernel (nr_profile_band_kernel: K6\'s band kernel inside nr_backward_pixel_map, calls issued back to '
@@ -932,6 +970,15 @@ def main():
                 'ns_per_wave_instr_per_simd': NS_PER_WAVE_INSTR, 'simds': NUM_SIMDS, 'issue_floor_us': floor_us,
                 'stage_us': stages['backward_pixel_map'], 'frac': floor_us / stages['backward_pixel_map'],
                 'source': 'SQ_INSTS_VALU from profiles/pmc_latest.json (' + str(valu.get('source')) + '); stage time measured in this run'}
+            ctr = valu.get('counters_per_launch', {})
+            if ctr.get('SQ_THREAD_CYCLES_VALU') and ctr.get('SQ_INSTS_VALU'):
+                # issued lanes that execute (the exec mask), from the counters; and the share of them that does useful work in the
+                # band kernel's visits (pixels inside a sweep / lanes of the steps walked: scripts/row_stats.py, work counters of a
+                # -DNR_ROW_STATS build, committed with the counter passes)
+                roofline['lane_efficiency'] = {
+                    'executing_lanes_per_issued_lane': ctr['SQ_THREAD_CYCLES_VALU'] / (64.0 * ctr['SQ_INSTS_VALU']),
+                    'definition': 'SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU) of ' + str(valu.get('kernel')),
+                    'visits': valu.get('row_stats')}
         extra_rows, e2e, exact_row = [], None, None
         if not args.light:
             # anti-aliasing on: raster 2 x image_size (the Renderer default), same views

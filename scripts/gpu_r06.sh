@@ -105,8 +105,10 @@ if [ -n "$PMC" ]; then
   ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o write -- python scripts/stage_times.py > $OUT/write.log 2>&1
   python scripts/pmc_traffic.py $OUT/fetch_results.db $OUT/write_results.db $OUT/pmc_hbm_traffic.json > $OUT/traffic.log 2>&1
   ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU -d $OUT -o sq -- python scripts/stage_times.py > $OUT/sq.log 2>&1
-  python scripts/pmc_valu.py $OUT/sq_results.db $OUT/pmc_hbm_traffic.json >> $OUT/traffic.log 2>&1
   ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT -o sq2 -- python scripts/stage_times.py > $OUT/sq2.log 2>&1
+  # (work counters of the band kernel from a -DNR_ROW_STATS variant build, when the tree holds one: scripts/row_stats.py)
+  [ -f neural_renderer_amd/libnr_hip_stats.so ] && SHAPES="64x256 64x512 8x256" timeout 300 python scripts/row_stats.py 2>/dev/null | grep "^{" > $OUT/row_stats.jsonl
+  ROW_STATS=$OUT/row_stats.jsonl python scripts/pmc_valu.py $OUT/sq_results.db,$OUT/sq2_results.db $OUT/pmc_hbm_traffic.json >> $OUT/traffic.log 2>&1
   ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES -d $OUT -o sq3 -- python scripts/stage_times.py > $OUT/sq3.log 2>&1
   for db in sq sq2 sq3; do python scripts/rocpd_pmc.py $OUT/${db}_results.db k_bpm >> $OUT/pmc_k6.txt 2>&1; done
   for k in k_face_raster k_line_setup "k_backward_textures_face<true, true>"; do
