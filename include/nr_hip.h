@@ -56,8 +56,8 @@
 extern "C" {
 #endif
 
-#define NR_VERSION 600 /* 0.6.0: K6's default mode on ONE band kernel for every call size (k_bpm_row: a line record per 16 lanes, the
-                          *        sums of a record on the matrix pipe in double); NR_FLAG_K6_PX is ignored;
+#define NR_VERSION 600 /* 0.6.0: K6's two arithmetic modes on ONE band kernel for every call size (k_bpm_row: a line record per 16 lanes,
+                          *        the sums of a record on the matrix pipe in double); NR_FLAG_K6_PX is ignored;
                           * 0.5.0: K6's default mode on the lane-parallel band kernel (k_bpm_px; NR_FLAG_K6_LEGACY keeps k_bpm_fast); the
                           *        measurement hook nr_profile_band_kernel left the product ABI (include/nr_hip_profile.h, libnr_hip_prof.so);
                           * 0.4.1: NR_FLAG_SERIAL_BACKWARD (the fused backward's gather shares a launch with K6's line setup);
@@ -115,14 +115,15 @@ extern "C" {
                                          grad_faces last.  Same values: one float addition per element of grad_faces either
                                          way; a testing / measuring aid. */
 
-#define NR_FLAG_K6_LEGACY 128          /* K6, default arithmetic mode: the piece-per-lane band kernel of rounds 3-4 (k_bpm_fast) instead of
-                                         k_bpm_row.  A testing / measuring aid: same sweeps, terms rounded and summed another way
-                                         (both within the default mode's bound of the oracle). */
+#define NR_FLAG_K6_LEGACY 128          /* K6, either arithmetic mode: the piece-per-lane band kernel of rounds 3-4 (k_bpm_fast) instead of
+                                         k_bpm_row.  A testing / measuring aid: same sweeps, terms rounded (default mode) and summed
+                                         another way (both within the mode's bound of the oracle). */
 #define NR_FLAG_K6_PX 65536              /* accepted and ignored since 0.6.0 (it forced round 5's lane-parallel kernel, whose place
-                                         k_bpm_row has taken for every call: the default mode has one band kernel -- 16 lanes per
-                                         line record, four records per wave instruction -- wherever its band fits the LDS (raster
-                                         <= 1024) and eps > 0; the exact mode, the scan path, larger rasters and eps = 0 run on
-                                         k_bpm_fast).  Which kernel a call takes does not depend on its batch size. */
+                                         k_bpm_row has taken for every call: both arithmetic modes have one band kernel -- 16 lanes
+                                         per line record, four records per wave instruction -- wherever its band fits the LDS
+                                         (raster <= 1024; the default mode: eps > 0); the scan path, larger rasters and the default
+                                         mode with eps = 0 run on k_bpm_fast).  Which kernel a call takes does not depend on its
+                                         batch size. */
 
 /*
  * faces_z_ref (nr_forward_texture_sampling, nr_forward_rasterize, nr_backward_textures, nr_backward_rasterize):

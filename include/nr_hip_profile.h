@@ -26,7 +26,7 @@ float nr_profile_band_kernel_ms(void);
 /* which band kernel the last bracketed launch was: 0 k_bpm_fast, 1 k_bpm_row (-1: none) */
 int nr_profile_band_kernel_which(void);
 /* which band kernel a call takes, as a function of the call (host logic only, callable without a device): 1 k_bpm_row, 0
- * k_bpm_fast (the exact mode, NR_FLAG_K6_SCAN / _LEGACY, rasters beyond 1024, eps = 0).  The batch size does not enter. */
+ * k_bpm_fast (NR_FLAG_K6_SCAN / _LEGACY, rasters beyond 1024, the default mode with eps = 0).  The batch size does not enter. */
 int nr_profile_k6_choice(int32_t B, int32_t F, int32_t S, int32_t return_rgb, int32_t return_alpha, double eps, int32_t flags);
 
 #ifdef __cplusplus

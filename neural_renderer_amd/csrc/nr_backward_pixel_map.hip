@@ -1414,7 +1414,7 @@ __device__ __forceinline__ void wave_lds_handover()
 // 4.6e-5 / 5.9e-5, headline 3.3e-5 / 4.1e-5).
 // Flush: one lane per record adds in sweep + out sweep to the double scratch (global_atomic_add_f64), as k_bpm_fast does.
 // Images whose records exceed the line buffer (lines_ok == 0) are left to k_bpm_fast's scan path (launched behind this kernel
-// with overflow_only set).  The exact mode (NR_FLAG_EXACT_GRADIENT) stays with k_bpm_fast.
+// with overflow_only set).
 #ifndef NR_ROW_OFF  // (development, switch-off builds -- results wrong by construction: 1 no out sweeps, 2 no in sweeps, 4 no global atomics at the flush)
 #define NR_ROW_OFF 0
 #endif
@@ -1429,10 +1429,15 @@ constexpr int MAX_SEGS = 64;       // segments of a line, at most (raster <= 102
 constexpr int IN_SEG = 16;        // float terms per double addition of an in sweep (a piece of k_bpm_fast holds 15)
 constexpr int IN_BATCH = 4;       // pixels of an in sweep whose LDS reads are requested together
 constexpr int MAX_PX = 1024;       // pixels of a band, at most
-// LDS of a workgroup: gradients [W][SP][NC] | sums P [W][SP] | face indices [W][SP] | K of the band's lines | a window per wave
+// LDS of a workgroup: gradients [W][SP][NC] | sums P [W][SP] (the exact mode: colours [W][SP][NC]) | face indices [W][SP] |
+// K of the band's lines (not in the exact mode) | a window per wave
 template <bool RGB> constexpr int g_bytes() { return RGB ? MAX_PX * 16 : MAX_PX * 4; }
 constexpr int P_BYTES = MAX_PX * 4, FI_BYTES = MAX_PX * 4, K_BYTES = NW * 16, WAVE_BYTES = WIN * 16;
-template <bool RGB> constexpr size_t lds_bytes() { return g_bytes<RGB>() + P_BYTES + FI_BYTES + K_BYTES + NW * WAVE_BYTES + NR_ROW_LDS_PAD; }
+template <bool RGB, bool EXACT> constexpr int c_bytes() { return EXACT ? g_bytes<RGB>() : P_BYTES; }
+template <bool RGB, bool EXACT> constexpr size_t lds_bytes()
+{
+    return g_bytes<RGB>() + c_bytes<RGB, EXACT>() + FI_BYTES + (EXACT ? 0 : K_BYTES) + NW * WAVE_BYTES + NR_ROW_LDS_PAD;
+}
 }  // namespace rowk
 
 #ifdef NR_ROW_STATS  // development builds (scripts/row_stats.py): work counters of k_bpm_row
@@ -1448,15 +1453,21 @@ NR_API int nr_dev_row_stats(unsigned long long *out8)
 #define NR_ROW_STAT(i, v) ((void)0)
 #endif
 
-template <bool RGB, bool ALPHA>
-__global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
+// MODE: K6_FAST -- the default arithmetic, as described above -- or K6_EXACT / K6_EXACT_POW2 (NR_FLAG_EXACT_GRADIENT): the same
+// groups of four records, every term with the reference's own operations: sum_c (I_c - ref_c) g_c rounded product by product
+// (the colours, not the centred sums, are staged: 36 bytes per pixel, four workgroups per CU), `x * 2. / is` and `dist +- eps` in
+// double, IEEE division, every sum in double -- a lane adds its terms to double accumulators, the matrix pipe adds the lanes.
+// A masked lane divides 0 by 1 (the select sits in front of the division: no 0 / 0, no Inf * 0).
+template <bool RGB, bool ALPHA, int MODE>
+__global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
     const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
     const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, double *__restrict__ scratch,
     const int *__restrict__ band_lines, const int *__restrict__ band_start, const int *__restrict__ lines_ok,
-    const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, float eps_f, int B,
+    const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, float eps_f, double eps_d, int B,
     uint4 *__restrict__ zero16, size_t n_zero16)
 {
     using namespace rowk;
+    constexpr bool EXACT = MODE != K6_FAST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
     const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
@@ -1479,11 +1490,12 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
     constexpr int G_BYTES = g_bytes<RGB>();
     // a line in LDS: SP pixels, a multiple of 32 (an even number of segments); the pixels behind the raster hold zeros
     const int SP = (S + 31) & ~31, nsl = SP / SEG;
+    constexpr int C_BYTES = c_bytes<RGB, EXACT>();
     float *const s_g = (float *)smem;                                  // [W][SP][NC] gradients
-    float *const s_p = (float *)(smem + G_BYTES);                      // [W][SP] sum_c (I_c - K_c) g_c
-    int *const s_fi = (int *)(smem + G_BYTES + P_BYTES);               // [W][SP] face index
-    float4 *const s_k = (float4 *)(smem + G_BYTES + P_BYTES + FI_BYTES);  // [W] K of each line: (alpha, r, g, b)
-    unsigned char *wave_mem = smem + G_BYTES + P_BYTES + FI_BYTES + K_BYTES + (size_t)wave * WAVE_BYTES;
+    float *const s_p = (float *)(smem + G_BYTES);                      // [W][SP] sum_c (I_c - K_c) g_c; exact mode: [W][SP][NC] colours
+    int *const s_fi = (int *)(smem + G_BYTES + C_BYTES);               // [W][SP] face index
+    float4 *const s_k = (float4 *)(smem + G_BYTES + C_BYTES + FI_BYTES);  // [W] K of each line: (alpha, r, g, b) (not in the exact mode)
+    unsigned char *wave_mem = smem + G_BYTES + C_BYTES + FI_BYTES + (EXACT ? 0 : K_BYTES) + (size_t)wave * WAVE_BYTES;
     double2 *acc = (double2 *)wave_mem;  // [WIN] a record's two out-sweep sums (magnitudes) ...
     int *hist = (int *)wave_mem;         // ... after the sort's counters are done with the same bytes
     const int n_parts = max(1, NW / W);  // (a band narrower than the workgroup has waves: they share the windows of a line)
@@ -1500,6 +1512,7 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
     };
     // K of a line: the colour of its first pixel (see above); not finite: 0
     auto line_k = [&](int ld) {
+        if constexpr (EXACT) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float4 k = map_colour(map_index(ld, 0));
         const bool fin = fabsf(k.x) <= 3.0e38f && fabsf(k.y) <= 3.0e38f && fabsf(k.z) <= 3.0e38f && fabsf(k.w) <= 3.0e38f;
         if (!fin) k = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1525,13 +1538,16 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
             s_fi[l] = fi;
             if constexpr (RGB) {
                 *reinterpret_cast<float4 *>(s_g + 4 * (size_t)l) = make_float4(ga, gr, gg, gb);
-                s_p[l] = (float)((ALPHA ? (double)(al - k.x) * (double)ga : 0.0) + (double)(r - k.y) * (double)gr +
-                                 (double)(g - k.z) * (double)gg + (double)(bl - k.w) * (double)gb);
+                if constexpr (EXACT)
+                    *reinterpret_cast<float4 *>(s_p + 4 * (size_t)l) = make_float4(al, r, g, bl);
+                else
+                    s_p[l] = (float)((ALPHA ? (double)(al - k.x) * (double)ga : 0.0) + (double)(r - k.y) * (double)gr +
+                                     (double)(g - k.z) * (double)gg + (double)(bl - k.w) * (double)gb);
             } else {
                 s_g[l] = ga;
-                s_p[l] = (al - k.x) * ga;
+                s_p[l] = EXACT ? al : (al - k.x) * ga;
             }
-            if (d1 == 0) s_k[ld] = k;
+            if constexpr (!EXACT) { if (d1 == 0) s_k[ld] = k; }
         };
         // four adjacent pixels of a map row with one 16-byte load per field (see fast_stage)
         auto put_quad = [&](size_t g, int ld0, int d10, int ld_step, int d1_step) {
@@ -1578,7 +1594,8 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
             for (int i = tid; i < nld * pad; i += NT) {
                 const int ld = i / pad, l = ld * SP + S + (i - ld * pad);
                 s_fi[l] = -1;
-                s_p[l] = 0.0f;
+                if constexpr (EXACT && RGB) *reinterpret_cast<float4 *>(s_p + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                else s_p[l] = 0.0f;
                 if constexpr (RGB) *reinterpret_cast<float4 *>(s_g + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 else s_g[l] = 0.0f;
             }
@@ -1601,6 +1618,22 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
 
     float eps_v = eps_f;
     asm volatile("" : "+v"(eps_v));
+    // the exact mode's term: :649-651 / :654-656 (x * 2. / S: an exact float scaling when S is a power of two); ct = c * t
+    const unsigned eps_hi = (unsigned)__double2hiint(eps_d), eps_lo = (unsigned)__double2loint(eps_d);
+    const double s_d = (double)S;
+    const float two_over_s_f = (float)(2.0 / (double)S);
+    auto exact_dist = [&](float ct) {
+        float dist = MODE == K6_EXACT_POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
+        return (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
+    };
+    // sum_c (I_c - ref_c) g_c with the reference's operations in its order (:631-638 / :709-716)
+    auto exact_diff = [&](const float4 &c4, const float4 &cr, const float4 &g4) {
+        if constexpr (!RGB) return (c4.x - cr.x) * g4.x;
+        float d = ALPHA ? (c4.x - cr.x) * g4.x + (c4.y - cr.y) * g4.y : (c4.y - cr.y) * g4.y;
+        d += (c4.z - cr.z) * g4.z;
+        d += (c4.w - cr.w) * g4.w;
+        return d;
+    };
     // the lane's block (record of a group) and its pixel inside a segment (see above)
     const int row = (lane >> 2) & 3, l16 = ((((lane >> 4) + ((lane >> 2) & 2)) & 3) << 2) | (lane & 3);
     for (int vt = wave; vt < nld * n_parts; vt += NW) {
@@ -1609,7 +1642,8 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
         if (n_rec == 0) continue;
         const BandLine *recs = recs_b + band_start[lt + ld];
         const int base = ld * SP;
-        const float4 kc = s_k[ld];
+        float4 kc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (!EXACT) kc = s_k[ld];
         for (int w0 = part * WIN; w0 < n_rec; w0 += WIN * n_parts) {
             const int nw = min(WIN, n_rec - w0);
             // ---- phase A: lane = record.  The lane keeps its record for the flush, walks the record's in sweep, and prepares what
@@ -1651,7 +1685,9 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                 if constexpr (RGB) g4 = lds_px4(s_g + 4 * (size_t)l);
                 else g4 = make_float4(s_g[l], 0.0f, 0.0f, 0.0f);
                 float d;
-                if constexpr (RGB) {
+                if constexpr (EXACT) {
+                    d = exact_diff(ci, cr, g4);
+                } else if constexpr (RGB) {
                     d = ALPHA ? __builtin_fmaf(ci.y - cr.y, g4.y, (ci.x - cr.x) * g4.x) : (ci.y - cr.y) * g4.y;
                     d = __builtin_fmaf(ci.z - cr.z, g4.z, d);
                     d = __builtin_fmaf(ci.w - cr.w, g4.w, d);
@@ -1661,7 +1697,7 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                 return d;
             };
             float f0 = 0.0f, f1 = 0.0f;  // the out pixel's terms (magnitudes: the sign goes on at the flush, with the out sweep's)
-            if (has_out) {
+            if (has_out && !EXACT) {  // (the exact mode: phase B walks the whole out sweep)
                 const float d = direct_diff(c_out, c_in, base + d1_out);                           // :631-638
                 const float dm = !(d <= 0.0f) ? d : 0.0f;                                           // :647
                 const float t = fabsf((float)d1_out - qq.x);
@@ -1669,14 +1705,15 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                 f1 = dm * __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(qq.z), t, eps_v));            // :654-656
             }
             // segments of what phase B walks of the out sweep -- [o_from + 1, S) or [0, o_to - 1]: [from / 16, nsl) or [0, to / 16]
-            const bool has_b = has_out && o_from < o_to;
-            const int nseg = has_b ? (dpos ? nsl - ((o_from + 1) >> 4) : ((o_to - 1) >> 4) + 1) : 0;
+            const bool has_b = has_out && (EXACT || o_from < o_to);
+            const int b_from = o_from + (EXACT ? 0 : 1), b_to = o_to - (EXACT ? 0 : 1);
+            const int nseg = has_b ? (dpos ? nsl - (b_from >> 4) : (b_to >> 4) + 1) : 0;
             hist[lane] = 0;
             double in0 = 0.0, in1 = 0.0;
             if (has_in && !(NR_ROW_OFF & 2)) {
                 const float cross = qq.x, c0k = qq.y, c1k = qq.z;
                 const int fnr = __float_as_int(qq.w);
-                const float d_first = direct_diff(c_in, c_out, base + d1_in);
+                const float d_first = EXACT ? 0.0f : direct_diff(c_in, c_out, base + d1_in);
                 // (batches of IN_BATCH pixels whose LDS reads are requested together -- nine in-sweeps in ten are one batch;
                 // IN_SEG float terms per double addition, like a piece of k_bpm_fast)
                 for (int s0 = in_from; s0 <= in_to; s0 += IN_SEG) {
@@ -1684,36 +1721,56 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                     float b0 = 0.0f, b1 = 0.0f;
                     for (int q0 = s0; q0 <= s1; q0 += IN_BATCH) {
                         int fi[IN_BATCH];
-                        float4 g4[IN_BATCH];
+                        float4 g4[IN_BATCH], c4[IN_BATCH];
                         float p4[IN_BATCH];
 #pragma unroll
                         for (int k = 0; k < IN_BATCH; ++k) {
                             const int l = base + min(q0 + k, s1);
                             fi[k] = s_fi[l];
-                            p4[k] = s_p[l];
+                            c4[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            p4[k] = 0.0f;
+                            if constexpr (EXACT) {
+                                if constexpr (RGB) c4[k] = lds_px4(s_p + 4 * (size_t)l);
+                                else c4[k].x = s_p[l];
+                            } else {
+                                p4[k] = s_p[l];
+                            }
                             if constexpr (RGB) g4[k] = lds_px4(s_g + 4 * (size_t)l);
                             else g4[k] = make_float4(s_g[l], 0.0f, 0.0f, 0.0f);
                         }
 #pragma unroll
                         for (int k = 0; k < IN_BATCH; ++k) {
-                            float diff = p4[k];                                                    // :709-716
-                            if constexpr (!RGB || ALPHA) diff = __builtin_fmaf(-iref.x, g4[k].x, diff);
-                            if constexpr (RGB) {
-                                diff = __builtin_fmaf(-iref.y, g4[k].y, diff);
-                                diff = __builtin_fmaf(-iref.z, g4[k].z, diff);
-                                diff = __builtin_fmaf(-iref.w, g4[k].w, diff);
+                            float diff;                                                            // :709-716
+                            if constexpr (EXACT) {
+                                diff = exact_diff(c4[k], c_out, g4[k]);
+                            } else {
+                                diff = p4[k];
+                                if constexpr (!RGB || ALPHA) diff = __builtin_fmaf(-iref.x, g4[k].x, diff);
+                                if constexpr (RGB) {
+                                    diff = __builtin_fmaf(-iref.y, g4[k].y, diff);
+                                    diff = __builtin_fmaf(-iref.z, g4[k].z, diff);
+                                    diff = __builtin_fmaf(-iref.w, g4[k].w, diff);
+                                }
+                                if (q0 + k == d1_in) diff = d_first;
                             }
-                            if (q0 + k == d1_in) diff = d_first;
                             // :707, :717 (a NaN diff goes through); a pixel beyond the batch's end repeats the last one: dropped
                             const bool take = (q0 + k <= s1) & (fi[k] == fnr) & !(diff <= 0.0f);
                             const float t = (float)(q0 + k) - cross;
-                            const float x0 = c0k * t, x1 = c1k * t;                               // :719 / :724 (2 / S folded into c)
-                            const float y0 = x0 + ((0.0f < x0) ? eps_v : -eps_v);                 // :720-721 / :725-726
-                            const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
-                            const float dm = take ? diff : 0.0f;
-                            // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
-                            b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
-                            b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
+                            if constexpr (EXACT) {
+                                // (the select in front of the division: a pixel that is not taken divides 0 by 1)
+                                const float dm = take ? diff : 0.0f;
+                                const float y0 = take ? exact_dist(c0k * t) : 1.0f, y1 = take ? exact_dist(c1k * t) : 1.0f;
+                                in0 -= (double)(dm / y0);                                            // :719-722
+                                in1 -= (double)(dm / y1);                                            // :724-727
+                            } else {
+                                const float x0 = c0k * t, x1 = c1k * t;                               // :719 / :724 (2 / S folded into c)
+                                const float y0 = x0 + ((0.0f < x0) ? eps_v : -eps_v);                 // :720-721 / :725-726
+                                const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
+                                const float dm = take ? diff : 0.0f;
+                                // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
+                                b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
+                                b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
+                            }
                         }
                     }
                     in0 += (double)b0;
@@ -1752,116 +1809,171 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
             // ---- phase B: four records at a time, one per block of 16 lanes
             // what a block is handed (from the lane that holds the record)
             const float v_ncd = dpos ? -qq.x : qq.x;
-            const float v_ac0 = __uint_as_float((__float_as_uint(qq.y) & 0x7fffffffu) | (dpos ? 0u : 0x80000000u));
-            const float v_ac1 = fabsf(qq.z);
+            // fast mode: |c0| carrying the direction in its sign bit, |c1|; exact mode: c0 * direction, c1 * direction (signed: a
+            // product with +-1 is exact, so (c * direction) * (direction * t) is the reference's c * t bit for bit), and the
+            // direction in the sign of the segment count
+            const float v_ac0 = EXACT ? (dpos ? qq.y : -qq.y)
+                                      : __uint_as_float((__float_as_uint(qq.y) & 0x7fffffffu) | (dpos ? 0u : 0x80000000u));
+            const float v_ac1 = EXACT ? (dpos ? qq.z : -qq.z) : fabsf(qq.z);
+            const int v_nseg = EXACT ? (dpos ? nseg : -nseg) : nseg;
+            float4 oref_b = oref;  // the out sweep's reference colour as the blocks use it: minus K, or as it is (exact mode)
+            if constexpr (EXACT) oref_b = c_in;
             int src_next = __builtin_amdgcn_ds_bpermute(row << 2, inv);
             for (int g0 = 0; g0 < ((NR_ROW_OFF & 1) ? 0 : n_out); g0 += 4) {
                 const bool act = g0 + row < n_out;
                 const int src = src_next;  // (of a block without a record: some lane; nothing of it is used)
                 src_next = __builtin_amdgcn_ds_bpermute(((g0 + 4 + row) & 63) << 2, inv);
                 const int sa = src << 2;
-                const int r_nseg = __builtin_amdgcn_ds_bpermute(sa, nseg);
+                const int r_nseg_s = __builtin_amdgcn_ds_bpermute(sa, v_nseg);
+                const int r_nseg = EXACT ? abs(r_nseg_s) : r_nseg_s;
                 float ncd = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ncd)));
                 const float ac0s = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ac0)));
                 const float ac1 = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(v_ac1)));
                 float ra = 0.0f, rr = 0.0f, rg = 0.0f, rb = 0.0f;
-                if constexpr (!RGB || ALPHA) ra = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.x)));
+                if constexpr (!RGB || ALPHA) ra = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref_b.x)));
                 if constexpr (RGB) {
-                    rr = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.y)));
-                    rg = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.z)));
-                    rb = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref.w)));
+                    rr = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref_b.y)));
+                    rg = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref_b.z)));
+                    rb = __int_as_float(__builtin_amdgcn_ds_bpermute(sa, __float_as_int(oref_b.w)));
                 }
                 // (a block without a record: td = -Inf for every pixel, nothing is taken, nothing stored)
                 if (!act) ncd = -__builtin_inff();
-                const float sdir = __uint_as_float(0x3f800000u | (__float_as_uint(ac0s) & 0x80000000u));
+                const float sdir = EXACT ? (r_nseg_s < 0 ? -1.0f : 1.0f)
+                                         : __uint_as_float(0x3f800000u | (__float_as_uint(ac0s) & 0x80000000u));
                 // the group walks as many steps as its longest sweep has segments (the first block's: the order of the sort), an
                 // even number; a sweep towards the end of the line ENDS with the group's last step, one from pixel 0 starts with its
                 // first; pixels in front of a sweep or behind it are masked (td <= 0)
                 const int steps = __builtin_amdgcn_readfirstlane(r_nseg), steps2 = (steps + 1) & ~1;
                 NR_ROW_STAT(5, 1);       // groups
                 NR_ROW_STAT(6, steps2);  // steps walked
-                const bool rpos = !(__float_as_uint(ac0s) >> 31);
+                const bool rpos = EXACT ? r_nseg_s >= 0 : !(__float_as_uint(ac0s) >> 31);
                 const int seg0 = rpos ? nsl - steps2 : 0;
                 const int p0 = seg0 * SEG + l16;
                 float pf = (float)p0;
-                const unsigned char *gp = (const unsigned char *)s_g + (size_t)(base + p0) * (NC * 4);
-                const float *pp = s_p + base + p0;
-                auto visit = [&](const float4 &g4, const float pv, const float pfv, float &a0, float &a1) {
-                    float d = pv;                                                                  // :631-638
-                    if constexpr (!RGB || ALPHA) d = __builtin_fmaf(-ra, g4.x, d);
-                    if constexpr (RGB) {
-                        d = __builtin_fmaf(-rr, g4.y, d);
-                        d = __builtin_fmaf(-rg, g4.z, d);
-                        d = __builtin_fmaf(-rb, g4.w, d);
+                double A0 = 0.0, A1 = 0.0;
+                if constexpr (EXACT) {
+                    // ---- the exact mode: gradients and colours of a step (two 16-byte reads), the reference's term (rasterize.py
+                    // :631-657) operation by operation, a double accumulator pair per lane; td = direction * (d1 - d1_cross) is the
+                    // reference's t = d1 - d1_cross times +-1, and ac0s / ac1 are its c0 / c1 times the same +-1: the products
+                    // c * t are the reference's bit for bit
+                    const unsigned char *gp = (const unsigned char *)s_g + (size_t)(base + p0) * (NC * 4);
+                    const unsigned char *cp = (const unsigned char *)s_p + (size_t)(base + p0) * (NC * 4);
+                    const float4 cref = make_float4(ra, rr, rg, rb);
+                    auto load_x = [&](int k, float4 &g4, float4 &c4) {
+                        if constexpr (RGB) {
+                            g4 = *reinterpret_cast<const float4 *>(gp + k * (SEG * NC * 4));
+                            c4 = *reinterpret_cast<const float4 *>(cp + k * (SEG * NC * 4));
+                        } else {
+                            g4 = make_float4(*reinterpret_cast<const float *>(gp + k * (SEG * NC * 4)), 0.0f, 0.0f, 0.0f);
+                            c4 = make_float4(*reinterpret_cast<const float *>(cp + k * (SEG * NC * 4)), 0.0f, 0.0f, 0.0f);
+                        }
+                    };
+                    auto visit_x = [&](const float4 &g4, const float4 &c4, const float pfv) {
+                        if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x), "v"(c4.x));
+                        const float d = exact_diff(c4, cref, g4);
+                        const float td = __builtin_fmaf(sdir, pfv, ncd);    // > 0 exactly on the sweep's pixels
+                        const bool keep = !(td <= 0.0f) && !(d <= 0.0f);   // (:647: a NaN diff goes through)
+                        // (both distances are formed for every lane and the select sits in front of the division: a masked lane
+                        // divides 0 by 1 -- and the loop has no branch)
+                        const float e0 = exact_dist(ac0s * td), e1 = exact_dist(ac1 * td);
+                        const float dm = keep ? d : 0.0f, y0 = keep ? e0 : 1.0f, y1 = keep ? e1 : 1.0f;
+                        A0 -= (double)(dm / y0);                                                    // :649-651
+                        A1 -= (double)(dm / y1);                                                    // :654-656
+                    };
+                    for (int s = 0; s < steps2; s += 2) {  // (two steps per iteration: their reads and their chains overlap)
+                        float4 gA, cA, gB, cB;
+                        load_x(0, gA, cA);
+                        load_x(1, gB, cB);
+                        visit_x(gA, cA, pf);
+                        visit_x(gB, cB, pf + (float)SEG);
+                        gp += 2 * SEG * NC * 4;
+                        cp += 2 * SEG * NC * 4;
+                        pf += (float)(2 * SEG);
                     }
-                    // direction * (d1 - d1_cross): > 0 exactly on the sweep's pixels, in (0, 1] on its first one -- phase A's
-                    const float td = __builtin_fmaf(sdir, pfv, ncd);
-                    const bool keep = !(td <= 1.0f) && !(d <= 0.0f);  // (:647: a NaN diff goes through)
-                    const float dm = keep ? d : 0.0f;
-                    const float y0 = __builtin_fmaf(fabsf(ac0s), fabsf(td), eps_v), y1 = __builtin_fmaf(ac1, fabsf(td), eps_v);  // :649-650 / :654-655
-                    a0 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y0), a0);                        // :651 (sign: the flush)
-                    a1 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y1), a1);                        // :656
-                };
-                // (plain 16-byte reads: lds_px4's barrier would make every read wait for its data on the spot; the instance without
-                // alpha keeps its first component formally alive BEHIND the visit instead, see lds_px4)
-                auto load = [&](int k, float4 &g4, float &pv) {
-                    if constexpr (RGB) g4 = *reinterpret_cast<const float4 *>(gp + k * (SEG * NC * 4));
-                    else g4 = make_float4(*reinterpret_cast<const float *>(gp + k * (SEG * NC * 4)), 0.0f, 0.0f, 0.0f);
-                    pv = pp[k * SEG];
-                };
-                auto used = [&](const float4 &g4) {
-                    if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x));
-                };
-                // A lane adds the terms of its even and of its odd segments in float (<= 8 terms each at raster 256, 32 at 1024: the
-                // terms fall off like 1 / t); everything above is double: the matrix pipe adds the 2 x 16 sums of a block.  seg0 is
-                // even, so which of a sweep's terms share a float sum does not depend on the other records of its group: a record's
-                // sums are the same bits whatever window, group or launch it is part of.  (Chains cut every 16 / 8 / 4 steps,
-                // each with a reduction of its own: +0 / +4 / +12 % kernel time at raster 256, error levels unchanged.)
-                float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
-                {
-                    // Two steps per pair, two pairs of registers: while one pair is visited the other pair's reads are in flight
-                    // (the scheduling barriers keep the compiler from gathering the reads at the top of the loop, where every
-                    // iteration would wait for them).  Behind the group's last step the reads fetch what is never used (inside
-                    // the workgroup's LDS: at most two segments past a line).
-                    float4 gA, gB, gC, gD;
-                    float pA, pB, pC, pD;
-                    load(0, gA, pA);
-                    load(1, gB, pB);
-                    int s = 0;
-                    for (; s + 4 <= steps2; s += 4) {
-                        load(2, gC, pC);
-                        load(3, gD, pD);
-                        __builtin_amdgcn_sched_barrier(0);
-                        visit(gA, pA, pf, a0, a1);
-                        used(gA);
-                        visit(gB, pB, pf + (float)SEG, b0, b1);
-                        used(gB);
-                        __builtin_amdgcn_sched_barrier(0);
-                        load(4, gA, pA);
-                        load(5, gB, pB);
-                        __builtin_amdgcn_sched_barrier(0);
-                        visit(gC, pC, pf + (float)(2 * SEG), a0, a1);
-                        used(gC);
-                        visit(gD, pD, pf + (float)(3 * SEG), b0, b1);
-                        used(gD);
-                        __builtin_amdgcn_sched_barrier(0);
-                        gp += 4 * (SEG * NC * 4);
-                        pp += 4 * SEG;
-                        pf += (float)(4 * SEG);
+                    A0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, 1.0, 0.0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, 1.0, 0.0, 0, 0, 0);
+                    A0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, 1.0, 0.0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, 1.0, 0.0, 0, 0, 0);
+                } else {
+                    const unsigned char *gp = (const unsigned char *)s_g + (size_t)(base + p0) * (NC * 4);
+                    const float *pp = s_p + base + p0;
+                    auto visit = [&](const float4 &g4, const float pv, const float pfv, float &a0, float &a1) {
+                        float d = pv;                                                                  // :631-638
+                        if constexpr (!RGB || ALPHA) d = __builtin_fmaf(-ra, g4.x, d);
+                        if constexpr (RGB) {
+                            d = __builtin_fmaf(-rr, g4.y, d);
+                            d = __builtin_fmaf(-rg, g4.z, d);
+                            d = __builtin_fmaf(-rb, g4.w, d);
+                        }
+                        // direction * (d1 - d1_cross): > 0 exactly on the sweep's pixels, in (0, 1] on its first one -- phase A's
+                        const float td = __builtin_fmaf(sdir, pfv, ncd);
+                        const bool keep = !(td <= 1.0f) && !(d <= 0.0f);  // (:647: a NaN diff goes through)
+                        const float dm = keep ? d : 0.0f;
+                        const float y0 = __builtin_fmaf(fabsf(ac0s), fabsf(td), eps_v), y1 = __builtin_fmaf(ac1, fabsf(td), eps_v);  // :649-650 / :654-655
+                        a0 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y0), a0);                        // :651 (sign: the flush)
+                        a1 = __builtin_fmaf(dm, __builtin_amdgcn_rcpf(y1), a1);                        // :656
+                    };
+                    // (plain 16-byte reads: lds_px4's barrier would make every read wait for its data on the spot; the instance without
+                    // alpha keeps its first component formally alive BEHIND the visit instead, see lds_px4)
+                    auto load = [&](int k, float4 &g4, float &pv) {
+                        if constexpr (RGB) g4 = *reinterpret_cast<const float4 *>(gp + k * (SEG * NC * 4));
+                        else g4 = make_float4(*reinterpret_cast<const float *>(gp + k * (SEG * NC * 4)), 0.0f, 0.0f, 0.0f);
+                        pv = pp[k * SEG];
+                    };
+                    auto used = [&](const float4 &g4) {
+                        if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x));
+                    };
+                    // A lane adds the terms of its even and of its odd segments in float (<= 8 terms each at raster 256, 32 at 1024: the
+                    // terms fall off like 1 / t); everything above is double: the matrix pipe adds the 2 x 16 sums of a block.  seg0 is
+                    // even, so which of a sweep's terms share a float sum does not depend on the other records of its group: a record's
+                    // sums are the same bits whatever window, group or launch it is part of.  (Chains cut every 16 / 8 / 4 steps,
+                    // each with a reduction of its own: +0 / +4 / +12 % kernel time at raster 256, error levels unchanged.)
+                    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+                    {
+                        // Two steps per pair, two pairs of registers: while one pair is visited the other pair's reads are in flight
+                        // (the scheduling barriers keep the compiler from gathering the reads at the top of the loop, where every
+                        // iteration would wait for them).  Behind the group's last step the reads fetch what is never used (inside
+                        // the workgroup's LDS: at most two segments past a line).
+                        float4 gA, gB, gC, gD;
+                        float pA, pB, pC, pD;
+                        load(0, gA, pA);
+                        load(1, gB, pB);
+                        int s = 0;
+                        for (; s + 4 <= steps2; s += 4) {
+                            load(2, gC, pC);
+                            load(3, gD, pD);
+                            __builtin_amdgcn_sched_barrier(0);
+                            visit(gA, pA, pf, a0, a1);
+                            used(gA);
+                            visit(gB, pB, pf + (float)SEG, b0, b1);
+                            used(gB);
+                            __builtin_amdgcn_sched_barrier(0);
+                            load(4, gA, pA);
+                            load(5, gB, pB);
+                            __builtin_amdgcn_sched_barrier(0);
+                            visit(gC, pC, pf + (float)(2 * SEG), a0, a1);
+                            used(gC);
+                            visit(gD, pD, pf + (float)(3 * SEG), b0, b1);
+                            used(gD);
+                            __builtin_amdgcn_sched_barrier(0);
+                            gp += 4 * (SEG * NC * 4);
+                            pp += 4 * SEG;
+                            pf += (float)(4 * SEG);
+                        }
+                        if (s < steps2) {  // (the last pair: already requested)
+                            visit(gA, pA, pf, a0, a1);
+                            used(gA);
+                            visit(gB, pB, pf + (float)SEG, b0, b1);
+                            used(gB);
+                        }
                     }
-                    if (s < steps2) {  // (the last pair: already requested)
-                        visit(gA, pA, pf, a0, a1);
-                        used(gA);
-                        visit(gB, pB, pf + (float)SEG, b0, b1);
-                        used(gB);
-                    }
+                    A0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, 1.0, 0.0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a1, 1.0, 0.0, 0, 0, 0);
+                    A0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b0, 1.0, A0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b1, 1.0, A1, 0, 0, 0);
+                    A0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, 1.0, 0.0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, 1.0, 0.0, 0, 0, 0);
                 }
-                double A0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, 1.0, 0.0, 0, 0, 0);
-                double A1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a1, 1.0, 0.0, 0, 0, 0);
-                A0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b0, 1.0, A0, 0, 0, 0);
-                A1 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)b1, 1.0, A1, 0, 0, 0);
-                A0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A0, 1.0, 0.0, 0, 0, 0);
-                A1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A1, 1.0, 0.0, 0, 0, 0);
                 if (act && lane == (row << 2)) acc[src] = make_double2(A0, A1);  // (every lane of the block holds the sums)
             }
             wave_lds_handover();
@@ -1875,7 +1987,9 @@ __global__ __launch_bounds__(rowk::NT, 5) void k_bpm_row(
                 a.x += (double)f0;
                 a.y += (double)f1;
                 const bool tneg = !dpos;
-                const bool neg0 = ((__float_as_uint(qq.y) >> 31) != 0) != tneg, neg1 = ((__float_as_uint(qq.z) >> 31) != 0) != tneg;
+                // (the exact mode's sums carry their signs: -(diff / dist) term by term)
+                const bool neg0 = EXACT || (((__float_as_uint(qq.y) >> 31) != 0) != tneg);
+                const bool neg1 = EXACT || (((__float_as_uint(qq.z) >> 31) != 0) != tneg);
                 const double t0 = (flags & 2) ? in0 + (neg0 ? a.x : -a.x) : 0.0;
                 const double t1 = (flags & 4) ? in1 + (neg1 ? a.y : -a.y) : 0.0;
                 const int tgt = hh.w, lpos = tgt & 0x0fffffff;
@@ -2097,28 +2211,29 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
 
 // k_bpm_row's band: the widest power of two of lines (<= one per wave) whose pixels fit its LDS regions (rowk::MAX_PX); 0: the
 // raster is too large for it (k_bpm_fast takes the launch)
-int row_band_config(int S, bool rgb, int B, size_t *lds_bytes)
+int row_band_config(int S, bool rgb, bool exact, int B, size_t *lds_bytes)
 {
     const size_t SP = ((size_t)S + 31) & ~(size_t)31;
     if (SP / rowk::SEG > (size_t)rowk::MAX_SEGS) return 0;
     for (int W = rowk::NW; W >= 1; W >>= 1) {
         if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::ROW_MIN_WGS) continue;  // (small launches: narrower bands until there are k6::ROW_MIN_WGS band workgroups; the waves of a workgroup then share the records of a line)
         if ((size_t)W * SP > (size_t)rowk::MAX_PX) continue;
-        *lds_bytes = rgb ? rowk::lds_bytes<true>() : rowk::lds_bytes<false>();
+        *lds_bytes = rgb ? (exact ? rowk::lds_bytes<true, true>() : rowk::lds_bytes<true, false>())
+                         : (exact ? rowk::lds_bytes<false, true>() : rowk::lds_bytes<false, false>());
         return W;
     }
     return 0;
 }
 
-template <bool RGB, bool ALPHA>
+template <bool RGB, bool ALPHA, int MODE>
 int launch_row(const int32_t *fi, const float *rgb, const float *alpha, const float *g_rgb, const float *g_alpha, double *scratch,
                const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap, int B,
                int F, int S, int W, size_t lds, double eps, hipStream_t st, void *zero_ptr, size_t zero_bytes)
 {
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
-    hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb, g_alpha,
-                       scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, B, (uint4 *)zero_ptr,
-                       zero_bytes / 16);
+    hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA, MODE>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb,
+                       g_alpha, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, eps, B,
+                       (uint4 *)zero_ptr, zero_bytes / 16);
     return 0;
 }
 
@@ -2133,20 +2248,21 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
 }
 
 // Which band kernel a call takes: the band width (lines per workgroup) of k_bpm_row and its LDS bytes, or 0 for k_bpm_fast.
-// The default arithmetic mode has ONE band kernel since round 6, k_bpm_row: it is ahead of k_bpm_fast on every shape measured
+// Both arithmetic modes have ONE band kernel since round 6, k_bpm_row: it is ahead of k_bpm_fast on every shape measured
 // (profiles/r06_k6_kernels.md: 8 ... 128 teapot views at 256^2, 64 views at rasters 320 ... 768, 32 and 4 views at 1024^2, 256
-// views at 128^2, 1024 at 32^2, configs 4 and 5), so nothing about the call's size enters the choice -- a batch and its shards
-// take the same kernel.  k_bpm_fast keeps what k_bpm_row does not do: the exact mode (NR_FLAG_EXACT_GRADIENT), the in-kernel
+// views at 128^2, 1024 at 32^2, configs 4 and 5; the exact mode: 64 views at 256^2 and 512^2), so nothing about the call's size
+// enters the choice -- a batch and its shards take the same kernel.  k_bpm_fast keeps what k_bpm_row does not do: the in-kernel
 // face scan (NR_FLAG_K6_SCAN, and the images of a call whose records exceed the line buffer: an overflow-only launch behind
-// k_bpm_row), rasters beyond k_bpm_row's LDS band (> 1024), eps = 0 (a lane outside a sweep multiplies 0 by 1 / (|c t| + eps),
-// and t = 0 -- the crossing point on a pixel centre -- would make that 0 * Inf), and NR_FLAG_K6_LEGACY (tests, measurements).
+// k_bpm_row), rasters beyond k_bpm_row's LDS band (> 1024), the default mode with eps = 0 (a lane outside a sweep multiplies 0
+// by 1 / (|c t| + eps), and t = 0 -- the crossing point on a pixel centre -- would make that 0 * Inf; the exact mode selects in
+// front of its division and takes any eps), and NR_FLAG_K6_LEGACY (tests, measurements).
 // With k_bpm_row the band tables and the line records are binned per LINE (band width 1).
 int k6_row_band(int B, int S, bool rgb, double eps, int flags, bool fast_fits, size_t *row_lds)
 {
     const bool exact = (flags & NR_FLAG_EXACT_GRADIENT) != 0;
-    const bool possible = !exact && !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY | NR_FLAG_K6_GLOBAL)) && B <= 65535 && fast_fits &&
-                          (float)eps >= 1e-30f;
-    return possible ? row_band_config(S, rgb, B, row_lds) : 0;
+    const bool possible = !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY | NR_FLAG_K6_GLOBAL)) && B <= 65535 && fast_fits &&
+                          (exact || (float)eps >= 1e-30f);
+    return possible ? row_band_config(S, rgb, exact, B, row_lds) : 0;
 }
 
 // Measurement hook (include/nr_hip_profile.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.  Only in the
@@ -2337,13 +2453,11 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         auto launch = [&](auto r, auto a, auto m, auto nt) {
             constexpr bool R = decltype(r)::value, A = decltype(a)::value;
             constexpr int M = decltype(m)::value, NTH = decltype(nt)::value;
-            if constexpr (M == K6_FAST) {
-                // (behind k_bpm_row: only the images whose records exceed the line buffer, by the scan path, no fill)
-                if (use_row)
-                    return launch_fast<R, A, M, NTH, true>(
-                        faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
-                        band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W_fast, lds, eps, k2s, win_lines, qcap, st, nullptr, 0);
-            }
+            // (behind k_bpm_row: only the images whose records exceed the line buffer, by the scan path, no fill)
+            if (use_row)
+                return launch_fast<R, A, M, NTH, true>(
+                    faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
+                    band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W_fast, lds, eps, k2s, win_lines, qcap, st, nullptr, 0);
             return launch_fast<R, A, M, NTH>(
                 faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, vis_list, vis_count, rng, scratch,
                 band_lines, band_start, lines_ok, line_buf, L.cap, B, F, S, W_fast, lds, eps, k2s, win_lines, qcap, st,
@@ -2363,10 +2477,15 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
         NR_BAND_TIMER_START(st);
         rc = 0;
         if (use_row) {
-            auto lp = [&](auto r, auto a) {
-                return launch_row<decltype(r)::value, decltype(a)::value>(
+            auto lpm = [&](auto r, auto a, auto m) {
+                return launch_row<decltype(r)::value, decltype(a)::value, decltype(m)::value>(
                     face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, scratch, band_lines, band_start, lines_ok,
                     line_buf, L.cap, B, F, S, W_row, row_lds, eps, st, zero_ok ? zero_ptr : nullptr, zero_ok ? zero_bytes : 0);
+            };
+            auto lp = [&](auto r, auto a) {
+                if (mode == K6_FAST) return lpm(r, a, std::integral_constant<int, K6_FAST>());
+                if (mode == K6_EXACT_POW2) return lpm(r, a, std::integral_constant<int, K6_EXACT_POW2>());
+                return lpm(r, a, std::integral_constant<int, K6_EXACT>());
             };
             rc = (rgb && alpha) ? lp(T(), T()) : (rgb ? lp(T(), N()) : lp(N(), T()));
             NR_BAND_TIMER_STOP(st);

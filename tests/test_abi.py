@@ -87,9 +87,9 @@ def test_host_only_entry_points(lib_path):
 
 
 def test_k6_band_kernel_choice_table(lib_path):
-    """Which band kernel a K6 call takes (k6_row_band, read through the measurement build: host logic, no device).  The default mode
-    has one band kernel since 0.6.0 -- k_bpm_row, ahead of k_bpm_fast on every shape of profiles/r06_k6_kernels.md --, so the call's
-    batch size must not enter: a batch and its shards take the same kernel (tests/test_full_size_gpu.py checks the results)."""
+    """Which band kernel a K6 call takes (k6_row_band, read through the measurement build: host logic, no device).  Both arithmetic
+    modes have one band kernel since 0.6.0 -- k_bpm_row, ahead of k_bpm_fast on every shape of profiles/r06_k6_kernels.md --, so the
+    call's batch size must not enter: a batch and its shards take the same kernel (tests/test_full_size_gpu.py checks the results)."""
     choice = _lib.load_profile().nr_profile_k6_choice
     ROW, FAST, T = 1, 0, 4928  # (teapot with fill_back)
     table = [
@@ -102,11 +102,12 @@ def test_k6_band_kernel_choice_table(lib_path):
         ((64, 10240, 256, 1, 0, 1e-3, 0), ROW),      # config 4
         ((1, 655360, 1024, 1, 1, 1e-3, 0), ROW),     # config 5
         ((1, T, 1056, 1, 1, 1e-3, 0), FAST), ((1, T, 2048, 1, 1, 1e-3, 0), FAST),   # beyond k_bpm_row's LDS band
-        ((64, T, 256, 0, 1, 0.0, 0), FAST),          # eps = 0: k_bpm_row needs a positive eps
-        ((64, T, 512, 1, 1, 1e-3, 2), FAST),         # NR_FLAG_EXACT_GRADIENT
-        ((64, T, 512, 1, 1, 1e-3, 8), FAST),         # NR_FLAG_K6_SCAN
-        ((64, T, 512, 1, 1, 1e-3, 128), FAST),       # NR_FLAG_K6_LEGACY
-        ((2, 40, 64, 1, 1, 1e-3, 65536), ROW), ((64, T, 512, 1, 1, 1e-3, 65536 | 2), FAST),  # NR_FLAG_K6_PX: ignored
+        ((64, T, 256, 0, 1, 0.0, 0), FAST),          # eps = 0: k_bpm_row's default arithmetic needs a positive eps ...
+        ((64, T, 256, 0, 1, 0.0, 2), ROW),           # ... its exact mode does not
+        ((64, T, 512, 1, 1, 1e-3, 2), ROW), ((8, T, 256, 1, 1, 1e-3, 2), ROW),   # NR_FLAG_EXACT_GRADIENT: the same kernel
+        ((64, T, 512, 1, 1, 1e-3, 8), FAST), ((64, T, 512, 1, 1, 1e-3, 8 | 2), FAST),  # NR_FLAG_K6_SCAN
+        ((64, T, 512, 1, 1, 1e-3, 128), FAST), ((64, T, 512, 1, 1, 1e-3, 128 | 2), FAST),  # NR_FLAG_K6_LEGACY
+        ((2, 40, 64, 1, 1, 1e-3, 65536), ROW), ((64, T, 512, 1, 1, 1e-3, 65536 | 2), ROW),  # NR_FLAG_K6_PX: ignored
     ]
     wrong = [(args, want, choice(*args)) for args, want in table if choice(*args) != want]
     assert not wrong, wrong

@@ -286,9 +286,9 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
             gf3, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                   use_face_inv_map=residual_maps, k6_flags=flags | K6_SCAN)
             assert H.rel_err(abi.host(gf3), gf) <= SAME_TERMS
-            # ... and the default mode's terms on the other band kernel (the call above ran k_bpm_row wherever its band fits;
+            # ... and the same mode on the other band kernel (the call above ran k_bpm_row wherever its band fits;
             # NR_FLAG_K6_LEGACY: k_bpm_fast): against the oracle and against k_bpm_row's
-            if not (flags & (EXACT | K6_GLOBAL | K6_SCAN | K6_LEGACY | K6_PX)):
+            if not (flags & (K6_GLOBAL | K6_SCAN | K6_LEGACY | K6_PX)):
                 for kflag, kname in ((K6_LEGACY, 'k_bpm_fast'),):
                     gf4, _ = abi.backward(fw, g_rgb, g_alpha, g_depth, use_sampling_maps=residual_maps,
                                           use_face_inv_map=residual_maps, k6_flags=flags | kflag)
@@ -302,7 +302,7 @@ def check_backward(faces, textures, S, eps, modes, seed, residual_maps=False, ts
                     # piece and forms sum (I - ref) g, k_bpm_row subtracts per pixel like the reference and forms the colour
                     # difference from centred sums: not the same terms in another order, so not SAME_TERMS; each kernel is
                     # within `bound` of the oracle)
-                    assert H.rel_err(gf4, gf) <= K6_BOUND_DEFAULT
+                    assert H.rel_err(gf4, gf) <= (K6_BOUND_EXACT if flags & EXACT else K6_BOUND_DEFAULT)
     if rgb:
         gt = abi.host(gt)
         assert not np.isnan(gt).any(), 'grad_textures has unwritten elements'
@@ -1269,7 +1269,7 @@ def test_band_kernel_timing_hook():
         t_fused = lib.nr_profile_band_kernel_ms()
         abi.backward(fw, g_rgb, g_alpha, None, k6_flags=EXACT)
         t_staged = lib.nr_profile_band_kernel_ms()
-        assert lib.nr_profile_band_kernel_which() == 0  # (the exact mode: k_bpm_fast)
+        assert lib.nr_profile_band_kernel_which() == 1  # (the exact mode: k_bpm_row as well)
         abi.backward(fw, g_rgb, g_alpha, None)  # (the default mode: k_bpm_row is bracketed as well, and named)
         t_px = lib.nr_profile_band_kernel_ms()
         assert lib.nr_profile_band_kernel_which() == 1
