@@ -2216,7 +2216,12 @@ int row_band_config(int S, bool rgb, bool exact, int B, size_t *lds_bytes)
     const size_t SP = ((size_t)S + 31) & ~(size_t)31;
     if (SP / rowk::SEG > (size_t)rowk::MAX_SEGS) return 0;
     for (int W = rowk::NW; W >= 1; W >>= 1) {
-        if (W > 1 && (size_t)B * 2 * ((S + W - 1) / W) < k6::ROW_MIN_WGS) continue;  // (small launches: narrower bands until there are k6::ROW_MIN_WGS band workgroups; the waves of a workgroup then share the records of a line)
+        // (small launches: narrower bands while there are few band workgroups -- the waves of a workgroup then share the windows of
+        // a line.  One-line bands stage single columns and most lines have one window, i.e. one busy wave: only below
+        // ROW_MIN_WGS_1 workgroups.  K6 stage, us, four- / two- / one-line bands: 4 views 46.3 (1) -> 45.4 (2); 8 views 62.8 (4),
+        // 59.3 (2), 61.8 (1); 16 views 79.9 (4), 75.6 (2), 86.0 (1); 8 views at 512^2 115.6 (2), 122.5 (1))
+        const size_t wgs = (size_t)B * 2 * ((S + W - 1) / W);
+        if ((W > 2 && wgs < k6::ROW_MIN_WGS) || (W == 2 && wgs < k6::ROW_MIN_WGS_1)) continue;
         if ((size_t)W * SP > (size_t)rowk::MAX_PX) continue;
         *lds_bytes = rgb ? (exact ? rowk::lds_bytes<true, true>() : rowk::lds_bytes<true, false>())
                          : (exact ? rowk::lds_bytes<false, true>() : rowk::lds_bytes<false, false>());

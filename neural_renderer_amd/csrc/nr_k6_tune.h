@@ -51,9 +51,13 @@
 #ifndef NR_K6_OVF_GRID      // workgroups of k_bpm_fast's overflow-only launch behind k_bpm_row (images whose records exceed the line buffer)
 #define NR_K6_OVF_GRID 1024
 #endif
-#ifndef NR_ROW_MIN_WGS      // k_bpm_row: bands are narrowed (4 -> 2 -> 1 lines) while the launch has fewer band workgroups than this
-#define NR_ROW_MIN_WGS 8192
+#ifndef NR_ROW_MIN_WGS      // k_bpm_row: four-line bands become two-line bands while the launch has fewer band workgroups than this ...
+#define NR_ROW_MIN_WGS 4096
 #endif
+#ifndef NR_ROW_MIN_WGS_1    // ... and two-line bands one-line bands below this many
+#define NR_ROW_MIN_WGS_1 1024
+#endif
+
 #ifndef NR_SHARED_LAUNCH_MAX_FACES  // fused backward: calls of up to this many faces (batch x faces) put the line setup and the
 #define NR_SHARED_LAUNCH_MAX_FACES 98304  // K7 / K8 gather into one launch (nr_backward_rasterize_lit; measured: LAB-NOTEBOOK, late round 4)
 #endif
@@ -73,7 +77,7 @@ constexpr int MINWAVES_256 = NR_K6_MINWAVES_256;
 constexpr int WMAX = NR_K6_WMAX;
 constexpr int FOLD_KB = NR_K6_FOLD_KB;
 constexpr unsigned long LDS_BUDGET = NR_K6_LDS_BUDGET;
-constexpr unsigned long ROW_MIN_WGS = NR_ROW_MIN_WGS;
+constexpr unsigned long ROW_MIN_WGS = NR_ROW_MIN_WGS, ROW_MIN_WGS_1 = NR_ROW_MIN_WGS_1;
 constexpr unsigned OVF_GRID = NR_K6_OVF_GRID;
 constexpr int WIDE_BUDGET_FROM = NR_K6_WIDE_BUDGET_FROM, WIDE_BUDGET_TO = NR_K6_WIDE_BUDGET_TO;
 constexpr unsigned long SHARED_LAUNCH_MAX_FACES = NR_SHARED_LAUNCH_MAX_FACES;
