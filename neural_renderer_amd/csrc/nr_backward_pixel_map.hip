@@ -1626,6 +1626,15 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
         float dist = MODE == K6_EXACT_POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
         return (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
     };
+    // The reciprocal of phase A's terms -- the in sweep and the out sweep's first pixel: the pixels next to the crossing point,
+    // whose terms are a record's largest -- with one Newton step: v_rcp_f32's 1 ulp becomes ~0.5.  A full ulp on the largest
+    // term of an entry that cancels down to the metric's floor (1e-3 of the largest gradient) reads as 2^-23 / 1e-3 = 1.2e-4:
+    // round 5's soak found such a scene at 1.13e-4.  Two fused multiply-adds per term of a lane-per-record loop: not measurable;
+    // on every visit of phase B they would be +25 % of the kernel's vector work.
+    auto recip_n = [](float y) {
+        const float r = __builtin_amdgcn_rcpf(y);
+        return __builtin_fmaf(__builtin_fmaf(-y, r, 1.0f), r, r);
+    };
     // sum_c (I_c - ref_c) g_c with the reference's operations in its order (:631-638 / :709-716)
     auto exact_diff = [&](const float4 &c4, const float4 &cr, const float4 &g4) {
         if constexpr (!RGB) return (c4.x - cr.x) * g4.x;
@@ -1701,8 +1710,8 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                 const float d = direct_diff(c_out, c_in, base + d1_out);                           // :631-638
                 const float dm = !(d <= 0.0f) ? d : 0.0f;                                           // :647
                 const float t = fabsf((float)d1_out - qq.x);
-                f0 = dm * __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(qq.y), t, eps_v));            // :649-651
-                f1 = dm * __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(qq.z), t, eps_v));            // :654-656
+                f0 = dm * recip_n(__builtin_fmaf(fabsf(qq.y), t, eps_v));                          // :649-651
+                f1 = dm * recip_n(__builtin_fmaf(fabsf(qq.z), t, eps_v));                          // :654-656
             }
             // segments of what phase B walks of the out sweep -- [o_from + 1, S) or [0, o_to - 1]: [from / 16, nsl) or [0, to / 16]
             const bool has_b = has_out && (EXACT || o_from < o_to);
@@ -1768,8 +1777,8 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                                 const float y1 = x1 + ((0.0f < x1) ? eps_v : -eps_v);
                                 const float dm = take ? diff : 0.0f;
                                 // (y is never 0 here: x and its eps have one sign, eps > 0 -- so 0 * (1 / y) adds nothing)
-                                b0 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y0), b0);              // :722
-                                b1 = __builtin_fmaf(-dm, __builtin_amdgcn_rcpf(y1), b1);              // :727
+                                b0 = __builtin_fmaf(-dm, recip_n(y0), b0);                            // :722
+                                b1 = __builtin_fmaf(-dm, recip_n(y1), b1);                            // :727
                             }
                         }
                     }
