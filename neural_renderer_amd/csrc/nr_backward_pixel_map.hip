@@ -1620,10 +1620,29 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
     asm volatile("" : "+v"(eps_v));
     // the exact mode's term: :649-651 / :654-656 (x * 2. / S: an exact float scaling when S is a power of two); ct = c * t
     const unsigned eps_hi = (unsigned)__double2hiint(eps_d), eps_lo = (unsigned)__double2loint(eps_d);
-    const double s_d = (double)S;
+    const double s_d = (double)S, two_over_s_d = 2.0 / (double)S;
     const float two_over_s_f = (float)(2.0 / (double)S);
+    // `x * 2. / S` of a float x, rounded to float, without the double division when S is not a power of two: the double product
+    // x * RN(2 / S) is within 2^-52 of the quotient, and so is the correctly rounded double quotient the reference's expression
+    // forms; the quotient itself is at least 2^-36 away (relative) from every point where the rounding to float changes -- such
+    // a point is M 2^f with M odd and of 25 bits, x = X 2^e with X below 2^24, S = 2^k s with s odd, >= 3 and below 2^11:
+    // X 2^e = M s 2^(f+k) is impossible (M s is odd and has 26 bits or more), and two different multiples of 2^f differ by 2^f
+    // at least, i.e. by 1 / (M S) > 2^-36 of the quotient -- so both doubles round to the same float.  The argument needs the
+    // float's full 24 bits: a result below the normal range takes the division (c is a ratio of differences of pixel coordinates
+    // and |t| a distance between them: such a product is 0 or far above 1e-38; the branch keeps the argument free of that).
+    // k_bpm_fast keeps the division everywhere; tests/test_hip_parity.py compares the two kernels' exact modes bit for bit.
+    auto exact_scale = [&](float ct) {
+        if constexpr (MODE == K6_EXACT_POW2) return ct * two_over_s_f;
+#ifdef NR_ROW_TRUE_DIV
+        return (float)((double)ct * 2.0 / s_d);
+#else
+        float q = (float)((double)ct * two_over_s_d);
+        if (__builtin_expect(!(fabsf(q) >= 1.17549435e-38f) && ct != 0.0f, 0)) q = (float)((double)ct * 2.0 / s_d);
+        return q;
+#endif
+    };
     auto exact_dist = [&](float ct) {
-        float dist = MODE == K6_EXACT_POW2 ? ct * two_over_s_f : (float)((double)ct * 2.0 / s_d);
+        const float dist = exact_scale(ct);
         return (float)((double)dist + signed_eps(dist, eps_hi, eps_lo));  // + eps when 0 < dist, - eps otherwise
     };
     // The reciprocal of phase A's terms -- the in sweep and the out sweep's first pixel: the pixels next to the crossing point,

@@ -14,10 +14,12 @@ SURVEY quirk Q1 under sharding: the reference samples textures with the vertex d
 (rasterize.py:389).  A shard's element 0 is not the global one, so a sharded run with per-view cameras and non-uniform
 textures (BASELINE configs 2 and 4) would differ from the unsharded run.  `broadcast_reference_faces` ships rank 0's
 first projected view to every rank once per step (F*36 bytes: 177 KB for the teapot); passed as `Rasterize.faces_z_ref` /
-`Renderer.faces_z_ref` / `rasterize(..., faces_z_ref=)` it makes sharded and unsharded images and texture gradients
-identical bit for bit and the vertex gradients identical up to what two calls of K6 on the same data differ by (default
-arithmetic: float run sums grouped by the order of atomics, <= 1.2e-5 of the largest gradient; NR_FLAG_EXACT_GRADIENT: the same
-bits; tests/test_sharding_gpu.py).  With fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) nothing needs to be exchanged.
+`Renderer.faces_z_ref` / `rasterize(..., faces_z_ref=)` it makes sharded and unsharded images, texture gradients AND vertex
+gradients identical bit for bit: every call size takes the same K6 band kernel (k_bpm_row), whose per-record sums do not depend
+on what else is in the launch (tests/test_sharding_gpu.py; at the metric's shape -- 64 views vs 2 x 32 vs 8 x 8 --
+tests/test_full_size_gpu.py::test_headline_batch_equals_its_shards.  With NR_FLAG_K6_LEGACY, k_bpm_fast's float run sums are
+grouped by the arrival order of its line records: <= 1.2e-5 of the largest gradient between two calls, sharded or not).  With
+fix_batch_z (NR_FIX_TEXTURE_BATCH_Z=1) nothing needs to be exchanged.
 """
 import os
 

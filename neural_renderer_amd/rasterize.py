@@ -40,8 +40,8 @@ FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 # term; the tests bound the deviation from the reference's terms summed exactly by the north star's 1e-4.  NR_EXACT_GRADIENT=1
 # (read once, here) or the `exact_gradient` attribute of a Rasterize instance: every term with the reference's own arithmetic,
 # sums in double (bound 2e-6).  Measured levels and costs of both: profiles/*_parity_summary.md.
-# Reproducibility: only the exact mode returns the same grad_faces bit for bit from call to call; the default mode's float
-# partial sums are grouped by the order its atomics arrive in (two calls on the same data: up to ~1.2e-5 of the largest gradient).
+# Reproducibility: both modes return the same grad_faces bit for bit from call to call, and for a batch and its shards (one band
+# kernel, k_bpm_row, whose per-record sums do not depend on the launch; profiles/r06_same_terms.txt).
 EXACT_GRADIENT = bool(int(os.environ.get('NR_EXACT_GRADIENT', '0')))
 # (measuring aid, read once: NR_SERIAL_BACKWARD=1 makes the fused backward launch K6's line setup, its band kernel and the gather one
 # after the other instead of the first and the last in one grid -- include/nr_hip.h NR_FLAG_SERIAL_BACKWARD; same values)

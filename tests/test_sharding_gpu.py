@@ -1,7 +1,7 @@
 """`-m gpu`: the batch-of-views sharding of the multi-GPU path is result-preserving under the reference-literal Q1 behaviour
 (textures are sampled with the vertex depths of batch element 0, rasterize.py:389): 8 views with per-view cameras and
 random textures rendered as one batch and as two shards of 4 -- each shard handed the global element 0's faces as
-`faces_z_ref` -- give identical bits for rgb and grad_textures and the same grad_faces up to the order of K6's double atomics.  Without the hand-over the second shard differs
+`faces_z_ref` -- give identical bits for rgb, grad_textures and grad_faces.  Without the hand-over the second shard differs
 (the test would notice a kernel that ignores the pointer), with fix_batch_z nothing needs to be handed over."""
 import numpy as np
 import pytest
@@ -32,16 +32,12 @@ def _run_abi(faces, textures, g_rgb, g_alpha, z_ref, flags=0):
 
 
 def _same(parts, full, names):
-    """Shards == batch: bit for bit for the images and grad_textures (atomic-free kernels); grad_faces consists of the same
-    per-pixel terms either way, but the default K6 arithmetic groups them into float run sums by the order of its atomics, which
-    is not fixed: two calls differ by up to 1.2e-5 of the largest gradient where a face's line sums cancel
-    (scripts/same_terms_probe.py), sharded or not: compared to 3e-5."""
+    """Shards == batch, bit for bit: images and grad_textures come from atomic-free kernels, and grad_faces from K6's k_bpm_row,
+    whose per-record sums do not depend on what else is in the launch (every record is reduced exactly once, in double above
+    the lanes' float sums; the double atomics that add a face's records round to the same float)."""
     for k, name in enumerate(names):
         got = np.concatenate((parts[0][k], parts[1][k]))
-        if name == 'grad_faces':
-            assert H.rel_err(got, full[k]) <= 3e-5, name
-        else:
-            np.testing.assert_array_equal(got, full[k], err_msg=name)
+        np.testing.assert_array_equal(got, full[k], err_msg=name)
 
 
 def test_two_shards_equal_one_batch_through_the_c_abi():
