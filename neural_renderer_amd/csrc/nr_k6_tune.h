@@ -48,9 +48,9 @@
 #ifndef NR_K6_WIDE_BUDGET_TO
 #define NR_K6_WIDE_BUDGET_TO 832
 #endif
-#ifndef NR_K6_OVF_GRID      // workgroups of k_bpm_fast's overflow-only launch behind k_bpm_row (images whose records exceed the line buffer)
-#define NR_K6_OVF_GRID 1024
-#endif
+#ifndef NR_K6_OVF_GRID      // workgroups of k_bpm_fast's overflow-only launch behind k_bpm_row (images whose records exceed the line buffer):
+#define NR_K6_OVF_GRID 256  // one per CU -- a launch whose workgroups leave at once costs 1.3 us up to 256 of them, 1.6 at 1024, 2.3 at
+#endif                      // 4096, 4.6 at 16 384 (scripts/dev/empty_launch_probe.hip); fused backward at the headline shape 214.4 -> 212.5 us
 #ifndef NR_ROW_MIN_WGS      // k_bpm_row: four-line bands become two-line bands while the launch has fewer band workgroups than this ...
 #define NR_ROW_MIN_WGS 4096
 #endif
