@@ -1422,21 +1422,27 @@ __device__ __forceinline__ void wave_lds_handover()
 #define NR_ROW_LDS_PAD 0
 #endif
 namespace rowk {
-constexpr int NT = 256, NW = NT / 64;
+#ifndef NR_ROW_NT  // (development: threads per workgroup of k_bpm_row -- 256, 128 or 64)
+#define NR_ROW_NT 256
+#endif
+constexpr int NT = NR_ROW_NT, NW = NT / 64;
 constexpr int WIN = 64;            // records per window (a lane each in phase A)
 constexpr int SEG = 16;            // pixels per step of a block
 constexpr int MAX_SEGS = 64;       // segments of a line, at most (raster <= 1024): the sort's keys
 constexpr int IN_SEG = 16;        // float terms per double addition of an in sweep (a piece of k_bpm_fast holds 15)
 constexpr int IN_BATCH = 4;       // pixels of an in sweep whose LDS reads are requested together
-constexpr int MAX_PX = 1024;       // pixels of a band, at most
-// LDS of a workgroup: gradients [W][SP][NC] | sums P [W][SP] (the exact mode: colours [W][SP][NC]) | face indices [W][SP] |
-// K of the band's lines (not in the exact mode) | a window per wave
-template <bool RGB> constexpr int g_bytes() { return RGB ? MAX_PX * 16 : MAX_PX * 4; }
-constexpr int P_BYTES = MAX_PX * 4, FI_BYTES = MAX_PX * 4, K_BYTES = NW * 16, WAVE_BYTES = WIN * 16;
-template <bool RGB, bool EXACT> constexpr int c_bytes() { return EXACT ? g_bytes<RGB>() : P_BYTES; }
-template <bool RGB, bool EXACT> constexpr size_t lds_bytes()
+#ifndef NR_ROW_MAX_PX  // (development)
+#define NR_ROW_MAX_PX 1024
+#endif
+constexpr int MAX_PX = NR_ROW_MAX_PX;       // pixels of a band, at most
+// LDS of a workgroup, for the npx = W * SP pixels of its band: gradients [W][SP][NC] | sums P [W][SP] (the exact mode: colours
+// [W][SP][NC]) | face indices [W][SP] | K of the band's lines (not in the exact mode) | a window per wave
+constexpr int K_BYTES = 4 * 16, WAVE_BYTES = WIN * 16;
+template <bool RGB> __host__ __device__ constexpr size_t g_bytes(size_t npx) { return npx * (RGB ? 16 : 4); }
+template <bool RGB, bool EXACT> __host__ __device__ constexpr size_t c_bytes(size_t npx) { return EXACT ? g_bytes<RGB>(npx) : npx * 4; }
+template <bool RGB, bool EXACT> __host__ __device__ constexpr size_t lds_bytes(size_t npx)
 {
-    return g_bytes<RGB>() + c_bytes<RGB, EXACT>() + FI_BYTES + (EXACT ? 0 : K_BYTES) + NW * WAVE_BYTES + NR_ROW_LDS_PAD;
+    return g_bytes<RGB>(npx) + c_bytes<RGB, EXACT>(npx) + npx * 4 + (EXACT ? 0 : K_BYTES) + NW * WAVE_BYTES + NR_ROW_LDS_PAD;
 }
 }  // namespace rowk
 
@@ -1487,15 +1493,14 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
     if (n_tot == 0) return;  // no visible face has a line here
 
     constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient array: (alpha, r, g, b) or alpha alone
-    constexpr int G_BYTES = g_bytes<RGB>();
     // a line in LDS: SP pixels, a multiple of 32 (an even number of segments); the pixels behind the raster hold zeros
     const int SP = (S + 31) & ~31, nsl = SP / SEG;
-    constexpr int C_BYTES = c_bytes<RGB, EXACT>();
+    const unsigned npx = (unsigned)(W * SP), G_BYTES = (unsigned)g_bytes<RGB>(npx), C_BYTES = (unsigned)c_bytes<RGB, EXACT>(npx), FI_BYTES = npx * 4u;
     float *const s_g = (float *)smem;                                  // [W][SP][NC] gradients
     float *const s_p = (float *)(smem + G_BYTES);                      // [W][SP] sum_c (I_c - K_c) g_c; exact mode: [W][SP][NC] colours
     int *const s_fi = (int *)(smem + G_BYTES + C_BYTES);               // [W][SP] face index
     float4 *const s_k = (float4 *)(smem + G_BYTES + C_BYTES + FI_BYTES);  // [W] K of each line: (alpha, r, g, b) (not in the exact mode)
-    unsigned char *wave_mem = smem + G_BYTES + C_BYTES + FI_BYTES + (EXACT ? 0 : K_BYTES) + (size_t)wave * WAVE_BYTES;
+    unsigned char *wave_mem = smem + G_BYTES + C_BYTES + FI_BYTES + (EXACT ? 0u : (unsigned)K_BYTES) + (unsigned)wave * WAVE_BYTES;
     double2 *acc = (double2 *)wave_mem;  // [WIN] a record's two out-sweep sums (magnitudes) ...
     int *hist = (int *)wave_mem;         // ... after the sort's counters are done with the same bytes
     const int n_parts = max(1, NW / W);  // (a band narrower than the workgroup has waves: they share the windows of a line)
@@ -2251,8 +2256,9 @@ int row_band_config(int S, bool rgb, bool exact, int B, size_t *lds_bytes)
         const size_t wgs = (size_t)B * 2 * ((S + W - 1) / W);
         if ((W > 2 && wgs < k6::ROW_MIN_WGS) || (W == 2 && wgs < k6::ROW_MIN_WGS_1)) continue;
         if ((size_t)W * SP > (size_t)rowk::MAX_PX) continue;
-        *lds_bytes = rgb ? (exact ? rowk::lds_bytes<true, true>() : rowk::lds_bytes<true, false>())
-                         : (exact ? rowk::lds_bytes<false, true>() : rowk::lds_bytes<false, false>());
+        const size_t npx = (size_t)W * SP;
+        *lds_bytes = rgb ? (exact ? rowk::lds_bytes<true, true>(npx) : rowk::lds_bytes<true, false>(npx))
+                         : (exact ? rowk::lds_bytes<false, true>(npx) : rowk::lds_bytes<false, false>(npx));
         return W;
     }
     return 0;

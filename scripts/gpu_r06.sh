@@ -6,7 +6,8 @@
 #   TESTS=1     every GPU test file (scripts/gpu_tests.sh)
 #   VARIANTS="r03 x"  stage timings of libnr_hip_<tag>.so next to the product library, STAGE_FLAGS="2 8" with k6 flags
 #   SHARDS="32 16 8"  stage timings + kernel trace + host enqueue time at these batch sizes
-#   BENCH=1 / KSTATS=1 / PMC=1 / CONFIGS=1 / STEPSEQ=1   as scripts/gpu_session.sh
+#   BENCH=1 / KSTATS=1 / PMC=1 / CONFIGS=1 / STEPSEQ=1   as scripts/gpu_session.sh (BENCH runs behind PMC and reads its counter file)
+#   K6AB=1 / SCALE=1   the band kernels side by side; the scaling sweep at 1 and 2 ranks on the one GPU
 TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -52,17 +53,6 @@ done
 [ -f $OUT/shards.log ] && cat $OUT/shards.log
 if [ -n "$HOSTPROF" ]; then
   for b in $HOSTPROF; do B=$b timeout 300 python scripts/host_profile.py 300 > $OUT/host_profile_B$b.txt 2>&1; head -50 $OUT/host_profile_B$b.txt; done
-fi
-if [ -n "$BENCH" ]; then timeout 900 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err; python - <<PY
-import json
-try:
-    d = json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
-    print('value', round(d['value'], 1), 'ms', round(d['ms_per_step'], 4), {k: round(v, 1) for k, v in d['stages_us'].items()})
-    for k in ('grad_check', 'roofline', 'extra_rows', 'shard_rows', 'renderer_end_to_end', 'timing'):
-        print(k, json.dumps(d.get(k))[:1500])
-except Exception as e:
-    print('bench parse failed', e); print(open('$OUT/bench.err').read()[-3000:])
-PY
 fi
 if [ -n "$CONFIGS" ]; then
   ONLY=${CONFIGS_ONLY} timeout 900 python scripts/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
@@ -125,5 +115,23 @@ if [ -n "$S512" ]; then
   python scripts/pmc_traffic.py $OUT/fetch512_results.db $OUT/write512_results.db $OUT/pmc_hbm_traffic_S512.json > $OUT/traffic_S512.log 2>&1
   cat $OUT/traffic_S512.log | head -30
 fi
+# (after the counter passes: the session's own counter file becomes profiles/pmc_latest.json of the box's tree, stamped with the tree's
+# source hash, so that this bench line carries `roofline.traffic` of the very build it timed)
+if [ -n "$BENCH" ]; then [ -f $OUT/pmc_hbm_traffic.json ] && cp $OUT/pmc_hbm_traffic.json profiles/pmc_latest.json; timeout 900 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err; python - <<PY
+import json
+try:
+    d = json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
+    print('value', round(d['value'], 1), 'ms', round(d['ms_per_step'], 4), {k: round(v, 1) for k, v in d['stages_us'].items()})
+    for k in ('grad_check', 'roofline', 'extra_rows', 'shard_rows', 'renderer_end_to_end', 'timing'):
+        print(k, json.dumps(d.get(k))[:1500])
+except Exception as e:
+    print('bench parse failed', e); print(open('$OUT/bench.err').read()[-3000:])
+PY
+fi
+# K6AB=1: k_bpm_row against k_bpm_fast, both modes: whole steps on every configuration + stage calls over a sweep of shapes
+# (scripts/gpu_k6_ab.sh -> profiles/r06_k6_kernels.md through scripts/k6_kernels_md.py)
+if [ -n "$K6AB" ]; then TAG=$TAG/k6ab bash scripts/gpu_k6_ab.sh > $OUT/k6ab.log 2>&1; tail -5 $OUT/k6ab.log; fi
+# SCALE=1: the turnkey scaling sweep at the rank counts one GPU allows (control-path record: scripts/scale_sweep.sh)
+if [ -n "$SCALE" ]; then GPUS="1 2" ONE_GPU=1 timeout 1500 bash scripts/scale_sweep.sh $OUT/scale > $OUT/scale_sweep.log 2>&1; grep "^|" $OUT/scale_sweep.log > $OUT/scale_sweep_table.md; cat $OUT/scale_sweep_table.md; fi
 if [ -n "$SAMETERMS" ]; then timeout 600 python scripts/same_terms_probe.py > $OUT/same_terms.txt 2>&1; tail -12 $OUT/same_terms.txt; fi
 rm -f $OUT/*_results.db
