@@ -677,6 +677,28 @@ def csrc_tree_hash():
     return h.hexdigest()[:16]
 
 
+def raster_512_kernel_traffic(kernel):
+    """HBM bytes per launch of the K6 band kernel at raster 512 (the anti-aliasing row) from the newest committed counter file
+    of that shape, profiles/r*_pmc_hbm_traffic_S512.json -- (bytes, file), or (None, why) when there is none or it was collected
+    on other sources than this tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic_S512.json')))
+    if not files or not kernel:
+        return None, 'no counter file of this shape'
+    rel = 'profiles/' + os.path.basename(files[-1])
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f)
+    except Exception:
+        return None, rel + ' unreadable'
+    if (rec.get('_build') or {}).get('csrc_sha1') != csrc_tree_hash():
+        return None, rel + ' was collected on other sources than this tree'
+    for name, v in rec.get('backward_pixel_map', {}).get('kernels', {}).items():
+        if name.startswith(kernel):
+            return v['fetch'] + v['write'], rel
+    return None, rel + ' holds no ' + kernel
+
+
 def profile_records():
     """Counter-derived figures of the committed profiles (they cannot be collected inside a timed run): HBM traffic of the
     dominant stage and the VALU instruction count of the K6 kernel.  Labelled with their source file.  The file carries the hash
@@ -993,18 +1015,20 @@ def main():
             sb2 = algorithmic_bytes(B, F, 2 * S, ts)['backward_pixel_map']
             k2_us = st2.get('k6_band_kernel_alone') or st2['backward_pixel_map']
             wb2 = whole_step_bytes(B, F, 2 * S, ts)
+            kname2 = k6_band_kernel(B, F, 2 * S, True, True, args.exact)
+            tr2, tr2_src = raster_512_kernel_traffic(kname2) if (B, S, ts) == (64, 256, 2) else (None, 'not the profiled shape')
             extra_rows.append({'row': 'anti_aliasing on: raster %dx%d for image_size %d' % (2 * S, 2 * S, S), 'ms_per_step': ms2,
                                'mpixel_per_s_raster': B * 4 * S * S / (ms2 * 1e-3) / 1e6,
                                'mpixel_per_s_image': B * S * S / (ms2 * 1e-3) / 1e6,
                                'roofline': {'bound': 'hbm', 'stage': 'backward_pixel_map',
-                                            'kernel': k6_band_kernel(B, F, 2 * S, True, True, args.exact), 'avg_launch_us': k2_us,
+                                            'kernel': kname2, 'avg_launch_us': k2_us,
                                             'algorithmic_bytes_per_launch': sb2, 'achieved': sb2 / (k2_us * 1e-6) / 1e9,
                                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': sb2 / (k2_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                             'stage_call_us': st2['backward_pixel_map'],
                                             'whole_step': {'algorithmic_bytes': wb2, 'achieved': wb2 / (ms2 * 1e-3) / 1e9,
                                                            'frac': wb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                                            'traffic': None,
-                                            'traffic_note': 'counter passes of this shape: profiles/r05_pmc_hbm_traffic_S512.json'}})
+                                            'traffic': tr2, 'traffic_ratio': (tr2 / sb2) if tr2 else None,
+                                            'traffic_note': 'the band kernel alone, counter passes of this shape: ' + tr2_src}})
             del faces2, tex2, g2
             ones = upstream_gradients(faces, textures, S, eps, 0, all_ones=True)
             ms3 = time_step(make_step(faces, textures, S, ones), dev, args.steps, 2)

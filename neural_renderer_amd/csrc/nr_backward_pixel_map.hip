@@ -1455,6 +1455,18 @@ NR_API int nr_dev_row_stats(unsigned long long *out8)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_row_stats), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
 #define NR_ROW_STAT(i, v) do { if (lane == 0) atomicAdd(&g_row_stats[i], (unsigned long long)(v)); } while (0)
+// (the records of the first NR_ROW_DUMP_WINDOWS windows -- segments of the out sweep | direction << 8 | has an out sweep << 9 |
+// valid << 10 -- for studies of the grouping on the host: scripts/row_groupings.py)
+constexpr unsigned NR_ROW_DUMP_WINDOWS = 1u << 16;
+__device__ unsigned g_row_dump_n;
+__device__ unsigned g_row_dump[NR_ROW_DUMP_WINDOWS * 64];
+NR_API int nr_dev_row_dump(unsigned *out, unsigned *n_windows)
+{
+    if (hipMemcpyFromSymbol(n_windows, HIP_SYMBOL(g_row_dump_n), sizeof(unsigned)) != hipSuccess) return 1;
+    const unsigned n = *n_windows < NR_ROW_DUMP_WINDOWS ? *n_windows : NR_ROW_DUMP_WINDOWS, zero = 0;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_dump), (size_t)n * 64 * sizeof(unsigned)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_row_dump_n), &zero, sizeof(unsigned)) == hipSuccess ? 0 : 1;
+}
 #else
 #define NR_ROW_STAT(i, v) ((void)0)
 #endif
@@ -1832,6 +1844,13 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
             NR_ROW_STAT(1, nw);       // records
             NR_ROW_STAT(2, n_out);    // records with an out sweep
 #ifdef NR_ROW_STATS
+            {
+                unsigned wid = 0;
+                if (lane == 0) wid = atomicAdd(&g_row_dump_n, 1u);
+                wid = (unsigned)__builtin_amdgcn_readfirstlane((int)wid);
+                if (wid < NR_ROW_DUMP_WINDOWS)
+                    g_row_dump[(size_t)wid * 64 + lane] = lane < nw ? ((unsigned)nseg | (dpos ? 256u : 0u) | (has_b ? 512u : 0u) | 1024u) : 0u;
+            }
             {
                 int sn = nseg, si = has_b ? (o_to - o_from) : 0;
                 for (int o = 32; o > 0; o >>= 1) { sn += __shfl_xor(sn, o, WAVE); si += __shfl_xor(si, o, WAVE); }
@@ -2233,8 +2252,10 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
     if (int rc = limit.ensure((const void *)kern, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     // 1-D grid: the kernel maps ids to (image, axis, band) per XCD
-    // (overflow-only launch behind k_bpm_row: a resident grid that strides over the bands.  1024 workgroups: with nothing to do
-    // it costs ~4 us (256: ~3), with every image over the line buffer -- 32 teapot views at 1024^2 -- 5.0 instead of 7.3 ms)
+    // (overflow-only launch behind k_bpm_row: a resident grid that strides over the bands, k6::OVF_GRID workgroups.  With nothing
+    // to do it costs 4.6 us in a step whatever the grid -- a launch (1.3 us for up to 256 workgroups that leave at once,
+    // scripts/dev/empty_launch_probe.hip) and one dependent load of the images' verdicts from memory the line setup wrote with
+    // atomics; with every image over the line buffer -- 32 teapot views at 1024^2 -- 1024 workgroups took 5.0 ms against 7.3 at 256)
     const unsigned grid = overflow_only ? (total_wg < k6::OVF_GRID ? total_wg : k6::OVF_GRID) : xcd_grid(total_wg);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, faces, fi, rgb, alpha, g_rgb, g_alpha,
                        vis_list, vis_count, rng, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, S + 4,
@@ -2269,6 +2290,8 @@ int launch_row(const int32_t *fi, const float *rgb, const float *alpha, const fl
                const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap, int B,
                int F, int S, int W, size_t lds, double eps, hipStream_t st, void *zero_ptr, size_t zero_bytes)
 {
+    static LdsLimit limit;  // one per instantiation (40 KB at most with the product's constants: never raised)
+    if (int rc = limit.ensure((const void *)k_bpm_row<RGB, ALPHA, MODE>, lds)) return rc;
     const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
     hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA, MODE>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb,
                        g_alpha, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, eps, B,
