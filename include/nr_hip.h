@@ -79,14 +79,18 @@ extern "C" {
 #define NR_FLAG_EXACT_GRADIENT 2      /* K6: every per-pixel term with the reference's arithmetic (its operations one by one, IEEE
                                          division, the double `dist +- eps`), all sums in double: bit-identical terms, bound 2e-6
                                          against the exactly summed reference terms.  Default (flag clear): float terms through
-                                         fused multiply-adds and v_rcp_f32, ~1 ulp per term, bound 1e-4 (the north star's
-                                         tolerance).  Same sweep structure either way; what the modes cost and measure:
+                                         fused multiply-adds and v_rcp_f32, ~1 ulp per term: within the north star's 1e-4 of the
+                                         exactly summed reference terms (measured <= 5e-5 on the BASELINE configurations) -- plus,
+                                         on entries that cancel down to 1e-3 of the largest gradient, where one ulp of a large
+                                         term counts as 1.2e-4, twice the reference's own float-summation noise (worst scene of a
+                                         soak built to cancel: 1.8e-4 where the reference's own sums are 7e-4 off).  Same sweep
+                                         structure either way; what the modes cost and measure:
                                          profiles/<round>_parity_summary.md, DESIGN.md 3.
-                                         REPRODUCIBILITY: only this flag gives run-to-run identical grad_faces.  The default mode
-                                         adds float partial sums in the order its atomics arrive: two calls on the same data
-                                         differ by up to ~1.2e-5 of the largest gradient (sharded vs unsharded batches and fused vs
-                                         staged calls included); the exact mode sums in double throughout (<= 1e-6, bit-identical
-                                         in every pair measured). */
+                                         REPRODUCIBILITY (since 0.6.0): both modes return the same grad_faces bits from call to
+                                         call, for a batch and its shards, and for fused and staged calls wherever k_bpm_row runs
+                                         (raster <= 1024): a record's sums have a fixed order and everything above is added in
+                                         double.  NR_FLAG_K6_LEGACY / the scan path in the default mode (k_bpm_fast: float run sums
+                                         grouped by arrival) agree to ~1.2e-5 of the largest gradient between two calls. */
 #define NR_FLAG_K6_GLOBAL 4           /* K6: force the global-memory kernel that otherwise only serves rasters whose band
                                          does not fit in LDS (a testing aid) */
 #define NR_FLAG_K6_SCAN 8             /* K6: let every band workgroup derive its lines from the image's visible-face list

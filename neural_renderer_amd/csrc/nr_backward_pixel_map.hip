@@ -1751,6 +1751,31 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
             }
             // segments of what phase B walks of the out sweep -- [o_from + 1, S) or [0, o_to - 1]: [from / 16, nsl) or [0, to / 16]
             const bool has_b = has_out && (EXACT || o_from < o_to);
+            if constexpr (!EXACT) {
+                // Phase B tells the out pixel from the rest of the sweep by |t| <= 1 -- exact for every pixel but one: with the
+                // crossing point within half an ulp of the in pixel's centre (a vertex snapped onto a pixel centre, the cross
+                // product a rounding below it) the SECOND pixel's |t| = 1 + 2^-24 rounds to 1 and phase B leaves it out as well.
+                // It is taken here, by the same comparison on the same float, with the centred sums phase B would have used
+                // (tests/test_fuzz_gpu.py, seed 118: the term of such a pixel was missing, 27 % of a corner face's gradient).
+                const int d1_2 = d1_out + (dpos ? 1 : -1);
+                const float t2 = fabsf((float)d1_2 - qq.x);
+                if (has_b && t2 <= 1.0f) {
+                    const int l = base + d1_2;
+                    float4 g4;
+                    if constexpr (RGB) g4 = lds_px4(s_g + 4 * (size_t)l);
+                    else g4 = make_float4(s_g[l], 0.0f, 0.0f, 0.0f);
+                    float d = s_p[l];
+                    if constexpr (!RGB || ALPHA) d = __builtin_fmaf(-oref.x, g4.x, d);
+                    if constexpr (RGB) {
+                        d = __builtin_fmaf(-oref.y, g4.y, d);
+                        d = __builtin_fmaf(-oref.z, g4.z, d);
+                        d = __builtin_fmaf(-oref.w, g4.w, d);
+                    }
+                    const float dm = !(d <= 0.0f) ? d : 0.0f;
+                    f0 = __builtin_fmaf(dm, recip_n(__builtin_fmaf(fabsf(qq.y), t2, eps_v)), f0);
+                    f1 = __builtin_fmaf(dm, recip_n(__builtin_fmaf(fabsf(qq.z), t2, eps_v)), f1);
+                }
+            }
             const int b_from = o_from + (EXACT ? 0 : 1), b_to = o_to - (EXACT ? 0 : 1);
             const int nseg = has_b ? (dpos ? nsl - (b_from >> 4) : (b_to >> 4) + 1) : 0;
             hist[lane] = 0;

@@ -37,7 +37,8 @@ if 'NEURAL_RENDERER_UNSAFE' in os.environ and int(os.environ['NEURAL_RENDERER_UN
 FIX_TEXTURE_BATCH_Z = bool(int(os.environ.get('NR_FIX_TEXTURE_BATCH_Z', '0')))
 
 # K6 (backward_pixel_map) numerics.  Default: float terms through fused multiply-adds and the hardware reciprocal, ~1 ulp per
-# term; the tests bound the deviation from the reference's terms summed exactly by the north star's 1e-4.  NR_EXACT_GRADIENT=1
+# term; the tests bound the deviation from the reference's terms summed exactly by the north star's 1e-4 (plus twice the reference's
+# own float-summation noise on entries that cancel down to the metric's floor: include/nr_hip.h).  NR_EXACT_GRADIENT=1
 # (read once, here) or the `exact_gradient` attribute of a Rasterize instance: every term with the reference's own arithmetic,
 # sums in double (bound 2e-6).  Measured levels and costs of both: profiles/*_parity_summary.md.
 # Reproducibility: both modes return the same grad_faces bit for bit from call to call, and for a batch and its shards (one band

@@ -115,9 +115,14 @@ if [ -n "$S512" ]; then
   python scripts/pmc_traffic.py $OUT/fetch512_results.db $OUT/write512_results.db $OUT/pmc_hbm_traffic_S512.json > $OUT/traffic_S512.log 2>&1
   cat $OUT/traffic_S512.log | head -30
 fi
-# (after the counter passes: the session's own counter file becomes profiles/pmc_latest.json of the box's tree, stamped with the tree's
+# K6AB=1: k_bpm_row against k_bpm_fast, both modes: whole steps on every configuration + stage calls over a sweep of shapes
+# (scripts/gpu_k6_ab.sh -> profiles/r06_k6_kernels.md through scripts/k6_kernels_md.py)
+if [ -n "$K6AB" ]; then TAG=$TAG/k6ab bash scripts/gpu_k6_ab.sh > $OUT/k6ab.log 2>&1; tail -5 $OUT/k6ab.log; fi
+# SCALE=1: the turnkey scaling sweep at the rank counts one GPU allows (control-path record: scripts/scale_sweep.sh)
+if [ -n "$SCALE" ]; then GPUS="1 2" ONE_GPU=1 timeout 1500 bash scripts/scale_sweep.sh $OUT/scale > $OUT/scale_sweep.log 2>&1; grep "^|" $OUT/scale_sweep.log > $OUT/scale_sweep_table.md; cat $OUT/scale_sweep_table.md; fi
+# (after the counter passes, raster 512's included: the session's own counter file becomes profiles/pmc_latest.json of the box's tree, stamped with the tree's
 # source hash, so that this bench line carries `roofline.traffic` of the very build it timed)
-if [ -n "$BENCH" ]; then [ -f $OUT/pmc_hbm_traffic.json ] && cp $OUT/pmc_hbm_traffic.json profiles/pmc_latest.json; timeout 900 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err; python - <<PY
+if [ -n "$BENCH" ]; then [ -f $OUT/pmc_hbm_traffic.json ] && cp $OUT/pmc_hbm_traffic.json profiles/pmc_latest.json; [ -f $OUT/pmc_hbm_traffic_S512.json ] && cp $OUT/pmc_hbm_traffic_S512.json profiles/${TAG%%_*}_pmc_hbm_traffic_S512.json; timeout 900 python bench.py ${BENCH_ARGS} > $OUT/bench.json 2> $OUT/bench.err; python - <<PY
 import json
 try:
     d = json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])
@@ -128,10 +133,5 @@ except Exception as e:
     print('bench parse failed', e); print(open('$OUT/bench.err').read()[-3000:])
 PY
 fi
-# K6AB=1: k_bpm_row against k_bpm_fast, both modes: whole steps on every configuration + stage calls over a sweep of shapes
-# (scripts/gpu_k6_ab.sh -> profiles/r06_k6_kernels.md through scripts/k6_kernels_md.py)
-if [ -n "$K6AB" ]; then TAG=$TAG/k6ab bash scripts/gpu_k6_ab.sh > $OUT/k6ab.log 2>&1; tail -5 $OUT/k6ab.log; fi
-# SCALE=1: the turnkey scaling sweep at the rank counts one GPU allows (control-path record: scripts/scale_sweep.sh)
-if [ -n "$SCALE" ]; then GPUS="1 2" ONE_GPU=1 timeout 1500 bash scripts/scale_sweep.sh $OUT/scale > $OUT/scale_sweep.log 2>&1; grep "^|" $OUT/scale_sweep.log > $OUT/scale_sweep_table.md; cat $OUT/scale_sweep_table.md; fi
 if [ -n "$SAMETERMS" ]; then timeout 600 python scripts/same_terms_probe.py > $OUT/same_terms.txt 2>&1; tail -12 $OUT/same_terms.txt; fi
 rm -f $OUT/*_results.db
