@@ -12,7 +12,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-# (a soak run: NR_FUZZ_EXTRA_SEEDS="4 5 6 ..." adds seeds to the first and the last test below; the suite itself runs the fixed ones)
+# (a soak run: NR_FUZZ_EXTRA_SEEDS="4 5 6 ..." adds seeds to the parameter, dense-scene and error-level tests below; the suite itself runs the fixed ones)
 import os
 EXTRA_SEEDS = [int(x) for x in os.environ.get('NR_FUZZ_EXTRA_SEEDS', '').split()]
 
@@ -70,6 +70,19 @@ def test_fuzz_unusual_parameters(seed):
         okn = np.isfinite(ref_gf) & np.isfinite(ref_f)
         noise = H.rel_err(ref_f[okn], ref_gf[okn]) if okn.any() else 0.0
         b_default, b_exact = 1e-4 + 2 * noise, 2e-5 + 2 * noise
+        # grad_faces = K6's sums + K8's (the depth gradient's), and the two can cancel: the default mode's ~1e-6 of a K6 sum of 8
+        # is 4e-4 of a total that cancels to the metric's floor (seed 171, scene 47: 4.3e-4 by helpers.rel_err with the exact
+        # mode at 0 and K6 alone at 1.6e-6).  The default-mode runs are therefore measured against the larger of the total and
+        # its K6 part, element by element, with the floor at 1e-3 of the larger maximum; the exact mode keeps the plain metric.
+        ref_k6 = fn.backward(g[0], g[1], np.zeros_like(g[2]), accumulate_double=True)[0]
+
+        def err_default(a, ok):
+            okk = ok & np.isfinite(ref_k6)
+            if not okk.any():
+                return 0.0
+            mag = np.maximum(np.abs(ref_gf[okk]), np.abs(ref_k6[okk]))
+            den = np.maximum(mag, 1e-3 * mag.max())
+            return float((np.abs(a[okk] - ref_gf[okk]) / np.where(den > 0, den, 1.0)).max())
         for name, run, bound in (('backward', abi.backward, b_default), ('backward_fused', abi.backward_fused, b_default),
                                  ('backward_legacy', lambda *a: abi.backward(*a, k6_flags=128), b_default),
                                  ('backward_fused_legacy', lambda *a: abi.backward_fused(*a, k6_flags=128), b_default),
@@ -80,8 +93,9 @@ def test_fuzz_unusual_parameters(seed):
             if not np.array_equal(np.isnan(gf), np.isnan(ref_gf)) or not np.array_equal(np.isnan(gt), np.isnan(ref_gt)):
                 msg.append(name + ': NaN pattern')
             ok = np.isfinite(ref_gf) & np.isfinite(gf)
-            if ok.any() and H.rel_err(gf[ok], ref_gf[ok]) > bound:
-                msg.append('%s: grad_faces %.2e (bound %.2e, reference noise %.2e)' % (name, H.rel_err(gf[ok], ref_gf[ok]), bound, noise))
+            e_gf = (H.rel_err(gf[ok], ref_gf[ok]) if name.endswith('exact') else err_default(gf, ok)) if ok.any() else 0.0
+            if e_gf > bound:
+                msg.append('%s: grad_faces %.2e (bound %.2e, reference noise %.2e)' % (name, e_gf, bound, noise))
             ok = np.isfinite(ref_gt) & np.isfinite(gt)
             if ok.any() and H.rel_err(gt[ok], ref_gt[ok]) > 1e-4:
                 msg.append('%s: grad_textures %.2e' % (name, H.rel_err(gt[ok], ref_gt[ok])))
@@ -90,7 +104,7 @@ def test_fuzz_unusual_parameters(seed):
     assert not failures, failures
 
 
-@pytest.mark.parametrize('seed', [11, 12])
+@pytest.mark.parametrize('seed', [11, 12] + [1000 + x for x in EXTRA_SEEDS])
 def test_fuzz_dense_scenes(seed):
     """Larger random scenes (up to 3000 faces, raster sizes up to 256 incl. non-powers of two, random output modes): several
     scan passes and line windows per band, accumulator-slot overflow, the large-face queue of the forward."""
