@@ -62,8 +62,9 @@ def test_fuzz_unusual_parameters(seed):
         # down to the floor reads as 2^-23 / 1e-3 = 1.2e-4.  k_bpm_row refines the reciprocals of the two pixels next to the
         # crossing point (a record's largest terms) with a Newton step, which took round 5's soak maximum (seed 6, scene 59:
         # 1.13e-4) to 7e-5 and kept 48 scenes x 60 below 1e-4 -- 100 more seeds then found 1.8e-4 in a scene built to cancel
-        # (test_fuzz_default_k6_error_levels, seed 185; k_bpm_fast 1.5e-4): the second, third ... pixel of a sweep carry 1 / 2,
-        # 1 / 3 ... of that ulp.  On such entries the reference's own sums differ from run to run (float atomics) by more.
+        # (test_fuzz_default_k6_error_levels, seed 185; k_bpm_fast 1.5e-4), which neither a Newton step on every reciprocal nor
+        # double sums in every lane move (LAB-NOTEBOOK, round 6): the terms themselves differ from the reference's by ~1 ulp
+        # (another order of roundings).  On such entries the reference's own sums differ from run to run (float atomics) by more.
         # NR_FLAG_EXACT_GRADIENT: K6's terms are the reference's bit for bit and summed in double (2e-6 on K6 alone:
         # test_hip_parity.py); with a depth gradient K8's float partial sums come on top -- 2e-5 plus the same allowance.
         ref_f, _ = fn.backward(*g)
