@@ -1391,8 +1391,8 @@ __device__ __forceinline__ void wave_lds_handover()
 //     td = direction * (d1 - d1_cross), a value the visit needs anyway: no range arithmetic, and a block may start segments
 //     before its sweep or run on behind it -- those lanes are masked by the same comparison;
 //   * the records of a window (64: a lane each in phase A) are SORTED by their number of segments (a counting sort in LDS) and
-//     dealt to the blocks four at a time: the blocks of a group walk (nearly) the same number of steps (lane efficiency 0.84 at
-//     raster 256, 0.90 at 512: scripts/row_stats.py), so the group is one loop with a uniform trip count and ONE reduction for
+//     dealt to the blocks four at a time: the blocks of a group walk (nearly) the same number of steps (lane efficiency 0.89 at
+//     raster 256, 0.92 at 512: scripts/row_stats.py), so the group is one loop with a uniform trip count and ONE reduction for
 //     four records;
 //   * that reduction is the matrix pipe's: a block is the 16 lanes of one block of v_mfma_f64_4x4x4_4b_f64 -- lanes
 //     4 b .. 4 b + 3 of each of the wave's four rows -- and two of these instructions with a matrix of ones add up a block's 16
@@ -1917,10 +1917,10 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                 if (!act) ncd = -__builtin_inff();
                 const float sdir = EXACT ? (r_nseg_s < 0 ? -1.0f : 1.0f)
                                          : __uint_as_float(0x3f800000u | (__float_as_uint(ac0s) & 0x80000000u));
-                // the group walks as many steps as its longest sweep has segments (the first block's: the order of the sort), an
-                // even number; a sweep towards the end of the line ENDS with the group's last step, one from pixel 0 starts with its
-                // first; pixels in front of a sweep or behind it are masked (td <= 0)
-                const int steps = __builtin_amdgcn_readfirstlane(r_nseg), steps2 = (steps + 1) & ~1;
+                // the group walks as many steps as its longest sweep has segments (the first block's: the order of the sort; the exact
+                // mode, which walks in pairs, an even number of them); a sweep towards the end of the line ENDS with the group's last
+                // step, one from pixel 0 starts with its first; pixels in front of a sweep or behind it are masked (td <= 0)
+                const int steps = __builtin_amdgcn_readfirstlane(r_nseg), steps2 = EXACT ? (steps + 1) & ~1 : steps;
                 NR_ROW_STAT(5, 1);       // groups
                 NR_ROW_STAT(6, steps2);  // steps walked
                 const bool rpos = EXACT ? r_nseg_s >= 0 : !(__float_as_uint(ac0s) >> 31);
@@ -2001,9 +2001,11 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                         if constexpr (RGB && !ALPHA) asm volatile("" : : "v"(g4.x));
                     };
                     // A lane adds the terms of its even and of its odd segments in float (<= 8 terms each at raster 256, 32 at 1024: the
-                    // terms fall off like 1 / t); everything above is double: the matrix pipe adds the 2 x 16 sums of a block.  seg0 is
-                    // even, so which of a sweep's terms share a float sum does not depend on the other records of its group: a record's
-                    // sums are the same bits whatever window, group or launch it is part of.  (Chains cut every 16 / 8 / 4 steps,
+                    // terms fall off like 1 / t); everything above is double: the matrix pipe adds the 2 x 16 sums of a block.  Steps
+                    // alternate between the two sums, so a sweep's terms are always split into its even and its odd segments -- which
+                    // of the two registers holds which depends on the group (seg0 may be odd), the two sets and their order do not, and
+                    // the two sums meet in a double addition: a record's sums are the same bits whatever window, group or launch it is
+                    // part of.  (Chains cut every 16 / 8 / 4 steps,
                     // each with a reduction of its own: +0 / +4 / +12 % kernel time at raster 256, error levels unchanged.)
                     float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
                     {
@@ -2037,11 +2039,18 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                             pp += 4 * SEG;
                             pf += (float)(4 * SEG);
                         }
-                        if (s < steps2) {  // (the last pair: already requested)
+                        if (const int rem = steps2 - s) {  // (the last one to three steps: two of them already requested)
+                            if (rem == 3) load(2, gC, pC);
                             visit(gA, pA, pf, a0, a1);
                             used(gA);
-                            visit(gB, pB, pf + (float)SEG, b0, b1);
-                            used(gB);
+                            if (rem >= 2) {
+                                visit(gB, pB, pf + (float)SEG, b0, b1);
+                                used(gB);
+                            }
+                            if (rem == 3) {
+                                visit(gC, pC, pf + (float)(2 * SEG), a0, a1);
+                                used(gC);
+                            }
                         }
                     }
                     A0 = __builtin_amdgcn_mfma_f64_4x4x4f64((double)a0, 1.0, 0.0, 0, 0, 0);

@@ -38,3 +38,4 @@ fi
 python scripts/parity_summary.py $R/parity_errors.jsonl $R/k6_numerics.jsonl $R/same_terms.txt > ${P}_parity_summary.md
 sed -i 's/[ \t]*$//' ${P}_same_terms.txt 2>/dev/null
 ls ${P}_* | wc -l
+python scripts/fill_profiles_readme.py > /dev/null
