@@ -1364,6 +1364,18 @@ __global__ __launch_bounds__(NT, MODE == K6_EXACT ? 4 : (NT == 256 ? k6::MINWAVE
     }
 }
 
+// k_bpm_row: how many of a line's n_parts waves (a power of two) share one of its windows -- n_parts over the number of windows
+// rounded up to a power of two, at least 1; lines of fewer than 32 segments (rasters below 481) keep a wave per window: their
+// sweeps are too short for the members' repeated set-up to pay (64 views at 384^2: +1.7 % with teams, 512^2: -1.7 %)
+__device__ __forceinline__ int window_team(int n_rec, int n_parts, int nsl)
+{
+    const int n_win = (n_rec + 63) >> 6;
+    if (nsl < 32) return 1;
+    int team = n_parts;
+    while (team > 1 && n_parts / team < n_win) team >>= 1;
+    return team;
+}
+
 // LDS hand-over between the lanes of ONE wave (its LDS operations execute in order; the fences keep the compiler from moving
 // accesses across)
 __device__ __forceinline__ void wave_lds_handover()
@@ -1541,7 +1553,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
     float4 qq_first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (wave < nld * n_parts) {
         const int ld = wave / n_parts, part = wave - ld * n_parts;
-        const int n_rec = band_lines[lt + ld], r = part * WIN + lane;
+        const int n_rec = band_lines[lt + ld], r = (part / window_team(n_rec, n_parts, nsl)) * WIN + lane;  // (shared windows: below)
         if (r < n_rec) {
             const BandLine *R = recs_b + band_start[lt + ld] + r;
             hh_first = *reinterpret_cast<const int4 *>(R);
@@ -1689,14 +1701,25 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
         const int base = ld * SP;
         float4 kc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if constexpr (!EXACT) kc = s_k[ld];
-        for (int w0 = part * WIN; w0 < n_rec; w0 += WIN * n_parts) {
+        // A line with fewer windows than its band gives it waves (bands narrower than the workgroup: rasters above 256, small
+        // launches; one or two windows of records per line are the rule on meshes of a few thousand faces): the waves form
+        // TEAMS that share a window instead of idling -- every member repeats the lane-per-record set-up (the records, the
+        // reference colours, the sort: the same result in each), member 0 walks the in sweeps and the out pixels, and the
+        // groups of phase B are dealt out in turn; every member flushes what it summed (a record's in and out parts may then
+        // arrive as two atomic additions instead of one).  The sums of a record are formed exactly as before, by whichever
+        // wave takes its group.  (K6 stage, us, teams off / on: 4 views at 1024^2 235 / 204, 32 views 1165 / 1028, 64 views at
+        // 768^2 1195 / 1154, at 512^2 508 / 500; the exact mode at 640^2 ... 1024^2 -15 ... -22 %.)
+        const int team = window_team(n_rec, n_parts, nsl), member = part & (team - 1), n_teams = n_parts / team;
+        const bool sweeps_mine = member == 0;
+        const int w_first = (part / team) * WIN;
+        for (int w0 = w_first; w0 < n_rec; w0 += WIN * n_teams) {
             const int nw = min(WIN, n_rec - w0);
             // ---- phase A: lane = record.  The lane keeps its record for the flush, walks the record's in sweep, and prepares what
             // its block will be handed in phase B: the reference colour of the OUT sweep (the in pixel, :594-601) minus K, |c0|
             // (carrying the direction in its sign bit), |c1|, -direction * crossing point, the number of segments of the sweep.
             int4 hh = hh_first;
             float4 qq = qq_first;
-            if (!(vt == wave && w0 == part * WIN)) {  // (not the window requested in front of the staging)
+            if (!(vt == wave && w0 == w_first)) {  // (not the window requested in front of the staging)
                 hh = make_int4(1, 1, 0, 0);
                 qq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (lane < nw) {
@@ -1742,7 +1765,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                 return d;
             };
             float f0 = 0.0f, f1 = 0.0f;  // the out pixel's terms (magnitudes: the sign goes on at the flush, with the out sweep's)
-            if (has_out && !EXACT) {  // (the exact mode: phase B walks the whole out sweep)
+            if (has_out && !EXACT && sweeps_mine) {  // (the exact mode: phase B walks the whole out sweep)
                 const float d = direct_diff(c_out, c_in, base + d1_out);                           // :631-638
                 const float dm = !(d <= 0.0f) ? d : 0.0f;                                           // :647
                 const float t = fabsf((float)d1_out - qq.x);
@@ -1759,7 +1782,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                 // (tests/test_fuzz_gpu.py, seed 118: the term of such a pixel was missing, 27 % of a corner face's gradient).
                 const int d1_2 = d1_out + (dpos ? 1 : -1);
                 const float t2 = fabsf((float)d1_2 - qq.x);
-                if (has_b && t2 <= 1.0f) {
+                if (has_b && t2 <= 1.0f && sweeps_mine) {
                     const int l = base + d1_2;
                     float4 g4;
                     if constexpr (RGB) g4 = lds_px4(s_g + 4 * (size_t)l);
@@ -1780,7 +1803,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
             const int nseg = has_b ? (dpos ? nsl - (b_from >> 4) : (b_to >> 4) + 1) : 0;
             hist[lane] = 0;
             double in0 = 0.0, in1 = 0.0;
-            if (has_in && !(NR_ROW_OFF & 2)) {
+            if (has_in && !(NR_ROW_OFF & 2) && sweeps_mine) {
                 const float cross = qq.x, c0k = qq.y, c1k = qq.z;
                 const int fnr = __float_as_int(qq.w);
                 const float d_first = EXACT ? 0.0f : direct_diff(c_in, c_out, base + d1_in);
@@ -1895,11 +1918,12 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
             const int v_nseg = EXACT ? (dpos ? nseg : -nseg) : nseg;
             float4 oref_b = oref;  // the out sweep's reference colour as the blocks use it: minus K, or as it is (exact mode)
             if constexpr (EXACT) oref_b = c_in;
-            int src_next = __builtin_amdgcn_ds_bpermute(row << 2, inv);
-            for (int g0 = 0; g0 < ((NR_ROW_OFF & 1) ? 0 : n_out); g0 += 4) {
+            const int g_first = 4 * member, g_step = 4 * team;  // (a shared window: every team-th group)
+            int src_next = __builtin_amdgcn_ds_bpermute(((g_first + row) & 63) << 2, inv);
+            for (int g0 = g_first; g0 < ((NR_ROW_OFF & 1) ? 0 : n_out); g0 += g_step) {
                 const bool act = g0 + row < n_out;
                 const int src = src_next;  // (of a block without a record: some lane; nothing of it is used)
-                src_next = __builtin_amdgcn_ds_bpermute(((g0 + 4 + row) & 63) << 2, inv);
+                src_next = __builtin_amdgcn_ds_bpermute(((g0 + g_step + row) & 63) << 2, inv);
                 const int sa = src << 2;
                 const int r_nseg_s = __builtin_amdgcn_ds_bpermute(sa, v_nseg);
                 const int r_nseg = EXACT ? abs(r_nseg_s) : r_nseg_s;
@@ -2069,7 +2093,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
             // :718 / :723): a contribution whose vertex sits on the line is not taken (its coefficient was Inf / NaN).
             if (lane < nw) {
                 double2 a = make_double2(0.0, 0.0);
-                if (has_b) a = acc[lane];
+                if (has_b && ((pos >> 2) & (team - 1)) == member) a = acc[lane];  // (the wave that walked the record's group)
                 a.x += (double)f0;
                 a.y += (double)f1;
                 const bool tneg = !dpos;
