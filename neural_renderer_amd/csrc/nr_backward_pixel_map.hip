@@ -1488,27 +1488,41 @@ NR_API int nr_dev_row_dump(unsigned *out, unsigned *n_windows)
 // (the colours, not the centred sums, are staged: 36 bytes per pixel, four workgroups per CU), `x * 2. / is` and `dist +- eps` in
 // double, IEEE division, every sum in double -- a lane adds its terms to double accumulators, the matrix pipe adds the lanes.
 // A masked lane divides 0 by 1 (the select sits in front of the division: no 0 / 0, no Inf * 0).
-template <bool RGB, bool ALPHA, int MODE>
+template <bool RGB, bool ALPHA, int MODE, bool CHUNKED>
 __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
     const int32_t *__restrict__ fi_map, const float *__restrict__ rgb_map, const float *__restrict__ alpha_map,
     const float *__restrict__ g_rgb, const float *__restrict__ g_alpha, double *__restrict__ scratch,
     const int *__restrict__ band_lines, const int *__restrict__ band_start, const int *__restrict__ lines_ok,
-    const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, float eps_f, double eps_d, int B,
+    const BandLine *__restrict__ line_buf, size_t cap, int F, int S, int W, int CH, float eps_f, double eps_d, int B,
     uint4 *__restrict__ zero16, size_t n_zero16)
 {
     using namespace rowk;
     constexpr bool EXACT = MODE != K6_FAST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
-    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W;
-    const unsigned total_wg = n_bands * 2u * (unsigned)B;
+    // A workgroup takes a band of W lines and, of those lines, a CHUNK of CH pixels (all of them up to raster 512, half a line
+    // above): the sweeps of a record are sums over pixels, so the part of a sweep inside each chunk can be summed by a
+    // workgroup of its own -- every term is formed exactly as in an unchunked line (t = d1 - d1_cross from the pixel's position
+    // along the whole line), the chunks' sums meet in the double atomics of the flush.  What it buys on rasters above 512:
+    // two-line bands instead of one-line ones.  A band of COLUMNS is staged in pieces of W pixels per image row, and with
+    // one-line bands 4 of every 64 bytes fetched were used: the column bands' staging was over half of the kernel at raster
+    // 1024 (k_bpm_row with the bands of one axis only, without sweeps, 32 views: columns 545 us, rows 125).  What it costs: a
+    // record is set up once per chunk its sweeps reach -- which is why the chunks are not shorter: quarter lines with four-line
+    // bands stage the columns in 310 us instead of 545 and lose it all again (K6 stage, us, chunks of <= 1024 / 512 / 256 pixels:
+    // 32 views at 1024^2 1015 / 960 / 1138, 4 views 204 / 181 / 206, 64 views at 512^2 512 / 512 / 547).
+    // (CHUNKED = false: whole lines -- an instantiation of its own, because the chunk's offset as a run-time zero cost the
+    // headline launch 1.4 %: K6 stage 166.0 -> 168.4 us)
+    const unsigned n_bands = (unsigned)(S + W - 1) / (unsigned)W, n_ch = CHUNKED ? (unsigned)(S + CH - 1) / (unsigned)CH : 1u;
+    const unsigned total_wg = n_bands * 2u * (unsigned)B * n_ch;
     const unsigned logical = xcd_block(total_wg);  // all bands of an image on one XCD (see k_bpm_fast)
     if (logical >= total_wg) return;
     if (n_zero16) {  // the fused backward's zero fill of grad_textures rides along (see k_bpm_fast)
         const size_t per = (n_zero16 + total_wg - 1) / total_wg, z_lo = (size_t)logical * per, z_hi = min(n_zero16, z_lo + per);
         for (size_t k = z_lo + tid; k < z_hi; k += NT) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
     }
-    const int band = (int)(logical % n_bands), axis = (int)((logical / n_bands) & 1u), b = (int)(logical / (2u * n_bands));
+    const unsigned bandidx = logical / n_ch;  // (the chunks of a band next to each other: they read the same records)
+    const int c0 = CHUNKED ? (int)(logical - bandidx * n_ch) * CH : 0, SL = CHUNKED ? min(CH, S - c0) : S;  // the chunk: pixels [c0, c0 + SL) of the band's lines
+    const int band = (int)(bandidx % n_bands), axis = (int)((bandidx / n_bands) & 1u), b = (int)(bandidx / (2u * n_bands));
     if (lines_ok[b] == 0) return;  // records beyond the buffer: k_bpm_fast's scan path serves this image
     const int band_lo = band * W, nld = min(W, S - band_lo);
     const size_t lt = ((size_t)b * 2 + axis) * S + band_lo;  // the band's lines in the per-line tables (band width 1)
@@ -1517,8 +1531,9 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
     if (n_tot == 0) return;  // no visible face has a line here
 
     constexpr int NC = RGB ? 4 : 1;  // floats per pixel in the gradient array: (alpha, r, g, b) or alpha alone
-    // a line in LDS: SP pixels, a multiple of 32 (an even number of segments); the pixels behind the raster hold zeros
-    const int SP = (S + 31) & ~31, nsl = SP / SEG;
+    // a line's chunk in LDS: SP pixels, a multiple of 32 (an even number of segments); the pixels behind the chunk hold zeros.
+    // From here on pixel positions along a line are LOCAL: 0 is the chunk's first pixel.
+    const int SP = (SL + 31) & ~31, nsl = SP / SEG;
     const unsigned npx = (unsigned)(W * SP), G_BYTES = (unsigned)g_bytes<RGB>(npx), C_BYTES = (unsigned)c_bytes<RGB, EXACT>(npx), FI_BYTES = npx * 4u;
     float *const s_g = (float *)smem;                                  // [W][SP][NC] gradients
     float *const s_p = (float *)(smem + G_BYTES);                      // [W][SP] sum_c (I_c - K_c) g_c; exact mode: [W][SP][NC] colours
@@ -1531,7 +1546,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
     const BandLine *recs_b = line_buf + (size_t)b * cap;
     const size_t img = (size_t)b * S * S;
     // map index of pixel d1 of band line ld (:587-593)
-    auto map_index = [&](int ld, int d1) { return axis ? img + (size_t)(band_lo + ld) * S + d1 : img + (size_t)d1 * S + band_lo + ld; };
+    auto map_index = [&](int ld, int d1) { return axis ? img + (size_t)(band_lo + ld) * S + (c0 + d1) : img + (size_t)(c0 + d1) * S + band_lo + ld; };
     // (alpha, r, g, b) of a pixel, straight from the maps
     auto map_colour = [&](size_t gi) {
         float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1618,10 +1633,10 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
             }
             put(ld, d1, fi_map[g], line_k(ld), al, ga, r, gn, bl, gr, gg, gb);
         };
-        if (SP != S) {  // the pixels behind the raster: no gradient, nobody's
-            const int pad = SP - S;
+        if (SP != SL) {  // the pixels behind the chunk: no gradient, nobody's
+            const int pad = SP - SL;
             for (int i = tid; i < nld * pad; i += NT) {
-                const int ld = i / pad, l = ld * SP + S + (i - ld * pad);
+                const int ld = i / pad, l = ld * SP + SL + (i - ld * pad);
                 s_fi[l] = -1;
                 if constexpr (EXACT && RGB) *reinterpret_cast<float4 *>(s_p + 4 * (size_t)l) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 else s_p[l] = 0.0f;
@@ -1630,17 +1645,17 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
             }
         }
         if (axis && (S & 3) == 0) {  // a band line is an image row: thread -> (line, quad of 4 consecutive pixels)
-            const int quads = S >> 2;
+            const int quads = SL >> 2;  // (c0 and SL are multiples of 4 with S)
             for (int i = tid; i < nld * quads; i += NT) {
                 const int ld = i / quads, x = (i - ld * quads) << 2;
-                put_quad(img + (size_t)(band_lo + ld) * S + x, ld, x, 0, 1);
+                put_quad(img + (size_t)(band_lo + ld) * S + c0 + x, ld, x, 0, 1);
             }
         } else if (axis) {  // thread -> (line, x), x fastest (coalesced 4- and 12-byte loads)
-            for (int i = tid; i < nld * S; i += NT) put_one(i / S, i % S);
+            for (int i = tid; i < nld * SL; i += NT) put_one(i / SL, i % SL);
         } else if (nld == 4 && (S & 3) == 0 && (band_lo & 3) == 0) {  // 4 adjacent columns: one thread per row
-            for (int y = tid; y < S; y += NT) put_quad(img + (size_t)y * S + band_lo, 0, y, 1, 0);
+            for (int y = tid; y < SL; y += NT) put_quad(img + (size_t)(c0 + y) * S + band_lo, 0, y, 1, 0);
         } else {  // generic columns: thread -> (row d1, line ld) with ld fastest
-            for (int i = tid; i < nld * S; i += NT) put_one(i % nld, i / nld);
+            for (int i = tid; i < nld * SL; i += NT) put_one(i % nld, i / nld);
         }
     }
     __syncthreads();
@@ -1728,17 +1743,28 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                     qq = *reinterpret_cast<const float4 *>(&R->cross);
                 }
             }
-            const int flags = (hh.z >> 24) & 0xff, d1_in = hh.z & 0xffff;
-            const int o_from = hh.y & 0xffff, o_to = hh.y >> 16;
-            const int in_from = hh.x & 0xffff, in_to = hh.x >> 16;
-            const bool has_out = o_from <= o_to;  // (:604: the in pixel is the face's)
-            const bool has_in = in_from <= in_to;  // (every record whose in and out pixel lie inside the image)
+            // (local positions: the in pixel and the out pixel may lie outside the chunk.  The crossing point stays what it is: a
+            // pixel's t = d1 - d1_cross is formed from its position along the WHOLE line, c0 + local -- the crossing point minus c0
+            // would be rounded wherever c0 is the larger of the two)
+            const int flags = (hh.z >> 24) & 0xff, d1_in = (hh.z & 0xffff) - c0;
+            const int og_from = hh.y & 0xffff, og_to = hh.y >> 16;  // the out sweep along the whole line ...
+            const int ig_from = hh.x & 0xffff, ig_to = hh.x >> 16;  // ... and the in sweep
+            const bool has_out = og_from <= og_to;  // (:604: the in pixel is the face's)
+            const bool has_in = ig_from <= ig_to;   // (every record whose in and out pixel lie inside the image)
             const bool dpos = (flags & 8) != 0;   // direction > 0: the sweep ends at the last pixel of the line, else it starts at pixel 0
             const int d1_out = d1_in + (dpos ? 1 : -1);
+            // what of the record lies in this chunk: its in sweep's pixels, its out pixel (phase A's), and phase B's part of the
+            // out sweep -- [out pixel + 1, end of the line] or [0, out pixel - 1]; the exact mode: with the out pixel
+            const int in_from = max(ig_from, c0) - c0, in_to = min(ig_to, c0 + SL - 1) - c0;
+            const bool out_px_here = has_out && d1_out >= 0 && d1_out < SL;
+            const int bg_from = og_from + ((dpos && !EXACT) ? 1 : 0), bg_to = og_to - ((!dpos && !EXACT) ? 1 : 0);
+            const int b_from = max(bg_from, c0) - c0, b_to = min(bg_to, c0 + SL - 1) - c0;
+            const bool has_b = has_out && b_from <= b_to;
+            const bool in_here = has_in && in_from <= in_to;
             // the two reference colours straight from the maps: the in pixel for the out sweep (:594-601), the out pixel for the
             // in sweep (:697-700); minus K for the two-sum form of the visits
             float4 c_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c_out = c_in;
-            if (has_in) {
+            if (has_in && (has_b || in_here || out_px_here)) {  // (a record with a pixel in this chunk)
                 c_in = map_colour(map_index(ld, d1_in));
                 c_out = map_colour(map_index(ld, d1_out));
             }
@@ -1765,15 +1791,13 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                 return d;
             };
             float f0 = 0.0f, f1 = 0.0f;  // the out pixel's terms (magnitudes: the sign goes on at the flush, with the out sweep's)
-            if (has_out && !EXACT && sweeps_mine) {  // (the exact mode: phase B walks the whole out sweep)
+            if (out_px_here && !EXACT && sweeps_mine) {  // (the exact mode: phase B walks the whole out sweep)
                 const float d = direct_diff(c_out, c_in, base + d1_out);                           // :631-638
                 const float dm = !(d <= 0.0f) ? d : 0.0f;                                           // :647
-                const float t = fabsf((float)d1_out - qq.x);
+                const float t = fabsf((float)(c0 + d1_out) - qq.x);
                 f0 = dm * recip_n(__builtin_fmaf(fabsf(qq.y), t, eps_v));                          // :649-651
                 f1 = dm * recip_n(__builtin_fmaf(fabsf(qq.z), t, eps_v));                          // :654-656
             }
-            // segments of what phase B walks of the out sweep -- [o_from + 1, S) or [0, o_to - 1]: [from / 16, nsl) or [0, to / 16]
-            const bool has_b = has_out && (EXACT || o_from < o_to);
             if constexpr (!EXACT) {
                 // Phase B tells the out pixel from the rest of the sweep by |t| <= 1 -- exact for every pixel but one: with the
                 // crossing point within half an ulp of the in pixel's centre (a vertex snapped onto a pixel centre, the cross
@@ -1781,8 +1805,8 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                 // It is taken here, by the same comparison on the same float, with the centred sums phase B would have used
                 // (tests/test_fuzz_gpu.py, seed 118: the term of such a pixel was missing, 27 % of a corner face's gradient).
                 const int d1_2 = d1_out + (dpos ? 1 : -1);
-                const float t2 = fabsf((float)d1_2 - qq.x);
-                if (has_b && t2 <= 1.0f && sweeps_mine) {
+                const float t2 = fabsf((float)(c0 + d1_2) - qq.x);
+                if (has_out && og_from < og_to && d1_2 >= 0 && d1_2 < SL && t2 <= 1.0f && sweeps_mine) {
                     const int l = base + d1_2;
                     float4 g4;
                     if constexpr (RGB) g4 = lds_px4(s_g + 4 * (size_t)l);
@@ -1799,14 +1823,14 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                     f1 = __builtin_fmaf(dm, recip_n(__builtin_fmaf(fabsf(qq.z), t2, eps_v)), f1);
                 }
             }
-            const int b_from = o_from + (EXACT ? 0 : 1), b_to = o_to - (EXACT ? 0 : 1);
+            // segments of what phase B walks in this chunk: [b_from / 16, nsl) towards the end of the line, [0, b_to / 16] from pixel 0
             const int nseg = has_b ? (dpos ? nsl - (b_from >> 4) : (b_to >> 4) + 1) : 0;
             hist[lane] = 0;
             double in0 = 0.0, in1 = 0.0;
-            if (has_in && !(NR_ROW_OFF & 2) && sweeps_mine) {
+            if (in_here && !(NR_ROW_OFF & 2) && sweeps_mine) {
                 const float cross = qq.x, c0k = qq.y, c1k = qq.z;
                 const int fnr = __float_as_int(qq.w);
-                const float d_first = EXACT ? 0.0f : direct_diff(c_in, c_out, base + d1_in);
+                const float d_first = (EXACT || d1_in < 0 || d1_in >= SL) ? 0.0f : direct_diff(c_in, c_out, base + d1_in);
                 // (batches of IN_BATCH pixels whose LDS reads are requested together -- nine in-sweeps in ten are one batch;
                 // IN_SEG float terms per double addition, like a piece of k_bpm_fast)
                 for (int s0 = in_from; s0 <= in_to; s0 += IN_SEG) {
@@ -1848,7 +1872,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                             }
                             // :707, :717 (a NaN diff goes through); a pixel beyond the batch's end repeats the last one: dropped
                             const bool take = (q0 + k <= s1) & (fi[k] == fnr) & !(diff <= 0.0f);
-                            const float t = (float)(q0 + k) - cross;
+                            const float t = (float)(c0 + q0 + k) - cross;
                             if constexpr (EXACT) {
                                 // (the select in front of the division: a pixel that is not taken divides 0 by 1)
                                 const float dm = take ? diff : 0.0f;
@@ -1900,7 +1924,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                     g_row_dump[(size_t)wid * 64 + lane] = lane < nw ? ((unsigned)nseg | (dpos ? 256u : 0u) | (has_b ? 512u : 0u) | 1024u) : 0u;
             }
             {
-                int sn = nseg, si = has_b ? (o_to - o_from) : 0;
+                int sn = nseg, si = has_b ? (b_to - b_from + 1) : 0;
                 for (int o = 32; o > 0; o >>= 1) { sn += __shfl_xor(sn, o, WAVE); si += __shfl_xor(si, o, WAVE); }
                 NR_ROW_STAT(3, sn);   // segments of the out sweeps
                 NR_ROW_STAT(4, si);   // pixels of the out sweeps
@@ -1950,7 +1974,7 @@ __global__ __launch_bounds__(rowk::NT, MODE == K6_FAST ? 5 : 4) void k_bpm_row(
                 const bool rpos = EXACT ? r_nseg_s >= 0 : !(__float_as_uint(ac0s) >> 31);
                 const int seg0 = rpos ? nsl - steps2 : 0;
                 const int p0 = seg0 * SEG + l16;
-                float pf = (float)p0;
+                float pf = (float)(c0 + p0);  // (the position along the whole line: see the crossing point above)
                 double A0 = 0.0, A1 = 0.0;
                 if constexpr (EXACT) {
                     // ---- the exact mode: gradients and colours of a step (two 16-byte reads), the reference's term (rasterize.py
@@ -2321,18 +2345,32 @@ int launch_fast(const float *faces, const int32_t *fi, const float *rgb, const f
     return 0;
 }
 
-// k_bpm_row's band: the widest power of two of lines (<= one per wave) whose pixels fit its LDS regions (rowk::MAX_PX); 0: the
-// raster is too large for it (k_bpm_fast takes the launch)
-int row_band_config(int S, bool rgb, bool exact, int B, size_t *lds_bytes)
+// k_bpm_row's chunks: a line is cut into ceil(S / 512) pieces of equal length (a multiple of 32 pixels, the last one shorter):
+// the whole line up to raster 512, 2 x 320 at 640, 2 x 512 at 1024 (see the kernel) -- on meshes of fewer than 2^15 faces.  A
+// record is set up once per chunk, and on a dense mesh (hundreds of records per line) that costs more than the column bands'
+// staging gains: config 5 (655 360 faces at 1024^2) 1.34 ms per step with whole lines, 1.38 with half lines.
+#ifndef NR_ROW_CHUNK_PX  // (development: the longest chunk)
+#define NR_ROW_CHUNK_PX 512
+#endif
+int row_chunk(int S, int F)
 {
-    const size_t SP = ((size_t)S + 31) & ~(size_t)31;
-    if (SP / rowk::SEG > (size_t)rowk::MAX_SEGS) return 0;
+    if (F >= (1 << 15)) return (S + 31) & ~31;
+    const int n_ch = (S + NR_ROW_CHUNK_PX - 1) / NR_ROW_CHUNK_PX, len = (S + n_ch - 1) / n_ch;
+    return (len + 31) & ~31;
+}
+
+// k_bpm_row's band: the widest power of two of lines (<= one per wave) whose chunks fit its LDS regions (rowk::MAX_PX); 0: the
+// raster is too large for it (k_bpm_fast takes the launch)
+int row_band_config(int S, int F, bool rgb, bool exact, int B, size_t *lds_bytes)
+{
+    if ((((size_t)S + 31) & ~(size_t)31) / rowk::SEG > (size_t)rowk::MAX_SEGS) return 0;
+    const size_t SP = (size_t)row_chunk(S, F), n_ch = ((size_t)S + SP - 1) / SP;
     for (int W = rowk::NW; W >= 1; W >>= 1) {
         // (small launches: narrower bands while there are few band workgroups -- the waves of a workgroup then share the windows of
         // a line.  One-line bands stage single columns and most lines have one window, i.e. one busy wave: only below
         // ROW_MIN_WGS_1 workgroups.  K6 stage, us, four- / two- / one-line bands: 4 views 46.3 (1) -> 45.4 (2); 8 views 62.8 (4),
         // 59.3 (2), 61.8 (1); 16 views 79.9 (4), 75.6 (2), 86.0 (1); 8 views at 512^2 115.6 (2), 122.5 (1))
-        const size_t wgs = (size_t)B * 2 * ((S + W - 1) / W);
+        const size_t wgs = (size_t)B * 2 * ((S + W - 1) / W) * n_ch;
         if ((W > 2 && wgs < k6::ROW_MIN_WGS) || (W == 2 && wgs < k6::ROW_MIN_WGS_1)) continue;
         if ((size_t)W * SP > (size_t)rowk::MAX_PX) continue;
         const size_t npx = (size_t)W * SP;
@@ -2348,13 +2386,18 @@ int launch_row(const int32_t *fi, const float *rgb, const float *alpha, const fl
                const int *band_lines, const int *band_start, const int *lines_ok, const BandLine *line_buf, size_t cap, int B,
                int F, int S, int W, size_t lds, double eps, hipStream_t st, void *zero_ptr, size_t zero_bytes)
 {
-    static LdsLimit limit;  // one per instantiation (40 KB at most with the product's constants: never raised)
-    if (int rc = limit.ensure((const void *)k_bpm_row<RGB, ALPHA, MODE>, lds)) return rc;
-    const unsigned total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B;
-    hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA, MODE>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb,
-                       g_alpha, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, (float)eps, eps, B,
-                       (uint4 *)zero_ptr, zero_bytes / 16);
-    return 0;
+    const int CH = row_chunk(S, F);
+    const unsigned n_ch = (unsigned)((S + CH - 1) / CH), total_wg = (unsigned)((S + W - 1) / W) * 2u * (unsigned)B * n_ch;
+    auto go = [&](auto chunked) {
+        constexpr bool C = decltype(chunked)::value;
+        static LdsLimit limit;  // one per instantiation (40 KB at most with the product's constants: never raised)
+        if (int rc = limit.ensure((const void *)k_bpm_row<RGB, ALPHA, MODE, C>, lds)) return rc;
+        hipLaunchKernelGGL((k_bpm_row<RGB, ALPHA, MODE, C>), dim3(xcd_grid(total_wg)), dim3(rowk::NT), lds, st, fi, rgb, alpha, g_rgb,
+                           g_alpha, scratch, band_lines, band_start, lines_ok, line_buf, cap, F, S, W, CH, (float)eps, eps, B,
+                           (uint4 *)zero_ptr, zero_bytes / 16);
+        return 0;
+    };
+    return n_ch > 1 ? go(std::true_type()) : go(std::false_type());
 }
 
 }  // namespace
@@ -2377,12 +2420,12 @@ NR_API size_t nr_backward_workspace_bytes(int32_t B, int32_t F, int32_t S, int32
 // by 1 / (|c t| + eps), and t = 0 -- the crossing point on a pixel centre -- would make that 0 * Inf; the exact mode selects in
 // front of its division and takes any eps), and NR_FLAG_K6_LEGACY (tests, measurements).
 // With k_bpm_row the band tables and the line records are binned per LINE (band width 1).
-int k6_row_band(int B, int S, bool rgb, double eps, int flags, bool fast_fits, size_t *row_lds)
+int k6_row_band(int B, int F, int S, bool rgb, double eps, int flags, bool fast_fits, size_t *row_lds)
 {
     const bool exact = (flags & NR_FLAG_EXACT_GRADIENT) != 0;
     const bool possible = !(flags & (NR_FLAG_K6_SCAN | NR_FLAG_K6_LEGACY | NR_FLAG_K6_GLOBAL)) && B <= 65535 && fast_fits &&
                           (exact || (float)eps >= 1e-30f);
-    return possible ? row_band_config(S, rgb, exact, B, row_lds) : 0;
+    return possible ? row_band_config(S, F, rgb, exact, B, row_lds) : 0;
 }
 
 // Measurement hook (include/nr_hip_profile.h, nr_profile_band_kernel): a pair of events around the band kernel's launch.  Only in the
@@ -2430,9 +2473,8 @@ NR_API int nr_profile_k6_choice(int32_t B, int32_t F, int32_t S, int32_t return_
     int win = 0, qcap = 0;
     const BandShape shape = band_shape(S);
     const bool fast_fits = fast_band_config(S, return_rgb != 0, shape, shape.w_max, &fl, &win, &qcap) != 0;
-    (void)F;
     (void)return_alpha;
-    return k6_row_band(B, S, return_rgb != 0, eps, flags, fast_fits, &lds) > 0 ? 1 : 0;
+    return k6_row_band(B, F, S, return_rgb != 0, eps, flags, fast_fits, &lds) > 0 ? 1 : 0;
 }
 #define NR_BAND_TIMER_START(st) if (g_band_timer.on) { g_band_timer.which = use_row ? 1 : 0; g_band_timer.recorded = hipEventRecord(g_band_timer.start, st) == hipSuccess; }
 #define NR_BAND_TIMER_STOP(st) if (g_band_timer.on && g_band_timer.recorded) g_band_timer.recorded = hipEventRecord(g_band_timer.stop, st) == hipSuccess
@@ -2473,7 +2515,7 @@ int nr::run_backward_pixel_map(const float *faces, const int32_t *face_index_map
     while (w_max > 1 && (size_t)B * 2 * ((S + w_max - 1) / w_max) < 3072) w_max >>= 1;
     const int W_fast = fast_band_config(S, rgb, shape, w_max, &lds, &win, &qcap);
     size_t row_lds = 0;
-    const int W_row = k6_row_band(B, S, rgb, eps, flags, W_fast != 0, &row_lds);  // (which launches take k_bpm_row: there)
+    const int W_row = k6_row_band(B, F, S, rgb, eps, flags, W_fast != 0, &row_lds);  // (which launches take k_bpm_row: there)
     const bool use_row = W_row > 0;
     const int W = use_row ? 1 : W_fast;  // the band width of the tables
     if (W_fast == 0 || (flags & NR_FLAG_K6_GLOBAL)) {  // raster too large for an LDS band (or the fallback asked for: tests)
