@@ -37,7 +37,12 @@ def _same(parts, full, names):
     the lanes' float sums; the double atomics that add a face's records round to the same float)."""
     for k, name in enumerate(names):
         got = np.concatenate((parts[0][k], parts[1][k]))
-        np.testing.assert_array_equal(got, full[k], err_msg=name)
+        if name == 'grad_faces':
+            # (the double atomics arrive in another order in a shard: a sum that sits within 1e-16 of a float rounding point may
+            # come out one ulp apart -- seen in no run, allowed in two entries so that the suite cannot flake on it)
+            assert int((got != full[k]).sum()) <= 2 and H.rel_err(got, full[k]) <= 1e-6, name
+        else:
+            np.testing.assert_array_equal(got, full[k], err_msg=name)
 
 
 def test_two_shards_equal_one_batch_through_the_c_abi():
